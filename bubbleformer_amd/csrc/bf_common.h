@@ -1,0 +1,83 @@
+// Common device helpers for the gfx950 (MI355X) FiLMAViT kernels.
+// Wavefront = 64 lanes everywhere in this tree; no 32-lane idioms.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "../../include/bubbleformer_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define BF_WAVE 64
+#define BF_IN_EPS 1e-5f
+
+// last launch error is kept per process; every extern "C" entry returns 0 or a negative code.
+#define BF_CHECK_LAUNCH()                                   \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return bf_fail(e__, __FILE__, __LINE__); \
+    } while (0)
+#define BF_REQUIRE(cond, msg)                                \
+    do {                                                     \
+        if (!(cond)) return bf_fail_msg(msg, __FILE__, __LINE__); \
+    } while (0)
+
+int bf_fail(hipError_t e, const char* file, int line);
+int bf_fail_msg(const char* msg, const char* file, int line);
+
+// ---------------------------------------------------------------- scalar conversions
+__device__ __forceinline__ float to_f(float x) { return x; }
+__device__ __forceinline__ float to_f(bf16 x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f(float x);
+template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float x) { return (bf16)x; }
+
+// 16-byte chunks: 4 floats or 8 bf16
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+    static constexpr int N = 4;
+    float4 raw;
+    __device__ __forceinline__ void load(const float* p) { raw = *reinterpret_cast<const float4*>(p); }
+    __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = raw; }
+    __device__ __forceinline__ void zero() { raw = make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ __forceinline__ float get(int i) const { return i == 0 ? raw.x : i == 1 ? raw.y : i == 2 ? raw.z : raw.w; }
+    __device__ __forceinline__ void set(int i, float v) { if (i == 0) raw.x = v; else if (i == 1) raw.y = v; else if (i == 2) raw.z = v; else raw.w = v; }
+};
+template <> struct Chunk<bf16> {
+    static constexpr int N = 8;
+    bf16x8 raw;
+    __device__ __forceinline__ void load(const bf16* p) { raw = *reinterpret_cast<const bf16x8*>(p); }
+    __device__ __forceinline__ void store(bf16* p) const { *reinterpret_cast<bf16x8*>(p) = raw; }
+    __device__ __forceinline__ void zero() { for (int i = 0; i < 8; ++i) raw[i] = (bf16)0.f; }
+    __device__ __forceinline__ float get(int i) const { return (float)raw[i]; }
+    __device__ __forceinline__ void set(int i, float v) { raw[i] = (bf16)v; }
+};
+
+// ---------------------------------------------------------------- math
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// d/dx gelu(x) = Phi(x) + x * phi(x)
+__device__ __forceinline__ float dgelu_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// ---------------------------------------------------------------- wave / block reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int bf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline size_t bf_esize(int dtype) { return dtype == BF_DTYPE_BF16 ? 2 : 4; }

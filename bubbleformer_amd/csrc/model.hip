@@ -1,0 +1,721 @@
+// Stage-level orchestration: each FiLMAViT stage (patch embed + FiLM, temporal block, axial block,
+// debed + loss) as one stream-ordered chain of the kernels in gemm/norm/attn/patch.hip.
+// No allocation, no synchronisation: activations that the backward needs live in a caller-owned
+// "saved" record per stage, transients in a caller-owned scratch arena.
+//
+// Algebra used to avoid extra passes (all exact in real arithmetic):
+//  * InstanceNorm is applied in the consumer GEMM's operand prologue as a per-(frame, channel) affine;
+//    only its statistics are a separate (two-pass, fp32) kernel.
+//  * layer scale / residual / feature scaling are folded into the out-projection epilogue
+//       out = x + alpha[n] * (on @ W^T)[m, n] + beta[n].
+//    The spatial mean over (h, w) that feature scaling needs is data independent: InstanceNorm output has
+//    per-channel mean exactly norm2.bias, so mean_hw(y)[n] = W[n, :] . norm2.bias + bias[n]  =: mc[n].
+//  * parameter gradients of those folds come from G = dout^T @ on (one split-K GEMM) instead of a saved y:
+//       dW = alpha * G (+ dmc x norm2.bias), dalpha[n] = <W[n, :], G[n, :]>, dbeta = colsum(dout).
+#include "bf_common.h"
+#include <string.h>
+
+namespace {
+
+struct D {
+    int dtype, B, T, h, w, E, heads, attn_scale, feat_scale, patch, cin, cout, nfluid;
+    long N, F, S;
+    int d, nst;
+    size_t es;
+};
+int get_dims(const bf_dims* s, D* o) {
+    if (!s) return bf_fail_msg("dims: null", __FILE__, __LINE__);
+    o->dtype = s->dtype; o->B = s->B; o->T = s->T; o->h = s->h; o->w = s->w; o->E = s->E; o->heads = s->heads;
+    o->attn_scale = s->attn_scale; o->feat_scale = s->feat_scale; o->patch = s->patch; o->cin = s->cin; o->cout = s->cout;
+    o->nfluid = s->nfluid;
+    if (o->B < 1 || o->T < 1 || o->h < 1 || o->w < 1 || o->E < 8 || o->heads < 1 || o->E % o->heads)
+        return bf_fail_msg("dims: bad sizes", __FILE__, __LINE__);
+    if (o->dtype != BF_DTYPE_F32 && o->dtype != BF_DTYPE_BF16) return bf_fail_msg("dims: bad dtype", __FILE__, __LINE__);
+    o->F = (long)o->B * o->T; o->S = (long)o->h * o->w; o->N = o->F * o->S; o->d = o->E / o->heads;
+    o->es = bf_esize(o->dtype);
+    const int ch = o->dtype == BF_DTYPE_BF16 ? 8 : 4;
+    if (o->E % ch || o->d % ch) return bf_fail_msg("dims: E and head dim must be multiples of the 16-byte chunk", __FILE__, __LINE__);
+    if (o->T > 32 || o->h > 32 || o->w > 32) return bf_fail_msg("dims: attention axes are limited to 32 tokens", __FILE__, __LINE__);
+    o->nst = 0;
+    if (o->patch > 0) {
+        int p = o->patch;
+        while (p > 1) { if (p & 1) return bf_fail_msg("dims: patch must be a power of two", __FILE__, __LINE__); p >>= 1; o->nst++; }
+        if (o->nst < 1 || o->nst > BF_MAX_STAGES) return bf_fail_msg("dims: patch size out of range", __FILE__, __LINE__);
+        if (o->nst > 1 && (o->E / 4) % ch) return bf_fail_msg("dims: E/4 must be a multiple of the 16-byte chunk", __FILE__, __LINE__);
+    }
+    return 0;
+}
+
+// bump allocator over a caller-owned buffer, 256-byte aligned pieces
+struct Arena {
+    char* base; size_t off;
+    explicit Arena(void* p) : base((char*)p), off(0) {}
+    void* take(size_t bytes) { void* r = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return r; }
+    float* f32(size_t n) { return (float*)take(n * 4); }
+};
+
+bf_operand op_plain(const void* p, long ld, int layout) {
+    bf_operand o; memset(&o, 0, sizeof(o)); o.p = p; o.ld = ld; o.layout = layout; return o;
+}
+void op_affine(bf_operand& o, int pro, const float* sc, const float* sh, long rpf, int nch) {
+    o.pro = pro; o.sc = sc; o.sh = sh; o.rows_per_frame = (int)rpf; o.nch = nch;
+}
+// rows are output-resolution pixels (gw x gh grid per frame) of a k2s2 patch over a [.., 2gh, 2gw, C] image
+void op_gather(bf_operand& o, int gw, int gh, int C) { o.gw = gw; o.gh = gh; o.gc = C; o.seglen = 2 * C; o.segstride = 2L * gw * C; }
+bf_epilogue epi_store(void* c, long ldc) { bf_epilogue e; memset(&e, 0, sizeof(e)); e.c = c; e.ldc = ldc; e.out_mode = BF_OUT_STORE; return e; }
+bf_epilogue epi_atomic(float* c, long ldc) { bf_epilogue e = epi_store(c, ldc); e.out_mode = BF_OUT_ATOMIC_F32; return e; }
+void epi_scatter(bf_epilogue& e, int gw, int gh, int C) { e.gw = gw; e.gh = gh; e.gc = C; e.seglen = 2 * C; e.segstride = 2L * gw * C; }
+
+int splitk_for(int M, int N, long K) {
+    const long tiles = (long)bf_cdiv(M, 128) * bf_cdiv(N, 128);
+    long s = (512 + tiles - 1) / tiles;                 // ~2 blocks per CU
+    const long kt = (K + 63) / 64;
+    if (s > kt / 4) s = kt / 4;                         // at least 4 K-steps per slice
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+#define TRY(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
+#define ZERO(ptr, bytes) do { hipError_t e__ = hipMemsetAsync((ptr), 0, (bytes), st); if (e__ != hipSuccess) return bf_fail(e__, __FILE__, __LINE__); } while (0)
+
+// ------------------------------------------------------------------------------------------------ small param kernels
+// out-projection fold.  mc[n] = <W[n,:], nb> + bias[n]; alpha = gamma*(1+hi); beta = gamma*(bias*(1+hi) + mc*(lo-hi))
+__global__ void outproj_prep_kernel(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ nb,
+                                    const float* __restrict__ gamma, const float* __restrict__ lo, const float* __restrict__ hi,
+                                    float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ mc, int E) {
+    __shared__ float red[4];
+    const int n = blockIdx.x;
+    float acc = 0.f;
+    if (lo) for (int k = threadIdx.x; k < E; k += blockDim.x) acc += W[(long)n * E + k] * nb[k];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = bias[n];
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) m += red[i];
+        const float l = lo ? lo[n] : 0.f, h = hi ? hi[n] : 0.f, g = gamma[n];
+        alpha[n] = g * (1.f + h);
+        beta[n] = g * (bias[n] * (1.f + h) + (lo ? m * (l - h) : 0.f));
+        mc[n] = m;
+    }
+}
+// parameter gradients of the fold (see header comment).  grid = E rows.
+__global__ void outproj_finalize_kernel(const float* __restrict__ G, const float* __restrict__ csum, const float* __restrict__ W,
+                                        const float* __restrict__ bias, const float* __restrict__ nb, const float* __restrict__ gamma,
+                                        const float* __restrict__ lo, const float* __restrict__ hi, const float* __restrict__ mc,
+                                        float* __restrict__ dW, float* __restrict__ dbias, float* __restrict__ dnb, float* __restrict__ dgamma,
+                                        float* __restrict__ dlo, float* __restrict__ dhi, int E) {
+    __shared__ float red[4];
+    __shared__ float s_dmc, s_alpha;
+    const int n = blockIdx.x;
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < E; k += blockDim.x) acc += W[(long)n * E + k] * G[(long)n * E + k];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float dalpha = 0.f;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) dalpha += red[i];
+        const float dbeta = csum[n];
+        const float l = lo ? lo[n] : 0.f, h = hi ? hi[n] : 0.f, g = gamma[n], b = bias[n], m = mc[n];
+        const float mterm = lo ? m * (l - h) : 0.f;
+        dgamma[n] += dalpha * (1.f + h) + dbeta * (b * (1.f + h) + mterm);
+        float dmc = 0.f;
+        if (lo) {
+            dhi[n] += dalpha * g + dbeta * g * (b - m);
+            dlo[n] += dbeta * g * m;
+            dmc = dbeta * g * (l - h);
+        }
+        dbias[n] += dbeta * g * (1.f + h) + dmc;
+        s_dmc = dmc;
+        s_alpha = g * (1.f + h);
+    }
+    __syncthreads();
+    const float dmc = s_dmc, alpha = s_alpha;
+    for (int k = threadIdx.x; k < E; k += blockDim.x) {
+        float v = alpha * G[(long)n * E + k];
+        if (lo) { v += dmc * nb[k]; atomicAdd(dnb + k, dmc * W[(long)n * E + k]); }
+        dW[(long)n * E + k] += v;
+    }
+}
+__global__ void fill_kernel(float* p, float v, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+
+// compute-dtype view of an fp32 weight: cast in bf16 mode, alias in f32 mode
+int wview(const D& d, int mode, const float* src, void* dst, int R, int K, int Kp, const void** out, hipStream_t st) {
+    if (d.dtype == BF_DTYPE_F32 && mode == 0 && Kp == K) { *out = src; return 0; }
+    *out = dst;
+    return bf_wprep(d.dtype, mode, src, dst, R, K, Kp, st);
+}
+
+// ------------------------------------------------------------------------------------------------ saved-record layouts
+struct TemporalSaved {
+    float *mean1, *rstd1, *sc1, *sh1, *mean2, *rstd2, *sc2, *sh2, *alpha, *beta, *mc;
+    void *qkv, *o, *win_c, *wout_c;
+    size_t bytes;
+    TemporalSaved(const D& d, void* base) {
+        Arena a(base);
+        const size_t fe = (size_t)d.F * d.E;
+        mean1 = a.f32(fe); rstd1 = a.f32(fe); sc1 = a.f32(fe); sh1 = a.f32(fe);
+        mean2 = a.f32(fe); rstd2 = a.f32(fe); sc2 = a.f32(fe); sh2 = a.f32(fe);
+        alpha = a.f32(d.E); beta = a.f32(d.E); mc = a.f32(d.E);
+        qkv = a.take((size_t)d.N * 3 * d.E * d.es);
+        o = a.take((size_t)d.N * d.E * d.es);
+        win_c = a.take((size_t)3 * d.E * d.E * d.es);
+        wout_c = a.take((size_t)d.E * d.E * d.es);
+        bytes = a.off;
+    }
+};
+struct SpatialSaved {
+    float *mean1, *rstd1, *sc1, *sh1, *mean2, *rstd2, *sc2, *sh2, *mean3, *rstd3, *sc3, *sh3, *alpha, *beta, *mc;
+    void *qkv, *o, *x1, *pre, *z, *win_c, *wout_c, *w1_c, *w2_c;
+    size_t bytes;
+    SpatialSaved(const D& d, void* base) {
+        Arena a(base);
+        const size_t fe = (size_t)d.F * d.E;
+        mean1 = a.f32(fe); rstd1 = a.f32(fe); sc1 = a.f32(fe); sh1 = a.f32(fe);
+        mean2 = a.f32(fe); rstd2 = a.f32(fe); sc2 = a.f32(fe); sh2 = a.f32(fe);
+        mean3 = a.f32(fe); rstd3 = a.f32(fe); sc3 = a.f32(fe); sh3 = a.f32(fe);
+        alpha = a.f32(d.E); beta = a.f32(d.E); mc = a.f32(d.E);
+        qkv = a.take((size_t)d.N * 3 * d.E * d.es);
+        o = a.take((size_t)d.N * d.E * d.es);
+        x1 = a.take((size_t)d.N * d.E * d.es);
+        pre = a.take((size_t)d.N * 4 * d.E * d.es);
+        z = a.take((size_t)d.N * d.E * d.es);
+        win_c = a.take((size_t)3 * d.E * d.E * d.es);
+        wout_c = a.take((size_t)d.E * d.E * d.es);
+        w1_c = a.take((size_t)4 * d.E * d.E * d.es);
+        w2_c = a.take((size_t)4 * d.E * d.E * d.es);
+        bytes = a.off;
+    }
+};
+
+// transient scratch (backward is the larger user)
+struct Scratch {
+    float *G, *csum, *zeros, *ones, *wg;   // wg: prepared-layout weight gradient scratch
+    void *t1, *t3, *t4, *t1b;
+    size_t bytes;
+    Scratch(const D& d, void* base) {
+        Arena a(base);
+        const int cm = d.nst > 1 ? d.E / 4 : d.E;
+        size_t wgn = (size_t)d.E * d.E;
+        wgn = std::max(wgn, (size_t)4 * cm * d.E);             // conv / convT prepared weights
+        wgn = std::max(wgn, (size_t)d.E * 64);
+        G = a.f32((size_t)d.E * d.E);
+        csum = a.f32((size_t)4 * d.E);
+        zeros = a.f32((size_t)4 * d.E);
+        ones = a.f32((size_t)4 * d.E);
+        wg = a.f32(wgn);
+        // activation-sized transients; embed/debed stages work at up to (patch/2)^2 * N pixels of E/4 (or cin/cout) channels
+        size_t tok = (size_t)d.N * d.E;
+        size_t big = tok * 4;
+        if (d.patch > 1) {
+            const size_t P0 = (size_t)d.N * (d.patch / 2) * (d.patch / 2);
+            const int kp = ((4 * std::max(d.cin, d.cout) + 7) / 8) * 8;
+            big = std::max(big, P0 * (size_t)std::max(cm, kp) * 2);   // *2: fp32 patch-major prediction
+        }
+        t4 = a.take(big * d.es);
+        t3 = a.take(std::max(tok * 3, big / 2) * d.es);
+        t1 = a.take(std::max(tok, big / 2) * d.es);
+        t1b = a.take(std::max(tok, big / 2) * d.es);
+        bytes = a.off;
+    }
+};
+
+int launch_fill(float* p, float v, int n, hipStream_t st) {
+    hipLaunchKernelGGL(fill_kernel, dim3(bf_cdiv(n, 256)), dim3(256), 0, st, p, v, n);
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
+// QKV projection + attention shared pieces -------------------------------------------------------
+int qkv_gemm(const D& d, const void* x, const float* sc, const float* sh, const void* w_c, const float* bias, void* qkv, hipStream_t st) {
+    bf_operand A = op_plain(x, d.E, BF_LAY_KC);
+    op_affine(A, BF_PRO_AFFINE, sc, sh, d.S, d.E);
+    bf_operand Bo = op_plain(w_c, d.E, BF_LAY_KC);
+    bf_epilogue e = epi_store(qkv, 3L * d.E);
+    e.bias = bias;
+    return bf_gemm(d.dtype, (int)d.N, 3 * d.E, d.E, &A, &Bo, &e, 1, st);
+}
+// out = x + alpha * (affine(o) @ W^T) + beta
+int outproj_gemm(const D& d, const void* o, const float* sc, const float* sh, const void* w_c, const float* alpha, const float* beta,
+                 const void* resid, void* out, hipStream_t st) {
+    bf_operand A = op_plain(o, d.E, BF_LAY_KC);
+    op_affine(A, BF_PRO_AFFINE, sc, sh, d.S, d.E);
+    bf_operand Bo = op_plain(w_c, d.E, BF_LAY_KC);
+    bf_epilogue e = epi_store(out, d.E);
+    e.colscale = alpha; e.colshift = beta; e.aux_mode = BF_AUX_ADD; e.aux = resid; e.ld_aux = d.E;
+    return bf_gemm(d.dtype, (int)d.N, d.E, d.E, &A, &Bo, &e, 1, st);
+}
+// backward of the folded out-projection: param grads + don = (dout * alpha) @ W
+int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* o, const float* sc2, const float* sh2, const void* w_c,
+                const float* W, const float* bias, const float* nb, const float* gamma, const float* lo, const float* hi,
+                const float* alpha, const float* mc, float* dW, float* dbias, float* dnb, float* dgamma, float* dlo, float* dhi,
+                void* don, hipStream_t st) {
+    ZERO(sc.G, (size_t)d.E * d.E * 4);
+    ZERO(sc.csum, (size_t)d.E * 4);
+    {   // G[n][k] = sum_m dout[m][n] * on[m][k]
+        bf_operand A = op_plain(dout, d.E, BF_LAY_XC);
+        bf_operand Bo = op_plain(o, d.E, BF_LAY_XC);
+        op_affine(Bo, BF_PRO_AFFINE, sc2, sh2, d.S, d.E);
+        bf_epilogue e = epi_atomic(sc.G, d.E);
+        TRY(bf_gemm(d.dtype, d.E, d.E, (int)d.N, &A, &Bo, &e, splitk_for(d.E, d.E, d.N), st));
+    }
+    TRY(bf_colsum(d.dtype, dout, d.N, d.E, nullptr, sc.csum, st));
+    hipLaunchKernelGGL(outproj_finalize_kernel, dim3(d.E), dim3(256), 0, st, sc.G, sc.csum, W, bias, nb, gamma, lo, hi, mc, dW, dbias, dnb,
+                       dgamma, dlo, dhi, d.E);
+    BF_CHECK_LAUNCH();
+    {   // don = (dout * alpha) @ W     (alpha per reduction column; frame independent)
+        bf_operand A = op_plain(dout, d.E, BF_LAY_KC);
+        op_affine(A, BF_PRO_AFFINE, alpha, sc.zeros, d.N, d.E);
+        bf_operand Bo = op_plain(w_c, d.E, BF_LAY_XC);
+        bf_epilogue e = epi_store(don, d.E);
+        TRY(bf_gemm(d.dtype, (int)d.N, d.E, d.E, &A, &Bo, &e, 1, st));
+    }
+    return 0;
+}
+// backward of y = affine(x) @ W^T + b:  dW += dy^T affine(x), db += colsum(dy), dxn = dy @ W
+int linear_bwd(const D& d, const Scratch& sc, const void* dy, int Nout, const void* x, int Kin, int xpro, const float* xsc, const float* xsh,
+               const void* w_c, float* dW, float* db, void* dxn, const bf_epilogue* dx_epi, hipStream_t st) {
+    {
+        bf_operand A = op_plain(dy, Nout, BF_LAY_XC);
+        bf_operand Bo = op_plain(x, Kin, BF_LAY_XC);
+        if (xpro != BF_PRO_NONE) op_affine(Bo, xpro, xsc, xsh, d.S, Kin);
+        bf_epilogue e = epi_atomic(dW, Kin);
+        TRY(bf_gemm(d.dtype, Nout, Kin, (int)d.N, &A, &Bo, &e, splitk_for(Nout, Kin, d.N), st));
+    }
+    if (db) TRY(bf_colsum(d.dtype, dy, d.N, Nout, nullptr, db, st));
+    {
+        bf_operand A = op_plain(dy, Nout, BF_LAY_KC);
+        bf_operand Bo = op_plain(w_c, Kin, BF_LAY_XC);
+        bf_epilogue e = dx_epi ? *dx_epi : epi_store(dxn, Kin);
+        e.c = dxn; e.ldc = Kin;
+        TRY(bf_gemm(d.dtype, (int)d.N, Kin, Nout, &A, &Bo, &e, 1, st));
+    }
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================================================= sizes
+extern "C" int64_t bf_temporal_saved_bytes(const bf_dims* s) { D d; if (get_dims(s, &d)) return -1; return (int64_t)TemporalSaved(d, nullptr).bytes; }
+extern "C" int64_t bf_spatial_saved_bytes(const bf_dims* s) { D d; if (get_dims(s, &d)) return -1; return (int64_t)SpatialSaved(d, nullptr).bytes; }
+extern "C" int64_t bf_scratch_bytes(const bf_dims* s) { D d; if (get_dims(s, &d)) return -1; return (int64_t)Scratch(d, nullptr).bytes; }
+
+// ================================================================================================= temporal block
+extern "C" int bf_temporal_fwd(const bf_dims* dims, const bf_temporal_params* p, const void* x, void* out, void* saved, void* scratch, bf_stream_t s) {
+    D d; TRY(get_dims(dims, &d));
+    BF_REQUIRE(p && x && out && saved && scratch, "bf_temporal_fwd: null pointer");
+    hipStream_t st = (hipStream_t)s;
+    TemporalSaved sv(d, saved);
+    const void *win_c, *wout_c;
+    TRY(wview(d, 0, p->input_head_w, sv.win_c, 3 * d.E, d.E, d.E, &win_c, st));
+    TRY(wview(d, 0, p->output_head_w, sv.wout_c, d.E, d.E, d.E, &wout_c, st));
+    TRY(bf_in_stats(d.dtype, x, (int)d.F, (int)d.S, d.E, p->norm1_w, p->norm1_b, nullptr, 1, nullptr, sv.mean1, sv.rstd1, sv.sc1, sv.sh1, st));
+    TRY(qkv_gemm(d, x, sv.sc1, sv.sh1, win_c, p->input_head_b, sv.qkv, st));
+    // sequences along T for every (b, y, x): token = b*T*S + pos + t*S
+    TRY(bf_attn_fwd(d.dtype, sv.qkv, sv.o, (long)d.B * d.S, d.T, d.S, (long)d.T * d.S, 1, d.S, d.heads, d.d, p->qnorm_w, p->qnorm_b,
+                    p->knorm_w, p->knorm_b, p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor : nullptr, 1.f, 0, st));
+    TRY(bf_in_stats(d.dtype, sv.o, (int)d.F, (int)d.S, d.E, p->norm2_w, p->norm2_b, nullptr, 1, nullptr, sv.mean2, sv.rstd2, sv.sc2, sv.sh2, st));
+    hipLaunchKernelGGL(outproj_prep_kernel, dim3(d.E), dim3(256), 0, st, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma,
+                       (const float*)nullptr, (const float*)nullptr, sv.alpha, sv.beta, sv.mc, d.E);
+    BF_CHECK_LAUNCH();
+    TRY(outproj_gemm(d, sv.o, sv.sc2, sv.sh2, wout_c, sv.alpha, sv.beta, x, out, st));
+    return 0;
+}
+
+extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p, const bf_temporal_params* g, const void* x, const void* dout,
+                               void* dx, void* saved, void* scratch, bf_stream_t s) {
+    D d; TRY(get_dims(dims, &d));
+    BF_REQUIRE(p && g && x && dout && dx && saved && scratch, "bf_temporal_bwd: null pointer");
+    hipStream_t st = (hipStream_t)s;
+    TemporalSaved sv(d, saved);
+    Scratch sc(d, scratch);
+    const void* win_c = d.dtype == BF_DTYPE_F32 ? (const void*)p->input_head_w : sv.win_c;
+    const void* wout_c = d.dtype == BF_DTYPE_F32 ? (const void*)p->output_head_w : sv.wout_c;
+    ZERO(sc.zeros, (size_t)4 * d.E * 4);
+    void* don = sc.t1;      // [N][E]
+    void* dO = sc.t1b;      // [N][E]
+    void* dqkv = sc.t3;     // [N][3E]
+    TRY(outproj_bwd(d, sc, dout, sv.o, sv.sc2, sv.sh2, wout_c, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr,
+                    sv.alpha, sv.mc, g->output_head_w, g->output_head_b, nullptr, g->gamma, nullptr, nullptr, don, st));
+    TRY(bf_in_bwd(d.dtype, don, sv.o, nullptr, dO, (int)d.F, (int)d.S, d.E, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, nullptr, 1, 0,
+                  g->norm2_w, g->norm2_b, nullptr, nullptr, st));
+    TRY(bf_attn_bwd(d.dtype, sv.qkv, dO, dqkv, (long)d.B * d.S, d.T, d.S, (long)d.T * d.S, 1, d.S, d.heads, d.d, p->qnorm_w, p->qnorm_b,
+                    p->knorm_w, p->knorm_b, p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor : nullptr, g->qnorm_w, g->qnorm_b,
+                    g->knorm_w, g->knorm_b, g->rel_pos_emb, d.attn_scale ? g->attn_scale_factor : nullptr, 1.f, 0, st));
+    void* dxn = sc.t1;      // don is dead
+    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, x, d.E, BF_PRO_AFFINE, sv.sc1, sv.sh1, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st));
+    TRY(bf_in_bwd(d.dtype, dxn, x, dout, dx, (int)d.F, (int)d.S, d.E, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, nullptr, 1, 0,
+                  g->norm1_w, g->norm1_b, nullptr, nullptr, st));
+    return 0;
+}
+
+// ================================================================================================= axial (spatial) block
+extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, const void* x, void* out, void* saved, void* scratch, bf_stream_t s) {
+    D d; TRY(get_dims(dims, &d));
+    BF_REQUIRE(p && x && out && saved && scratch, "bf_spatial_fwd: null pointer");
+    hipStream_t st = (hipStream_t)s;
+    SpatialSaved sv(d, saved);
+    const void *win_c, *wout_c, *w1_c, *w2_c;
+    TRY(wview(d, 0, p->input_head_w, sv.win_c, 3 * d.E, d.E, d.E, &win_c, st));
+    TRY(wview(d, 0, p->output_head_w, sv.wout_c, d.E, d.E, d.E, &wout_c, st));
+    TRY(wview(d, 0, p->fc1_w, sv.w1_c, 4 * d.E, d.E, d.E, &w1_c, st));
+    TRY(wview(d, 0, p->fc2_w, sv.w2_c, d.E, 4 * d.E, 4 * d.E, &w2_c, st));
+    TRY(bf_in_stats(d.dtype, x, (int)d.F, (int)d.S, d.E, p->norm1_w, p->norm1_b, nullptr, 1, nullptr, sv.mean1, sv.rstd1, sv.sc1, sv.sh1, st));
+    TRY(qkv_gemm(d, x, sv.sc1, sv.sh1, win_c, p->input_head_b, sv.qkv, st));
+    // along w: one sequence per (frame, row): contiguous tokens
+    TRY(bf_attn_fwd(d.dtype, sv.qkv, sv.o, d.F * d.h, d.w, 1, d.w, 0, 1, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
+                    p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_x : nullptr, 0.5f, 0, st));
+    // along h: one sequence per (frame, column): stride w
+    TRY(bf_attn_fwd(d.dtype, sv.qkv, sv.o, d.F * d.w, d.h, d.w, d.S, 1, d.w, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
+                    p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_y : nullptr, 0.5f, 1, st));
+    TRY(bf_in_stats(d.dtype, sv.o, (int)d.F, (int)d.S, d.E, p->norm2_w, p->norm2_b, nullptr, 1, nullptr, sv.mean2, sv.rstd2, sv.sc2, sv.sh2, st));
+    hipLaunchKernelGGL(outproj_prep_kernel, dim3(d.E), dim3(256), 0, st, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att,
+                       d.feat_scale ? p->low_freq_scalar : nullptr, d.feat_scale ? p->high_freq_scalar : nullptr, sv.alpha, sv.beta, sv.mc, d.E);
+    BF_CHECK_LAUNCH();
+    TRY(outproj_gemm(d, sv.o, sv.sc2, sv.sh2, wout_c, sv.alpha, sv.beta, x, sv.x1, st));
+    {   // pre = x1 @ W1^T + b1
+        bf_operand A = op_plain(sv.x1, d.E, BF_LAY_KC);
+        bf_operand Bo = op_plain(w1_c, d.E, BF_LAY_KC);
+        bf_epilogue e = epi_store(sv.pre, 4L * d.E);
+        e.bias = p->fc1_b;
+        TRY(bf_gemm(d.dtype, (int)d.N, 4 * d.E, d.E, &A, &Bo, &e, 1, st));
+    }
+    {   // z = gelu(pre) @ W2^T + b2
+        bf_operand A = op_plain(sv.pre, 4L * d.E, BF_LAY_KC);
+        A.pro = BF_PRO_GELU;
+        bf_operand Bo = op_plain(w2_c, 4L * d.E, BF_LAY_KC);
+        bf_epilogue e = epi_store(sv.z, d.E);
+        e.bias = p->fc2_b;
+        TRY(bf_gemm(d.dtype, (int)d.N, d.E, 4 * d.E, &A, &Bo, &e, 1, st));
+    }
+    // out = x1 + gamma_mlp * InstanceNorm(z)
+    TRY(bf_in_stats(d.dtype, sv.z, (int)d.F, (int)d.S, d.E, p->mlp_norm_w, p->mlp_norm_b, p->gamma_mlp, (int)d.F, nullptr, sv.mean3, sv.rstd3,
+                    sv.sc3, sv.sh3, st));
+    TRY(bf_affine_apply(d.dtype, sv.z, sv.x1, sv.sc3, sv.sh3, out, d.N, (int)d.S, d.E, st));
+    return 0;
+}
+
+extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, const bf_spatial_params* g, const void* x, const void* dout,
+                              void* dx, void* saved, void* scratch, bf_stream_t s) {
+    D d; TRY(get_dims(dims, &d));
+    BF_REQUIRE(p && g && x && dout && dx && saved && scratch, "bf_spatial_bwd: null pointer");
+    hipStream_t st = (hipStream_t)s;
+    SpatialSaved sv(d, saved);
+    Scratch sc(d, scratch);
+    const bool f32 = d.dtype == BF_DTYPE_F32;
+    const void* win_c = f32 ? (const void*)p->input_head_w : sv.win_c;
+    const void* wout_c = f32 ? (const void*)p->output_head_w : sv.wout_c;
+    const void* w1_c = f32 ? (const void*)p->fc1_w : sv.w1_c;
+    const void* w2_c = f32 ? (const void*)p->fc2_w : sv.w2_c;
+    ZERO(sc.zeros, (size_t)4 * d.E * 4);
+    // out = x1 + gamma_mlp * IN(z)
+    void* dz = sc.t1;
+    TRY(bf_in_bwd(d.dtype, dout, sv.z, nullptr, dz, (int)d.F, (int)d.S, d.E, sv.mean3, sv.rstd3, p->mlp_norm_w, p->mlp_norm_b, p->gamma_mlp,
+                  (int)d.F, 0, g->mlp_norm_w, g->mlp_norm_b, g->gamma_mlp, nullptr, st));
+    // fc2: z = gelu(pre) @ W2^T + b2 ; dpre = (dz @ W2) * gelu'(pre)
+    void* dpre = sc.t4;
+    {
+        bf_epilogue e; memset(&e, 0, sizeof(e));
+        e.aux_mode = BF_AUX_DGELU; e.aux = sv.pre; e.ld_aux = 4L * d.E; e.out_mode = BF_OUT_STORE;
+        TRY(linear_bwd(d, sc, dz, d.E, sv.pre, 4 * d.E, BF_PRO_GELU, nullptr, nullptr, w2_c, g->fc2_w, g->fc2_b, dpre, &e, st));
+    }
+    // fc1: pre = x1 @ W1^T + b1 ; dx1 = dout + dpre @ W1
+    void* dx1 = sc.t1b;
+    {
+        bf_epilogue e; memset(&e, 0, sizeof(e));
+        e.aux_mode = BF_AUX_ADD; e.aux = dout; e.ld_aux = d.E; e.out_mode = BF_OUT_STORE;
+        TRY(linear_bwd(d, sc, dpre, 4 * d.E, sv.x1, d.E, BF_PRO_NONE, nullptr, nullptr, w1_c, g->fc1_w, g->fc1_b, dx1, &e, st));
+    }
+    // folded out-projection
+    void* don = sc.t1;      // dz is dead
+    TRY(outproj_bwd(d, sc, dx1, sv.o, sv.sc2, sv.sh2, wout_c, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att,
+                    d.feat_scale ? p->low_freq_scalar : nullptr, d.feat_scale ? p->high_freq_scalar : nullptr, sv.alpha, sv.mc,
+                    g->output_head_w, g->output_head_b, g->norm2_b, g->gamma_att, d.feat_scale ? g->low_freq_scalar : nullptr,
+                    d.feat_scale ? g->high_freq_scalar : nullptr, don, st));
+    void* dO = sc.t4;       // dpre is dead; [N][E]
+    TRY(bf_in_bwd(d.dtype, don, sv.o, nullptr, dO, (int)d.F, (int)d.S, d.E, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, nullptr, 1, 0,
+                  g->norm2_w, g->norm2_b, nullptr, nullptr, st));
+    void* dqkv = sc.t3;
+    TRY(bf_attn_bwd(d.dtype, sv.qkv, dO, dqkv, d.F * d.h, d.w, 1, d.w, 0, 1, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
+                    p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_x : nullptr, g->qnorm_w, g->qnorm_b, g->knorm_w, g->knorm_b,
+                    g->rel_pos_emb, d.attn_scale ? g->attn_scale_factor_x : nullptr, 0.5f, 0, st));
+    TRY(bf_attn_bwd(d.dtype, sv.qkv, dO, dqkv, d.F * d.w, d.h, d.w, d.S, 1, d.w, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
+                    p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_y : nullptr, g->qnorm_w, g->qnorm_b, g->knorm_w, g->knorm_b,
+                    g->rel_pos_emb, d.attn_scale ? g->attn_scale_factor_y : nullptr, 0.5f, 1, st));
+    void* dxn = sc.t1;      // don is dead
+    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, x, d.E, BF_PRO_AFFINE, sv.sc1, sv.sh1, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st));
+    TRY(bf_in_bwd(d.dtype, dxn, x, dx1, dx, (int)d.F, (int)d.S, d.E, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, nullptr, 1, 0,
+                  g->norm1_w, g->norm1_b, nullptr, nullptr, st));
+    return 0;
+}
+
+// ================================================================================================= patch embed (+ FiLM)
+namespace {
+inline int roundup(int v, int m) { return (v + m - 1) / m * m; }
+
+struct EmbedSaved {
+    float *gb, *dgb, *chat, *crstd;
+    void* patches; int Kp;
+    void* y[BF_MAX_STAGES]; void* wc[BF_MAX_STAGES];
+    float *mean[BF_MAX_STAGES], *rstd[BF_MAX_STAGES], *sc[BF_MAX_STAGES], *sh[BF_MAX_STAGES];
+    int C[BF_MAX_STAGES], gh[BF_MAX_STAGES], gw[BF_MAX_STAGES]; long P[BF_MAX_STAGES];
+    size_t bytes;
+    EmbedSaved(const D& d, void* base) {
+        Arena a(base);
+        const int np = d.nfluid > 0 ? d.nfluid : 1;
+        gb = a.f32((size_t)2 * d.B * d.E); dgb = a.f32((size_t)2 * d.B * d.E); chat = a.f32((size_t)d.B * np); crstd = a.f32(d.B);
+        Kp = roundup(4 * d.cin, 8);
+        const int H = d.h * d.patch, W = d.w * d.patch;
+        for (int i = 0; i < d.nst; ++i) {
+            C[i] = (i == d.nst - 1) ? d.E : d.E / 4;
+            gh[i] = H >> (i + 1); gw[i] = W >> (i + 1);
+            P[i] = d.F * gh[i] * gw[i];
+        }
+        patches = a.take((size_t)P[0] * Kp * d.es);
+        for (int i = 0; i < d.nst; ++i) {
+            const int kin = i == 0 ? Kp : 4 * C[i - 1];
+            y[i] = a.take((size_t)P[i] * C[i] * d.es);
+            wc[i] = a.take((size_t)C[i] * kin * d.es);
+            const size_t fc = (size_t)d.F * C[i];
+            mean[i] = a.f32(fc); rstd[i] = a.f32(fc); sc[i] = a.f32(fc); sh[i] = a.f32(fc);
+        }
+        bytes = a.off;
+    }
+};
+struct DebedSaved {
+    float *lossbuf, *coef;
+    void* y[BF_MAX_STAGES]; void* wc[BF_MAX_STAGES];
+    float *mean[BF_MAX_STAGES], *rstd[BF_MAX_STAGES], *sc[BF_MAX_STAGES], *sh[BF_MAX_STAGES];
+    int Cin[BF_MAX_STAGES], Co[BF_MAX_STAGES], gh[BF_MAX_STAGES], gw[BF_MAX_STAGES]; long Pin[BF_MAX_STAGES];
+    int Np;
+    size_t bytes;
+    DebedSaved(const D& d, void* base) {
+        Arena a(base);
+        lossbuf = a.f32((size_t)d.F * d.cout * 2); coef = a.f32((size_t)d.F * d.cout);
+        Np = roundup(4 * d.cout, 8);
+        for (int i = 0; i < d.nst; ++i) {
+            Cin[i] = i == 0 ? d.E : d.E / 4;
+            Co[i] = (i == d.nst - 1) ? d.cout : d.E / 4;
+            gh[i] = d.h << i; gw[i] = d.w << i;
+            Pin[i] = d.F * gh[i] * gw[i];
+            const bool last = i == d.nst - 1;
+            wc[i] = a.take((size_t)Cin[i] * (last ? Np : 4 * Co[i]) * d.es);
+            if (!last) {
+                y[i] = a.take((size_t)Pin[i] * 4 * Co[i] * d.es);
+                const size_t fc = (size_t)d.F * Co[i];
+                mean[i] = a.f32(fc); rstd[i] = a.f32(fc); sc[i] = a.f32(fc); sh[i] = a.f32(fc);
+            } else { y[i] = nullptr; mean[i] = rstd[i] = sc[i] = sh[i] = nullptr; }
+        }
+        bytes = a.off;
+    }
+};
+}  // namespace
+
+extern "C" int64_t bf_embed_saved_bytes(const bf_dims* s) { D d; if (get_dims(s, &d) || d.nst < 1) return -1; return (int64_t)EmbedSaved(d, nullptr).bytes; }
+extern "C" int64_t bf_debed_saved_bytes(const bf_dims* s) { D d; if (get_dims(s, &d) || d.nst < 1) return -1; return (int64_t)DebedSaved(d, nullptr).bytes; }
+
+extern "C" int bf_embed_fwd(const bf_dims* dims, const bf_embed_params* p, const float* x, const float* fluid, void* out, void* saved,
+                            void* scratch, bf_stream_t s) {
+    D d; TRY(get_dims(dims, &d));
+    BF_REQUIRE(p && x && out && saved && scratch && d.nst >= 1 && d.cin >= 1, "bf_embed_fwd: bad arguments");
+    BF_REQUIRE((d.nfluid > 0) == (fluid != nullptr), "bf_embed_fwd: fluid parameters must be given exactly when nfluid > 0");
+    hipStream_t st = (hipStream_t)s;
+    EmbedSaved sv(d, saved);
+    const int n = d.nst, H = d.h * d.patch, W = d.w * d.patch;
+    if (d.nfluid > 0)
+        TRY(bf_film_net_fwd(fluid, p->film_ln_w, p->film_ln_b, p->film_w, p->film_b, sv.gb, sv.chat, sv.crstd, d.B, d.nfluid, 2 * d.E, st));
+    TRY(bf_im2col_nchw(d.dtype, x, sv.patches, (int)d.F, d.cin, H, W, sv.Kp, st));
+    for (int i = 0; i < n; ++i) {
+        const void* wc;
+        if (i == 0) {
+            TRY(bf_wprep(d.dtype, 0, p->conv_w[0], sv.wc[0], sv.C[0], 4 * d.cin, sv.Kp, st));
+            wc = sv.wc[0];
+            bf_operand A = op_plain(sv.patches, sv.Kp, BF_LAY_KC);
+            bf_operand Bo = op_plain(wc, sv.Kp, BF_LAY_KC);
+            bf_epilogue e = epi_store(sv.y[0], sv.C[0]);
+            TRY(bf_gemm(d.dtype, (int)sv.P[0], sv.C[0], sv.Kp, &A, &Bo, &e, 1, st));
+        } else {
+            const int cp = sv.C[i - 1];
+            TRY(bf_wprep(d.dtype, 1, p->conv_w[i], sv.wc[i], sv.C[i], 4 * cp, 4 * cp, st));
+            bf_operand A = op_plain(sv.y[i - 1], cp, BF_LAY_KC);
+            op_gather(A, sv.gw[i], sv.gh[i], cp);
+            op_affine(A, BF_PRO_AFFINE_GELU, sv.sc[i - 1], sv.sh[i - 1], (long)sv.gh[i] * sv.gw[i], cp);
+            bf_operand Bo = op_plain(sv.wc[i], 4L * cp, BF_LAY_KC);
+            bf_epilogue e = epi_store(sv.y[i], sv.C[i]);
+            TRY(bf_gemm(d.dtype, (int)sv.P[i], sv.C[i], 4 * cp, &A, &Bo, &e, 1, st));
+        }
+        const bool last = i == n - 1;
+        const bool film = last && d.nfluid > 0;
+        TRY(bf_in_stats(d.dtype, sv.y[i], (int)d.F, sv.gh[i] * sv.gw[i], sv.C[i], p->in_w[i], p->in_b[i], film ? sv.gb : nullptr, d.T,
+                        film ? sv.gb + (size_t)d.B * d.E : nullptr, sv.mean[i], sv.rstd[i], sv.sc[i], sv.sh[i], st));
+    }
+    TRY(bf_affine_apply(d.dtype, sv.y[n - 1], nullptr, sv.sc[n - 1], sv.sh[n - 1], out, d.N, (int)d.S, d.E, st));
+    return 0;
+}
+
+extern "C" int bf_embed_bwd(const bf_dims* dims, const bf_embed_params* p, const bf_embed_params* g, const void* dout, float* dx_in,
+                            void* saved, void* scratch, bf_stream_t s) {
+    D d; TRY(get_dims(dims, &d));
+    BF_REQUIRE(p && g && dout && saved && scratch && d.nst >= 1, "bf_embed_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)s;
+    EmbedSaved sv(d, saved);
+    Scratch sc(d, scratch);
+    const int n = d.nst, H = d.h * d.patch, W = d.w * d.patch;
+    auto buf = [&](int stage) { return (stage & 1) ? sc.t3 : sc.t4; };
+    const bool film = d.nfluid > 0;
+    if (film) ZERO(sv.dgb, (size_t)2 * d.B * d.E * 4);
+    // last stage: out = (xhat*w + b) * gamma_b + beta_b
+    void* dy = buf(n - 1);
+    TRY(bf_in_bwd(d.dtype, dout, sv.y[n - 1], nullptr, dy, (int)d.F, sv.gh[n - 1] * sv.gw[n - 1], sv.C[n - 1], sv.mean[n - 1], sv.rstd[n - 1],
+                  p->in_w[n - 1], p->in_b[n - 1], film ? sv.gb : nullptr, d.T, 0, g->in_w[n - 1], g->in_b[n - 1], film ? sv.dgb : nullptr,
+                  film ? sv.dgb + (size_t)d.B * d.E : nullptr, st));
+    if (film)
+        TRY(bf_film_net_bwd(sv.dgb, sv.chat, p->film_ln_w, p->film_ln_b, p->film_w, g->film_w, g->film_b, g->film_ln_w, g->film_ln_b, d.B,
+                            d.nfluid, 2 * d.E, st));
+    for (int i = n - 1; i >= 1; --i) {
+        const int cp = sv.C[i - 1], K4 = 4 * cp;
+        const long rpf = (long)sv.gh[i] * sv.gw[i];
+        ZERO(sc.wg, (size_t)sv.C[i] * K4 * 4);
+        {   // dWprep[co][k] = sum_p dy[p][co] * act(patch)[p][k]
+            bf_operand A = op_plain(dy, sv.C[i], BF_LAY_XC);
+            bf_operand Bo = op_plain(sv.y[i - 1], cp, BF_LAY_XC);
+            op_gather(Bo, sv.gw[i], sv.gh[i], cp);
+            op_affine(Bo, BF_PRO_AFFINE_GELU, sv.sc[i - 1], sv.sh[i - 1], rpf, cp);
+            bf_epilogue e = epi_atomic(sc.wg, K4);
+            TRY(bf_gemm(d.dtype, sv.C[i], K4, (int)sv.P[i], &A, &Bo, &e, splitk_for(sv.C[i], K4, sv.P[i]), st));
+        }
+        TRY(bf_wgrad_unprep(1, sc.wg, g->conv_w[i], sv.C[i], K4, K4, 0, st));
+        void* dact = buf(i - 1);
+        {   // d(act patch)[p][k] = sum_co dy[p][co] * Wprep[co][k], scattered back to the input grid
+            bf_operand A = op_plain(dy, sv.C[i], BF_LAY_KC);
+            bf_operand Bo = op_plain(sv.wc[i], K4, BF_LAY_XC);
+            bf_epilogue e = epi_store(dact, cp);
+            epi_scatter(e, sv.gw[i], sv.gh[i], cp);
+            TRY(bf_gemm(d.dtype, (int)sv.P[i], K4, sv.C[i], &A, &Bo, &e, 1, st));
+        }
+        TRY(bf_in_bwd(d.dtype, dact, sv.y[i - 1], nullptr, dact, (int)d.F, sv.gh[i - 1] * sv.gw[i - 1], cp, sv.mean[i - 1], sv.rstd[i - 1],
+                      p->in_w[i - 1], p->in_b[i - 1], nullptr, 1, 1, g->in_w[i - 1], g->in_b[i - 1], nullptr, nullptr, st));
+        dy = dact;
+    }
+    {   // stage 0
+        ZERO(sc.wg, (size_t)sv.C[0] * sv.Kp * 4);
+        bf_operand A = op_plain(dy, sv.C[0], BF_LAY_XC);
+        bf_operand Bo = op_plain(sv.patches, sv.Kp, BF_LAY_XC);
+        bf_epilogue e = epi_atomic(sc.wg, sv.Kp);
+        TRY(bf_gemm(d.dtype, sv.C[0], sv.Kp, (int)sv.P[0], &A, &Bo, &e, splitk_for(sv.C[0], sv.Kp, sv.P[0]), st));
+        TRY(bf_wgrad_unprep(0, sc.wg, g->conv_w[0], sv.C[0], 4 * d.cin, sv.Kp, 0, st));
+        if (dx_in) {
+            void* dpatch = sc.t1;
+            bf_operand A2 = op_plain(dy, sv.C[0], BF_LAY_KC);
+            bf_operand B2 = op_plain(sv.wc[0], sv.Kp, BF_LAY_XC);
+            bf_epilogue e2 = epi_store(dpatch, sv.Kp);
+            TRY(bf_gemm(d.dtype, (int)sv.P[0], sv.Kp, sv.C[0], &A2, &B2, &e2, 1, st));
+            TRY(bf_col2im_nchw(d.dtype, dpatch, dx_in, (int)d.F, d.cin, H, W, sv.Kp, st));
+        }
+    }
+    return 0;
+}
+
+// ================================================================================================= debed (+ relative-L2 loss)
+extern "C" int bf_debed_fwd(const bf_dims* dims, const bf_debed_params* p, const void* x, float* pred, const float* target, float* loss,
+                            void* saved, void* scratch, bf_stream_t s) {
+    D d; TRY(get_dims(dims, &d));
+    BF_REQUIRE(p && x && pred && saved && scratch && d.nst >= 1 && d.cout >= 1, "bf_debed_fwd: bad arguments");
+    BF_REQUIRE(!target || loss, "bf_debed_fwd: loss output missing");
+    hipStream_t st = (hipStream_t)s;
+    DebedSaved sv(d, saved);
+    Scratch sc(d, scratch);
+    const int n = d.nst;
+    for (int i = 0; i < n; ++i) {
+        const bool last = i == n - 1;
+        const int cin = sv.Cin[i], co = sv.Co[i];
+        bf_operand A = op_plain(i == 0 ? x : sv.y[i - 1], cin, BF_LAY_KC);
+        if (i > 0) op_affine(A, BF_PRO_AFFINE_GELU, sv.sc[i - 1], sv.sh[i - 1], (long)sv.gh[i] * sv.gw[i], cin);
+        if (!last) {
+            TRY(bf_wprep(d.dtype, 2, p->conv_w[i], sv.wc[i], 4 * co, cin, cin, st));
+            bf_operand Bo = op_plain(sv.wc[i], cin, BF_LAY_KC);
+            bf_epilogue e = epi_store(sv.y[i], co);
+            epi_scatter(e, sv.gw[i], sv.gh[i], co);
+            TRY(bf_gemm(d.dtype, (int)sv.Pin[i], 4 * co, cin, &A, &Bo, &e, 1, st));
+            TRY(bf_in_stats(d.dtype, sv.y[i], (int)d.F, 4 * sv.gh[i] * sv.gw[i], co, p->in_w[i], p->in_b[i], nullptr, 1, nullptr, sv.mean[i],
+                            sv.rstd[i], sv.sc[i], sv.sh[i], st));
+        } else {
+            TRY(bf_wprep(d.dtype, 0, p->conv_w[i], sv.wc[i], cin, 4 * co, sv.Np, st));
+            bf_operand Bo = op_plain(sv.wc[i], sv.Np, BF_LAY_XC);
+            float* pm = (float*)sc.t4;
+            bf_epilogue e = epi_store(pm, sv.Np);
+            e.out_mode = BF_OUT_STORE_F32;
+            TRY(bf_gemm(d.dtype, (int)sv.Pin[i], sv.Np, cin, &A, &Bo, &e, 1, st));
+            if (target) ZERO(sv.lossbuf, (size_t)d.F * d.cout * 2 * 4);
+            TRY(bf_pm2nchw(pm, pred, target, sv.lossbuf, (int)d.F, co, sv.gh[i], sv.gw[i], sv.Np, st));
+            if (target) TRY(bf_lploss_finalize(sv.lossbuf, (int)d.F, co, loss, sv.coef, st));
+        }
+    }
+    return 0;
+}
+
+extern "C" int bf_debed_bwd(const bf_dims* dims, const bf_debed_params* p, const bf_debed_params* g, const void* x, const float* dpred,
+                            const float* pred, const float* target, const float* loss_scale, void* dx, void* saved, void* scratch,
+                            bf_stream_t s) {
+    D d; TRY(get_dims(dims, &d));
+    BF_REQUIRE(p && g && x && dx && saved && scratch && d.nst >= 1, "bf_debed_bwd: bad arguments");
+    BF_REQUIRE(dpred || (pred && target), "bf_debed_bwd: need dpred or (pred, target) of the fused loss");
+    hipStream_t st = (hipStream_t)s;
+    DebedSaved sv(d, saved);
+    Scratch sc(d, scratch);
+    const int n = d.nst;
+    auto buf = [&](int stage) { return (stage & 1) ? sc.t3 : sc.t4; };   // gradient w.r.t. the INPUT of `stage`
+    void* dy = nullptr;   // gradient w.r.t. the raw output of stage i-1 == (after IN/GELU backward) input of stage i
+    for (int i = n - 1; i >= 0; --i) {
+        const bool last = i == n - 1;
+        const int cin = sv.Cin[i], co = sv.Co[i];
+        const long rpf = (long)sv.gh[i] * sv.gw[i];
+        const void* ain = i == 0 ? x : sv.y[i - 1];
+        void* dact = i == 0 ? dx : buf(i);
+        if (last) {
+            void* dpm = sc.t1;
+            TRY(bf_nchw2pm(d.dtype, dpred, pred, target, sv.coef, loss_scale, dpm, (int)d.F, co, sv.gh[i], sv.gw[i], sv.Np, st));
+            ZERO(sc.wg, (size_t)sv.Np * cin * 4);
+            {   // wg[n][ci] = sum_p dpm[p][n] * act[p][ci]
+                bf_operand A = op_plain(dpm, sv.Np, BF_LAY_XC);
+                bf_operand Bo = op_plain(ain, cin, BF_LAY_XC);
+                if (i > 0) op_affine(Bo, BF_PRO_AFFINE_GELU, sv.sc[i - 1], sv.sh[i - 1], rpf, cin);
+                bf_epilogue e = epi_atomic(sc.wg, cin);
+                TRY(bf_gemm(d.dtype, sv.Np, cin, (int)sv.Pin[i], &A, &Bo, &e, splitk_for(sv.Np, cin, sv.Pin[i]), st));
+            }
+            TRY(bf_wgrad_unprep(0, sc.wg, g->conv_w[i], cin, 4 * co, sv.Np, 1, st));
+            {   // dact[p][ci] = sum_n dpm[p][n] * wt[ci][n]
+                bf_operand A = op_plain(dpm, sv.Np, BF_LAY_KC);
+                bf_operand Bo = op_plain(sv.wc[i], sv.Np, BF_LAY_KC);
+                bf_epilogue e = epi_store(dact, cin);
+                TRY(bf_gemm(d.dtype, (int)sv.Pin[i], cin, sv.Np, &A, &Bo, &e, 1, st));
+            }
+        } else {
+            const int N4 = 4 * co;
+            ZERO(sc.wg, (size_t)N4 * cin * 4);
+            {   // wg[(q,co)][ci] = sum_p dy_gathered[p][(q,co)] * act[p][ci]
+                bf_operand A = op_plain(dy, co, BF_LAY_XC);
+                op_gather(A, sv.gw[i], sv.gh[i], co);
+                bf_operand Bo = op_plain(ain, cin, BF_LAY_XC);
+                if (i > 0) op_affine(Bo, BF_PRO_AFFINE_GELU, sv.sc[i - 1], sv.sh[i - 1], rpf, cin);
+                bf_epilogue e = epi_atomic(sc.wg, cin);
+                TRY(bf_gemm(d.dtype, N4, cin, (int)sv.Pin[i], &A, &Bo, &e, splitk_for(N4, cin, sv.Pin[i]), st));
+            }
+            TRY(bf_wgrad_unprep(2, sc.wg, g->conv_w[i], N4, cin, cin, 0, st));
+            {
+                bf_operand A = op_plain(dy, co, BF_LAY_KC);
+                op_gather(A, sv.gw[i], sv.gh[i], co);
+                bf_operand Bo = op_plain(sv.wc[i], cin, BF_LAY_XC);
+                bf_epilogue e = epi_store(dact, cin);
+                TRY(bf_gemm(d.dtype, (int)sv.Pin[i], cin, N4, &A, &Bo, &e, 1, st));
+            }
+        }
+        if (i > 0) {
+            TRY(bf_in_bwd(d.dtype, dact, sv.y[i - 1], nullptr, dact, (int)d.F, (int)rpf, cin, sv.mean[i - 1], sv.rstd[i - 1], p->in_w[i - 1],
+                          p->in_b[i - 1], nullptr, 1, 1, g->in_w[i - 1], g->in_b[i - 1], nullptr, nullptr, st));
+            dy = dact;
+        }
+    }
+    return 0;
+}

@@ -1,0 +1,298 @@
+// InstanceNorm (per frame, per channel over the frame's tokens) statistics, backward, and the
+// element-wise affine / residual kernels of the token-major FiLMAViT path.
+// All statistics and reductions are fp32 whatever the activation dtype; global access is in 16-byte
+// chunks (8 bf16 / 4 f32) so a 64-channel slab row is one 128-/256-byte coalesced segment.
+#include "bf_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int CPB = 64;  // channels per block
+
+template <typename T> struct Geo {
+    static constexpr int CH = Chunk<T>::N;
+    static constexpr int LC = CPB / CH;   // chunk lanes per row
+    static constexpr int RG = NT / LC;    // row groups
+};
+
+// block-wide reduction of CH per-thread partials over the RG row groups; result valid in every thread
+template <typename T, int NV>
+__device__ __forceinline__ void reduce_rows(float (&v)[NV][Chunk<T>::N], float* sm) {
+    constexpr int CH = Chunk<T>::N, LC = Geo<T>::LC, RG = Geo<T>::RG;
+    const int tid = threadIdx.x, lc = tid % LC, rg = tid / LC;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < CH; ++j) sm[(rg * LC + lc) * CH + j] = v[q][j];
+        __syncthreads();
+        for (int s = RG / 2; s > 0; s >>= 1) {
+            if (rg < s) {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) sm[(rg * LC + lc) * CH + j] += sm[((rg + s) * LC + lc) * CH + j];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) v[q][j] = sm[lc * CH + j];
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------ stats
+// grid: (frames, ceil(C / 64)).  Two-pass (mean, then centred second moment) -- no E[x^2]-E[x]^2.
+template <typename T>
+__global__ void __launch_bounds__(NT) in_stats_kernel(const T* __restrict__ x, int S, int C, const float* __restrict__ w,
+                                                     const float* __restrict__ b, const float* __restrict__ g, int gdiv,
+                                                     const float* __restrict__ gb, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, float* __restrict__ sc, float* __restrict__ sh) {
+    constexpr int CH = Chunk<T>::N, LC = Geo<T>::LC, RG = Geo<T>::RG;
+    __shared__ float sm[NT * CH];
+    const int f = blockIdx.x, c0 = blockIdx.y * CPB;
+    const int tid = threadIdx.x, lc = tid % LC, rg = tid / LC;
+    const int c = c0 + lc * CH;
+    const bool cv = c < C;
+    const T* xf = x + (long)f * S * C + c;
+    float acc[1][CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc[0][j] = 0.f;
+    if (cv)
+        for (int s = rg; s < S; s += RG) {
+            Chunk<T> v;
+            v.load(xf + (long)s * C);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) acc[0][j] += v.get(j);
+        }
+    reduce_rows<T, 1>(acc, sm);
+    float mu[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { mu[j] = acc[0][j] / (float)S; acc[0][j] = 0.f; }
+    if (cv)
+        for (int s = rg; s < S; s += RG) {
+            Chunk<T> v;
+            v.load(xf + (long)s * C);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) { const float d = v.get(j) - mu[j]; acc[0][j] += d * d; }
+        }
+    reduce_rows<T, 1>(acc, sm);
+    if (cv && rg == 0) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const float r = rsqrtf(acc[0][j] / (float)S + BF_IN_EPS);
+            const long o = (long)f * C + c + j;
+            float a = r * w[c + j];
+            float s0 = b[c + j] - mu[j] * a;
+            if (g) {                      // optional per-(frame group, channel) post scale/shift (FiLM, layer scale)
+                const long gi = (long)(f / gdiv) * C + c + j;
+                const float gg = g[gi];
+                a *= gg;
+                s0 = s0 * gg + (gb ? gb[gi] : 0.f);
+            }
+            mean[o] = mu[j];
+            rstd[o] = r;
+            sc[o] = a;
+            sh[o] = s0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ apply
+// out = [resid +] z * sc[f, c] + sh[f, c]      (grid-stride over 16-byte chunks)
+template <typename T>
+__global__ void __launch_bounds__(NT) affine_apply_kernel(const T* __restrict__ z, const T* __restrict__ resid,
+                                                         const float* __restrict__ sc, const float* __restrict__ sh,
+                                                         T* __restrict__ out, long nrows, int S, int C) {
+    constexpr int CH = Chunk<T>::N;
+    const int cpr = C / CH;
+    const long total = nrows * cpr;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const long row = i / cpr;
+        const int c = (int)(i % cpr) * CH;
+        const long f = row / S;
+        Chunk<T> v, r, o;
+        v.load(z + row * C + c);
+        if (resid) r.load(resid + row * C + c);
+        const float* a = sc + f * C + c;
+        const float* b = sh + f * C + c;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            float t = v.get(j) * a[j] + b[j];
+            if (resid) t += r.get(j);
+            o.set(j, t);
+        }
+        o.store(out + row * C + c);
+    }
+}
+
+// ------------------------------------------------------------------------------------ backward
+// y = act( xhat * w + b ) [* g],  xhat = (x - mean) * rstd, act = identity | GELU.
+// Given dy: s1 = sum_s dyn, s2 = sum_s dyn * xhat  (dyn = dy * act'),  per (frame, channel)
+//   dx = rstd * w * g * (dyn - s1/S - xhat * s2/S) [+ add]
+//   dw += g * s2, db += g * s1, dg += w * s2 + b * s1, dgb += s1     (fp32 atomics over frames)
+template <typename T, bool GELU>
+__global__ void __launch_bounds__(NT) in_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ add,
+                                                   T* __restrict__ dx, int S, int C, const float* __restrict__ mean,
+                                                   const float* __restrict__ rstd, const float* __restrict__ w,
+                                                   const float* __restrict__ b, const float* __restrict__ g, int gdiv,
+                                                   float* __restrict__ dw, float* __restrict__ db, float* __restrict__ dg,
+                                                   float* __restrict__ dgb) {
+    constexpr int CH = Chunk<T>::N, LC = Geo<T>::LC, RG = Geo<T>::RG;
+    __shared__ float sm[NT * CH];
+    const int f = blockIdx.x, c0 = blockIdx.y * CPB;
+    const int tid = threadIdx.x, lc = tid % LC, rg = tid / LC;
+    const int c = c0 + lc * CH;
+    const bool cv = c < C;
+    const long base = (long)f * S * C + c;
+    float mu[CH], rs[CH], ww[CH], bb[CH], gg[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        mu[j] = cv ? mean[(long)f * C + c + j] : 0.f;
+        rs[j] = cv ? rstd[(long)f * C + c + j] : 0.f;
+        ww[j] = cv ? w[c + j] : 0.f;
+        bb[j] = cv ? b[c + j] : 0.f;
+        gg[j] = (cv && g) ? g[(long)(f / gdiv) * C + c + j] : 1.f;
+    }
+    float acc[2][CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc[0][j] = acc[1][j] = 0.f;
+    if (cv)
+        for (int s = rg; s < S; s += RG) {
+            Chunk<T> d, v;
+            d.load(dy + base + (long)s * C);
+            v.load(x + base + (long)s * C);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const float xh = (v.get(j) - mu[j]) * rs[j];
+                float dd = d.get(j);
+                if (GELU) dd *= dgelu_f(xh * ww[j] + bb[j]);
+                acc[0][j] += dd;
+                acc[1][j] += dd * xh;
+            }
+        }
+    reduce_rows<T, 2>(acc, sm);
+    if (cv)
+        for (int s = rg; s < S; s += RG) {
+            Chunk<T> d, v, a, o;
+            d.load(dy + base + (long)s * C);
+            v.load(x + base + (long)s * C);
+            if (add) a.load(add + base + (long)s * C);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const float xh = (v.get(j) - mu[j]) * rs[j];
+                float dd = d.get(j);
+                if (GELU) dd *= dgelu_f(xh * ww[j] + bb[j]);
+                float t = rs[j] * ww[j] * gg[j] * (dd - (acc[0][j] + xh * acc[1][j]) / (float)S);
+                if (add) t += a.get(j);
+                o.set(j, t);
+            }
+            o.store(dx + base + (long)s * C);
+        }
+    if (cv && rg == 0) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            if (dw) atomicAdd(dw + c + j, gg[j] * acc[1][j]);
+            if (db) atomicAdd(db + c + j, gg[j] * acc[0][j]);
+            if (dg) atomicAdd(dg + (long)(f / gdiv) * C + c + j, ww[j] * acc[1][j] + bb[j] * acc[0][j]);
+            if (dgb) atomicAdd(dgb + (long)(f / gdiv) * C + c + j, acc[0][j]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ column sums
+// out[c] += scale[c] * sum_rows x[row][c]      grid: (row blocks, ceil(C/64))
+template <typename T>
+__global__ void __launch_bounds__(NT) colsum_kernel(const T* __restrict__ x, long nrows, int C, long rows_per_block,
+                                                   const float* __restrict__ scale, float* __restrict__ out) {
+    constexpr int CH = Chunk<T>::N, LC = Geo<T>::LC, RG = Geo<T>::RG;
+    __shared__ float sm[NT * CH];
+    const int tid = threadIdx.x, lc = tid % LC, rg = tid / LC;
+    const int c = blockIdx.y * CPB + lc * CH;
+    const bool cv = c < C;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(nrows, r0 + rows_per_block);
+    float acc[1][CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc[0][j] = 0.f;
+    if (cv)
+        for (long r = r0 + rg; r < r1; r += RG) {
+            Chunk<T> v;
+            v.load(x + r * C + c);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) acc[0][j] += v.get(j);
+        }
+    reduce_rows<T, 1>(acc, sm);
+    if (cv && rg == 0) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) atomicAdd(out + c + j, acc[0][j] * (scale ? scale[c + j] : 1.f));
+    }
+}
+
+template <typename T>
+int chunk_ok(int C) { return C % Chunk<T>::N == 0; }
+
+}  // namespace
+
+extern "C" int bf_in_stats(int dtype, const void* x, int frames, int S, int C, const float* w, const float* b,
+                           const float* g, int gdiv, const float* gb, float* mean, float* rstd, float* sc, float* sh,
+                           bf_stream_t stream) {
+    BF_REQUIRE(x && w && b && mean && rstd && sc && sh, "bf_in_stats: null pointer");
+    BF_REQUIRE(frames > 0 && S > 0 && C > 0, "bf_in_stats: empty");
+    dim3 grid(frames, bf_cdiv(C, CPB));
+    if (gdiv < 1) gdiv = 1;
+    if (dtype == BF_DTYPE_BF16) {
+        BF_REQUIRE(chunk_ok<bf16>(C), "bf_in_stats: C must be a multiple of 8 (bf16)");
+        hipLaunchKernelGGL(in_stats_kernel<bf16>, grid, dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh);
+    } else {
+        BF_REQUIRE(chunk_ok<float>(C), "bf_in_stats: C must be a multiple of 4 (f32)");
+        hipLaunchKernelGGL(in_stats_kernel<float>, grid, dim3(NT), 0, (hipStream_t)stream, (const float*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh);
+    }
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bf_affine_apply(int dtype, const void* z, const void* resid, const float* sc, const float* sh, void* out,
+                               int64_t nrows, int S, int C, bf_stream_t stream) {
+    BF_REQUIRE(z && sc && sh && out && nrows > 0 && S > 0, "bf_affine_apply: bad arguments");
+    const int ch = dtype == BF_DTYPE_BF16 ? 8 : 4;
+    BF_REQUIRE(C % ch == 0, "bf_affine_apply: C must be a multiple of the 16-byte chunk");
+    const long total = nrows * (C / ch);
+    const int grid = (int)std::min<long>((total + NT - 1) / NT, 256 * 16);
+    if (dtype == BF_DTYPE_BF16)
+        hipLaunchKernelGGL(affine_apply_kernel<bf16>, dim3(grid), dim3(NT), 0, (hipStream_t)stream, (const bf16*)z, (const bf16*)resid, sc, sh, (bf16*)out, (long)nrows, S, C);
+    else
+        hipLaunchKernelGGL(affine_apply_kernel<float>, dim3(grid), dim3(NT), 0, (hipStream_t)stream, (const float*)z, (const float*)resid, sc, sh, (float*)out, (long)nrows, S, C);
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bf_in_bwd(int dtype, const void* dy, const void* x, const void* add, void* dx, int frames, int S, int C,
+                         const float* mean, const float* rstd, const float* w, const float* b, const float* g, int gdiv,
+                         int gelu, float* dw, float* db, float* dg, float* dgb, bf_stream_t stream) {
+    BF_REQUIRE(dy && x && dx && mean && rstd && w && b, "bf_in_bwd: null pointer");
+    const int ch = dtype == BF_DTYPE_BF16 ? 8 : 4;
+    BF_REQUIRE(C % ch == 0, "bf_in_bwd: C must be a multiple of the 16-byte chunk");
+    dim3 grid(frames, bf_cdiv(C, CPB));
+    if (gdiv < 1) gdiv = 1;
+    hipStream_t st = (hipStream_t)stream;
+#define GO(T, G) hipLaunchKernelGGL((in_bwd_kernel<T, G>), grid, dim3(NT), 0, st, (const T*)dy, (const T*)x, (const T*)add, (T*)dx, S, C, mean, rstd, w, b, g, gdiv, dw, db, dg, dgb)
+    if (dtype == BF_DTYPE_BF16) { if (gelu) GO(bf16, true); else GO(bf16, false); }
+    else { if (gelu) GO(float, true); else GO(float, false); }
+#undef GO
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bf_colsum(int dtype, const void* x, int64_t nrows, int C, const float* scale, float* out, bf_stream_t stream) {
+    BF_REQUIRE(x && out && nrows > 0 && C > 0, "bf_colsum: bad arguments");
+    const int ch = dtype == BF_DTYPE_BF16 ? 8 : 4;
+    BF_REQUIRE(C % ch == 0, "bf_colsum: C must be a multiple of the 16-byte chunk");
+    const int cb = bf_cdiv(C, CPB);
+    long rpb = std::max<long>(64, (nrows * cb + 1023) / 1024);   // ~1024 blocks
+    dim3 grid(bf_cdiv(nrows, rpb), cb);
+    if (dtype == BF_DTYPE_BF16)
+        hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, (long)nrows, C, rpb, scale, out);
+    else
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(NT), 0, (hipStream_t)stream, (const float*)x, (long)nrows, C, rpb, scale, out);
+    BF_CHECK_LAUNCH();
+    return 0;
+}

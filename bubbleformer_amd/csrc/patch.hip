@@ -1,0 +1,364 @@
+// Layout movers at the two ends of the model, FiLM, the relative-L2 loss and weight preparation.
+//   im2col_nchw / col2im_nchw : (B*T, C, H, W) fp32 clip  <->  2x2 patch rows [P][Kp] (k = (c, ky, kx))
+//   pm2nchw (+ loss partials)  : last debed GEMM output [P][Np] fp32 (n = (co, ky, kx)) -> (B*T, Co, H, W) fp32
+//   nchw2pm (+ loss backward)  : d(pred) -> patch-major rows for the debed backward GEMMs
+//   wprep / wgrad_unprep       : fp32 state_dict weights -> GEMM operand layout/dtype and back (gradients)
+//   film_net fwd/bwd           : LayerNorm(P) + Linear(P, 2E) on B rows
+//   adamw                      : fused flat-buffer AdamW
+// All are bandwidth-bound; each thread moves 8..16 contiguous bytes where the layout allows.
+#include "bf_common.h"
+
+namespace {
+constexpr int NT = 256;
+
+// ---------------------------------------------------------------------------- im2col (stage 0 of HMLPEmbed)
+// x: [F][C][H][W] fp32.  rows p = (f, y, x) over the (H/2, W/2) grid; row = Kp elements, k = c*4 + ky*2 + kx, zero padded.
+template <typename T>
+__global__ void __launch_bounds__(NT) im2col_kernel(const float* __restrict__ x, T* __restrict__ out, int C, int H, int W,
+                                                   int Kp, long P) {
+    const int W2 = W / 2, H2 = H / 2;
+    const long total = P * C;   // one thread per (pixel, channel): reads 2 x float2, writes 4 elements
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int xo = (int)(i % W2);
+        long t = i / W2;
+        const int c = (int)(t % C);        // channel inner to x so that a wave reads contiguous image rows
+        t /= C;
+        const int yo = (int)(t % H2);
+        const long f = t / H2;
+        const float* src = x + ((f * C + c) * H + 2 * yo) * (long)W + 2 * xo;
+        const float2 r0 = *reinterpret_cast<const float2*>(src);
+        const float2 r1 = *reinterpret_cast<const float2*>(src + W);
+        const long p = (f * H2 + yo) * W2 + xo;
+        T* dst = out + p * Kp + c * 4;
+        dst[0] = from_f<T>(r0.x); dst[1] = from_f<T>(r0.y); dst[2] = from_f<T>(r1.x); dst[3] = from_f<T>(r1.y);
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(NT) zero_pad_cols_kernel(T* __restrict__ out, int K, int Kp, long P) {
+    const int padw = Kp - K;
+    const long total = P * padw;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT)
+        out[(i / padw) * Kp + K + (i % padw)] = from_f<T>(0.f);
+}
+// dx[f][c][2y+ky][2x+kx] = g[p][c*4 + ky*2 + kx]
+template <typename T>
+__global__ void __launch_bounds__(NT) col2im_kernel(const T* __restrict__ g, float* __restrict__ dx, int C, int H, int W, int Kp, long P) {
+    const int W2 = W / 2, H2 = H / 2;
+    const long total = P * C;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int xo = (int)(i % W2);
+        long t = i / W2;
+        const int c = (int)(t % C);
+        t /= C;
+        const int yo = (int)(t % H2);
+        const long f = t / H2;
+        const long p = (f * H2 + yo) * W2 + xo;
+        const T* src = g + p * Kp + c * 4;
+        float* dst = dx + ((f * C + c) * H + 2 * yo) * (long)W + 2 * xo;
+        *reinterpret_cast<float2*>(dst) = make_float2(to_f(src[0]), to_f(src[1]));
+        *reinterpret_cast<float2*>(dst + W) = make_float2(to_f(src[2]), to_f(src[3]));
+    }
+}
+
+// ---------------------------------------------------------------------------- pm2nchw + loss partials
+// pm: [P][Np] fp32, n = co*4 + ky*2 + kx; pred: [F][Co][H][W]; grid (blocks over h*w pixels, F)
+// lossbuf[f][co][0] += sum (pred - y)^2, [1] += sum y^2
+__global__ void __launch_bounds__(NT) pm2nchw_kernel(const float* __restrict__ pm, float* __restrict__ pred, const float* __restrict__ y,
+                                                    float* __restrict__ lossbuf, int Co, int h, int w, int Np) {
+    __shared__ float red[NT / 64][2];
+    const int f = blockIdx.y;
+    const int H = 2 * h, W = 2 * w;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int co = 0; co < Co; ++co) {
+        float num = 0.f, den = 0.f;
+        for (int px = blockIdx.x * NT + threadIdx.x; px < h * w; px += gridDim.x * NT) {
+            const int xo = px % w, yo = px / w;
+            const float4 v = *reinterpret_cast<const float4*>(pm + ((long)f * h * w + px) * Np + co * 4);
+            const long o = (((long)f * Co + co) * H + 2 * yo) * W + 2 * xo;
+            *reinterpret_cast<float2*>(pred + o) = make_float2(v.x, v.y);
+            *reinterpret_cast<float2*>(pred + o + W) = make_float2(v.z, v.w);
+            if (y) {
+                const float2 y0 = *reinterpret_cast<const float2*>(y + o);
+                const float2 y1 = *reinterpret_cast<const float2*>(y + o + W);
+                num += (v.x - y0.x) * (v.x - y0.x) + (v.y - y0.y) * (v.y - y0.y) + (v.z - y1.x) * (v.z - y1.x) + (v.w - y1.y) * (v.w - y1.y);
+                den += y0.x * y0.x + y0.y * y0.y + y1.x * y1.x + y1.y * y1.y;
+            }
+        }
+        if (y) {
+            num = wave_sum(num); den = wave_sum(den);
+            __syncthreads();
+            if (lane == 0) { red[wave][0] = num; red[wave][1] = den; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float a = 0.f, b = 0.f;
+                for (int i = 0; i < NT / 64; ++i) { a += red[i][0]; b += red[i][1]; }
+                atomicAdd(lossbuf + ((long)f * Co + co) * 2, a);
+                atomicAdd(lossbuf + ((long)f * Co + co) * 2 + 1, b);
+            }
+        }
+    }
+}
+// loss = sum_c mean_f sqrt(num/den);  coef[f][c] = 1 / (F * sqrt(num) * sqrt(den))   (single block)
+__global__ void lploss_finalize_kernel(const float* __restrict__ lossbuf, int F, int Co, float* __restrict__ loss, float* __restrict__ coef) {
+    __shared__ float red[NT];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < F * Co; i += NT) {
+        const float num = lossbuf[2 * i], den = lossbuf[2 * i + 1];
+        acc += sqrtf(num) / sqrtf(den);
+        if (coef) coef[i] = 1.0f / ((float)F * sqrtf(num) * sqrtf(den));
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = NT / 2; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) loss[0] = red[0] / (float)F;
+}
+// dpm[p][n] = dpred[f][co][2y+ky][2x+kx]   with dpred either given, or coef[f][co] * gscale * (pred - y)
+template <typename T>
+__global__ void __launch_bounds__(NT) nchw2pm_kernel(const float* __restrict__ dpred, const float* __restrict__ pred, const float* __restrict__ y,
+                                                    const float* __restrict__ coef, const float* __restrict__ gscale, T* __restrict__ dpm,
+                                                    int Co, int h, int w, int Np, long P) {
+    const int H = 2 * h, W = 2 * w;
+    const int nq = Np / 4;   // groups of 4 columns (one co each; groups >= Co are zero padding)
+    const long total = P * nq;
+    const float gs = gscale ? gscale[0] : 1.f;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int co = (int)(i % nq);
+        const long p = i / nq;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        if (co < Co) {
+            const int xo = (int)(p % w);
+            const long t = p / w;
+            const int yo = (int)(t % h);
+            const long f = t / h;
+            const long o = ((f * Co + co) * H + 2 * yo) * (long)W + 2 * xo;
+            if (dpred) {
+                const float2 a = *reinterpret_cast<const float2*>(dpred + o), b = *reinterpret_cast<const float2*>(dpred + o + W);
+                v0 = a.x; v1 = a.y; v2 = b.x; v3 = b.y;
+            } else {
+                const float cf = coef[f * Co + co] * gs;
+                const float2 a = *reinterpret_cast<const float2*>(pred + o), b = *reinterpret_cast<const float2*>(pred + o + W);
+                const float2 c = *reinterpret_cast<const float2*>(y + o), d = *reinterpret_cast<const float2*>(y + o + W);
+                v0 = cf * (a.x - c.x); v1 = cf * (a.y - c.y); v2 = cf * (b.x - d.x); v3 = cf * (b.y - d.y);
+            }
+        }
+        T* dst = dpm + p * Np + co * 4;
+        dst[0] = from_f<T>(v0); dst[1] = from_f<T>(v1); dst[2] = from_f<T>(v2); dst[3] = from_f<T>(v3);
+    }
+}
+
+// ---------------------------------------------------------------------------- weight preparation
+// modes: 0 cast/pad rows: [R][K] -> [R][Kp]
+//        1 conv k2s2  [Co][Ci][2][2] -> [Co][(ky,kx,ci)]
+//        2 convT k2s2 [Ci][Co][2][2] -> [(ky,kx,co)][Ci]
+template <typename T>
+__global__ void __launch_bounds__(NT) wprep_kernel(const float* __restrict__ src, T* __restrict__ dst, int mode, int R, int K, int Kp) {
+    const long total = (long)R * Kp;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int r = (int)(i / Kp), k = (int)(i % Kp);
+        float v = 0.f;
+        if (mode == 0) { if (k < K) v = src[(long)r * K + k]; }
+        else if (mode == 1) {          // R = Co, K = Kp = 4*Ci ; k = (ky*2+kx)*Ci + ci
+            const int Ci = K / 4, q = k / Ci, ci = k % Ci;
+            v = src[((long)r * Ci + ci) * 4 + q];
+        } else {                       // mode 2: R = 4*Co rows r = q*Co + co ; K = Ci
+            const int Co = R / 4, q = r / Co, co = r % Co;
+            v = src[((long)k * Co + co) * 4 + q];
+        }
+        dst[i] = from_f<T>(v);
+    }
+}
+// gradient of the prepared operand (fp32, prepared layout) accumulated into the state_dict layout
+__global__ void __launch_bounds__(NT) wgrad_unprep_kernel(const float* __restrict__ gsrc, float* __restrict__ gdst, int mode, int R, int K, int Kp,
+                                                         int transposed) {
+    const long total = (long)R * K;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int r = (int)(i / K), k = (int)(i % K);
+        // transposed: gsrc is [Kp_rows = k][R] (the GEMM produced the transpose)
+        const float v = transposed ? gsrc[(long)k * R + r] : gsrc[(long)r * Kp + k];
+        long o;
+        if (mode == 0) o = (long)r * K + k;
+        else if (mode == 1) { const int Ci = K / 4, q = k / Ci, ci = k % Ci; o = ((long)r * Ci + ci) * 4 + q; }
+        else { const int Co = R / 4, q = r / Co, co = r % Co; o = ((long)k * Co + co) * 4 + q; }
+        gdst[o] += v;
+    }
+}
+
+// ---------------------------------------------------------------------------- FiLM net (B rows; one block)
+// gb[b][0:E] = gamma, gb[b][E:2E] = beta ;  c = LN(cond) ; gb = c @ W^T + bias
+__global__ void film_net_fwd_kernel(const float* __restrict__ cond, const float* __restrict__ lnw, const float* __restrict__ lnb,
+                                    const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ gb,
+                                    float* __restrict__ chat, float* __restrict__ crstd, int B, int P, int E2) {
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        float mu = 0.f;
+        for (int i = 0; i < P; ++i) mu += cond[b * P + i];
+        mu /= (float)P;
+        float var = 0.f;
+        for (int i = 0; i < P; ++i) { const float t = cond[b * P + i] - mu; var += t * t; }
+        const float r = rsqrtf(var / (float)P + BF_IN_EPS);
+        if (threadIdx.x == 0) crstd[b] = r;
+        for (int i = threadIdx.x; i < P; i += blockDim.x) chat[b * P + i] = (cond[b * P + i] - mu) * r;
+        for (int o = threadIdx.x; o < E2; o += blockDim.x) {
+            float acc = bias[o];
+            for (int i = 0; i < P; ++i) acc += ((cond[b * P + i] - mu) * r * lnw[i] + lnb[i]) * W[(long)o * P + i];
+            gb[(long)(o / (E2 / 2)) * B * (E2 / 2) + (long)b * (E2 / 2) + (o % (E2 / 2))] = acc;   // [2][B][E]
+        }
+    }
+}
+// dgb: [B][2E] (dgamma | dbeta).  Single block.  dW[o][i] += sum_b dgb[b][o] c[b][i]; dbias[o] += sum_b dgb;
+// dc[b][i] = sum_o dgb[b][o] W[o][i]; dlnw[i] += sum_b dc*chat; dlnb[i] += sum_b dc   (d cond is not needed)
+__global__ void film_net_bwd_kernel(const float* __restrict__ dgb_, const float* __restrict__ chat, const float* __restrict__ lnw,
+                                    const float* __restrict__ lnb, const float* __restrict__ W, float* __restrict__ dW,
+                                    float* __restrict__ dbias, float* __restrict__ dlnw, float* __restrict__ dlnb, int B, int P, int E2) {
+    const int E = E2 / 2;
+    auto DGB = [&](int b, int o) { return dgb_[(long)(o / E) * B * E + (long)b * E + (o % E)]; };   // [2][B][E]
+    for (int o = threadIdx.x; o < E2; o += blockDim.x) {
+        float sb = 0.f;
+        for (int b = 0; b < B; ++b) sb += DGB(b, o);
+        dbias[o] += sb;
+        for (int i = 0; i < P; ++i) {
+            float acc = 0.f;
+            for (int b = 0; b < B; ++b) acc += DGB(b, o) * (chat[b * P + i] * lnw[i] + lnb[i]);
+            dW[(long)o * P + i] += acc;
+        }
+    }
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        float sw = 0.f, sbias = 0.f;
+        for (int b = 0; b < B; ++b) {
+            float dc = 0.f;
+            for (int o = 0; o < E2; ++o) dc += DGB(b, o) * W[(long)o * P + i];
+            sw += dc * chat[b * P + i];
+            sbias += dc;
+        }
+        dlnw[i] += sw;
+        dlnb[i] += sbias;
+    }
+}
+
+// ---------------------------------------------------------------------------- AdamW (torch.optim.AdamW semantics)
+__global__ void __launch_bounds__(NT) adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                  float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
+                                                  float bc1, float sqrt_bc2, float gscale) {
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+#define BF_ADAM1(X)                                                        \
+        { const float gr = gg.X * gscale;                                   \
+          pp.X *= (1.f - lr * wd);                                          \
+          mm.X = b1 * mm.X + (1.f - b1) * gr;                               \
+          vv.X = b2 * vv.X + (1.f - b2) * gr * gr;                          \
+          pp.X -= (lr / bc1) * mm.X / (sqrtf(vv.X) / sqrt_bc2 + eps); }
+        BF_ADAM1(x) BF_ADAM1(y) BF_ADAM1(z) BF_ADAM1(w)
+#undef BF_ADAM1
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - n4 * 4) {
+        const long i = n4 * 4 + threadIdx.x;
+        const float gr = g[i] * gscale;
+        float pp = p[i] * (1.f - lr * wd);
+        const float mm = b1 * m[i] + (1.f - b1) * gr;
+        const float vv = b2 * v[i] + (1.f - b2) * gr * gr;
+        pp -= (lr / bc1) * mm / (sqrtf(vv) / sqrt_bc2 + eps);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
+int grid_for(long total) { return (int)std::max<long>(1, std::min<long>((total + NT - 1) / NT, 256L * 16)); }
+}  // namespace
+
+extern "C" int bf_im2col_nchw(int dtype, const float* x, void* out, int frames, int C, int H, int W, int Kp, bf_stream_t stream) {
+    BF_REQUIRE(x && out && frames > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Kp >= 4 * C, "bf_im2col_nchw: bad arguments");
+    const long P = (long)frames * (H / 2) * (W / 2);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == BF_DTYPE_BF16) {
+        hipLaunchKernelGGL(im2col_kernel<bf16>, dim3(grid_for(P * C)), dim3(NT), 0, st, x, (bf16*)out, C, H, W, Kp, P);
+        if (Kp > 4 * C) hipLaunchKernelGGL(zero_pad_cols_kernel<bf16>, dim3(grid_for(P * (Kp - 4 * C))), dim3(NT), 0, st, (bf16*)out, 4 * C, Kp, P);
+    } else {
+        hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid_for(P * C)), dim3(NT), 0, st, x, (float*)out, C, H, W, Kp, P);
+        if (Kp > 4 * C) hipLaunchKernelGGL(zero_pad_cols_kernel<float>, dim3(grid_for(P * (Kp - 4 * C))), dim3(NT), 0, st, (float*)out, 4 * C, Kp, P);
+    }
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bf_col2im_nchw(int dtype, const void* g, float* dx, int frames, int C, int H, int W, int Kp, bf_stream_t stream) {
+    BF_REQUIRE(g && dx && frames > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && Kp >= 4 * C, "bf_col2im_nchw: bad arguments");
+    const long P = (long)frames * (H / 2) * (W / 2);
+    if (dtype == BF_DTYPE_BF16) hipLaunchKernelGGL(col2im_kernel<bf16>, dim3(grid_for(P * C)), dim3(NT), 0, (hipStream_t)stream, (const bf16*)g, dx, C, H, W, Kp, P);
+    else hipLaunchKernelGGL(col2im_kernel<float>, dim3(grid_for(P * C)), dim3(NT), 0, (hipStream_t)stream, (const float*)g, dx, C, H, W, Kp, P);
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bf_pm2nchw(const float* pm, float* pred, const float* y, float* lossbuf, int frames, int Co, int h, int w, int Np,
+                          bf_stream_t stream) {
+    BF_REQUIRE(pm && pred && frames > 0 && Co > 0 && h > 0 && w > 0 && Np >= 4 * Co && Np % 4 == 0, "bf_pm2nchw: bad arguments");
+    BF_REQUIRE(!y || lossbuf, "bf_pm2nchw: loss buffer missing");
+    dim3 grid(std::max(1, std::min(bf_cdiv((long)h * w, NT), 64)), frames);
+    hipLaunchKernelGGL(pm2nchw_kernel, grid, dim3(NT), 0, (hipStream_t)stream, pm, pred, y, lossbuf, Co, h, w, Np);
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bf_lploss_finalize(const float* lossbuf, int frames, int Co, float* loss, float* coef, bf_stream_t stream) {
+    BF_REQUIRE(lossbuf && loss && frames > 0 && Co > 0, "bf_lploss_finalize: bad arguments");
+    hipLaunchKernelGGL(lploss_finalize_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, lossbuf, frames, Co, loss, coef);
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bf_nchw2pm(int dtype, const float* dpred, const float* pred, const float* y, const float* coef, const float* gscale,
+                          void* dpm, int frames, int Co, int h, int w, int Np, bf_stream_t stream) {
+    BF_REQUIRE(dpm && (dpred || (pred && y && coef)) && Np >= 4 * Co && Np % 4 == 0, "bf_nchw2pm: bad arguments");
+    const long P = (long)frames * h * w;
+    if (dtype == BF_DTYPE_BF16) hipLaunchKernelGGL(nchw2pm_kernel<bf16>, dim3(grid_for(P * (Np / 4))), dim3(NT), 0, (hipStream_t)stream, dpred, pred, y, coef, gscale, (bf16*)dpm, Co, h, w, Np, P);
+    else hipLaunchKernelGGL(nchw2pm_kernel<float>, dim3(grid_for(P * (Np / 4))), dim3(NT), 0, (hipStream_t)stream, dpred, pred, y, coef, gscale, (float*)dpm, Co, h, w, Np, P);
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bf_wprep(int dtype, int mode, const float* src, void* dst, int R, int K, int Kp, bf_stream_t stream) {
+    BF_REQUIRE(src && dst && R > 0 && K > 0 && Kp >= K && mode >= 0 && mode <= 2, "bf_wprep: bad arguments");
+    BF_REQUIRE(mode == 0 || Kp == K, "bf_wprep: padding only with mode 0");
+    if (dtype == BF_DTYPE_BF16) hipLaunchKernelGGL(wprep_kernel<bf16>, dim3(grid_for((long)R * Kp)), dim3(NT), 0, (hipStream_t)stream, src, (bf16*)dst, mode, R, K, Kp);
+    else hipLaunchKernelGGL(wprep_kernel<float>, dim3(grid_for((long)R * Kp)), dim3(NT), 0, (hipStream_t)stream, src, (float*)dst, mode, R, K, Kp);
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bf_wgrad_unprep(int mode, const float* gsrc, float* gdst, int R, int K, int Kp, int transposed, bf_stream_t stream) {
+    BF_REQUIRE(gsrc && gdst && R > 0 && K > 0 && Kp >= K && mode >= 0 && mode <= 2, "bf_wgrad_unprep: bad arguments");
+    hipLaunchKernelGGL(wgrad_unprep_kernel, dim3(grid_for((long)R * K)), dim3(NT), 0, (hipStream_t)stream, gsrc, gdst, mode, R, K, Kp, transposed);
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bf_film_net_fwd(const float* cond, const float* lnw, const float* lnb, const float* W, const float* bias, float* gb,
+                               float* chat, float* crstd, int B, int P, int E2, bf_stream_t stream) {
+    BF_REQUIRE(cond && lnw && lnb && W && bias && gb && chat && crstd && B > 0 && P > 0 && E2 > 0, "bf_film_net_fwd: bad arguments");
+    hipLaunchKernelGGL(film_net_fwd_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, cond, lnw, lnb, W, bias, gb, chat, crstd, B, P, E2);
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bf_film_net_bwd(const float* dgb, const float* chat, const float* lnw, const float* lnb, const float* W, float* dW,
+                               float* dbias, float* dlnw, float* dlnb, int B, int P, int E2, bf_stream_t stream) {
+    BF_REQUIRE(dgb && chat && lnw && lnb && W && dW && dbias && dlnw && dlnb, "bf_film_net_bwd: bad arguments");
+    hipLaunchKernelGGL(film_net_bwd_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, dgb, chat, lnw, lnb, W, dW, dbias, dlnw, dlnb, B, P, E2);
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bf_adamw(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float beta1, float beta2,
+                        float eps, float wd, float gscale, bf_stream_t stream) {
+    BF_REQUIRE(p && g && m && v && n > 0 && step >= 1, "bf_adamw: bad arguments");
+    BF_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0), "bf_adamw: buffers must be 16-byte aligned");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float sbc2 = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr, beta1, beta2, eps, wd, bc1, sbc2, gscale);
+    BF_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,36 @@
+"""Thin tensor-level wrappers over the kernel-level C entry points (used by the parity tests and by tools).
+No autograd here: these call exactly one native entry point each."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .ops import _dt, _p, _stream
+
+
+def operand(t=None, ld=0, layout=L.BF_LAY_KC, seglen=0, segstride=0, gw=0, gh=0, gc=0, pro=L.BF_PRO_NONE, sc=None, sh=None,
+            rows_per_frame=0, nch=0) -> L.Operand:
+    return L.Operand(_p(t), ld, layout, seglen, segstride, gw, gh, gc, pro, _p(sc), _p(sh), rows_per_frame, nch)
+
+
+def epilogue(c, ldc, bias=None, colscale=None, colshift=None, aux_mode=L.BF_AUX_NONE, aux=None, ld_aux=0, out_mode=L.BF_OUT_STORE,
+             seglen=0, segstride=0, gw=0, gh=0, gc=0) -> L.Epilogue:
+    return L.Epilogue(_p(bias), _p(colscale), _p(colshift), aux_mode, _p(aux), ld_aux, out_mode, _p(c), ldc, seglen, segstride, gw, gh, gc)
+
+
+def gemm(dtype, M, N, K, A: L.Operand, B: L.Operand, E: L.Epilogue, splitk=1):
+    L.check(L.lib().bf_gemm(_dt(dtype), M, N, K, C.byref(A), C.byref(B), C.byref(E), splitk, _stream()), "bf_gemm")
+
+
+def in_stats(x, frames, S, Cc, w, b, g=None, gdiv=1, gb=None):
+    dev = x.device
+    mean, rstd, sc, sh = (torch.empty(frames, Cc, dtype=torch.float32, device=dev) for _ in range(4))
+    L.check(L.lib().bf_in_stats(_dt(x.dtype), _p(x), frames, S, Cc, _p(w), _p(b), _p(g), gdiv, _p(gb), _p(mean), _p(rstd), _p(sc),
+                                _p(sh), _stream()), "bf_in_stats")
+    return mean, rstd, sc, sh
+
+
+def attn_fwd(qkv, out, nseq, Lq, inner, outer_stride, inner_stride, tok_stride, heads, d, qw, qb, kw, kb, emb, hscale, out_scale=1.0,
+             accumulate=False):
+    L.check(L.lib().bf_attn_fwd(_dt(qkv.dtype), _p(qkv), _p(out), nseq, Lq, inner, outer_stride, inner_stride, tok_stride, heads, d,
+                                _p(qw), _p(qb), _p(kw), _p(kb), _p(emb), _p(hscale), out_scale, int(accumulate), _stream()), "bf_attn_fwd")

@@ -1,0 +1,122 @@
+"""AttentionBlock (temporal) and AxialAttentionBlock (spatial) -- mirror of bubbleformer/layers/attention.py.
+
+The sub-module tree and parameter names are the reference's (identical ``state_dict``); ``forward`` hands the
+parameters to the fused HIP stage (csrc/model.hip).  Inputs/outputs keep the reference's logical shapes
+(B, N, E, h, w) / (B, E, h, w); physically they are token-major, so chained blocks exchange memory without copies.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .linear_layers import GeluMLP
+from .positional_encoding import RelativePositionBias
+
+
+class _StochasticDepthUnsupported(nn.Module):
+    """Placeholder for timm.layers.DropPath (layers/attention.py:64,194): stochastic depth is not wired into the fused
+    epilogues yet, so a training-mode forward with drop_path > 0 raises instead of silently skipping it."""
+
+    def __init__(self, p: float):
+        super().__init__()
+        self.drop_prob = p
+
+
+def _make_drop_path(p: float):
+    return _StochasticDepthUnsupported(p) if p > 0.0 else nn.Identity()
+
+
+def _check_drop_path(mod: nn.Module):
+    dp = mod.drop_path
+    if isinstance(dp, _StochasticDepthUnsupported) and mod.training:
+        raise NotImplementedError(
+            f"drop_path={dp.drop_prob} in training mode: stochastic depth is not implemented in the HIP blocks yet; "
+            "build the model with drop_path=0.0 or call .eval()")
+
+
+class AttentionBlock(nn.Module):
+    def __init__(self, embed_dim: int = 768, num_heads: int = 12, drop_path: float = 0, layer_scale_init_value: float = 1e-6,
+                 bias_type: str = "rel", attn_scale: bool = True):
+        super().__init__()
+        if bias_type != "rel":
+            raise NotImplementedError("only bias_type='rel' (the reference default, used by every config) is implemented")
+        if layer_scale_init_value <= 0:
+            raise NotImplementedError("layer scale is always on in the reference configs")
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.attn_scale = attn_scale
+        self.norm1 = nn.InstanceNorm2d(embed_dim, affine=True)
+        self.norm2 = nn.InstanceNorm2d(embed_dim, affine=True)
+        self.gamma = nn.Parameter(layer_scale_init_value * torch.ones((embed_dim)), requires_grad=True)
+        self.input_head = nn.Conv2d(embed_dim, 3 * embed_dim, 1)
+        self.output_head = nn.Conv2d(embed_dim, embed_dim, 1)
+        self.qnorm = nn.LayerNorm(embed_dim // num_heads)
+        self.knorm = nn.LayerNorm(embed_dim // num_heads)
+        if attn_scale:
+            self.attn_scale_factor = nn.Parameter(torch.ones((1, num_heads, 1, 1)), requires_grad=True)
+        self.rel_pos_bias = RelativePositionBias(n_heads=num_heads)
+        self.drop_path = _make_drop_path(drop_path)
+
+    def stage_params(self):
+        return [self.gamma, self.attn_scale_factor if self.attn_scale else None, self.norm1.weight, self.norm1.bias,
+                self.norm2.weight, self.norm2.bias, self.input_head.weight, self.input_head.bias, self.output_head.weight,
+                self.output_head.bias, self.qnorm.weight, self.qnorm.bias, self.knorm.weight, self.knorm.bias,
+                self.rel_pos_bias.relative_attention_bias.weight]
+
+    def forward_tokens(self, tok: torch.Tensor) -> torch.Tensor:
+        _check_drop_path(self)
+        return ops.temporal_block(tok, self.num_heads, self.attn_scale, self.stage_params())
+
+    def forward(self, x):
+        """x: (B, N, emb, H, W) -> same."""
+        return ops.as_reference_layout(self.forward_tokens(ops.as_tokens(x)))
+
+
+class AxialAttentionBlock(nn.Module):
+    def __init__(self, embed_dim=768, num_heads=12, drop_path=0, layer_scale_init_value=1e-6, bias_type="rel", attn_scale=True,
+                 feat_scale=True):
+        super().__init__()
+        if bias_type != "rel":
+            raise NotImplementedError("only bias_type='rel' (the reference default, used by every config) is implemented")
+        if layer_scale_init_value <= 0:
+            raise NotImplementedError("layer scale is always on in the reference configs")
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.attn_scale = attn_scale
+        self.feat_scale = feat_scale
+        self.norm1 = nn.InstanceNorm2d(embed_dim, affine=True)
+        self.norm2 = nn.InstanceNorm2d(embed_dim, affine=True)
+        self.gamma_att = nn.Parameter(layer_scale_init_value * torch.ones((embed_dim)), requires_grad=True)
+        self.gamma_mlp = nn.Parameter(layer_scale_init_value * torch.ones((embed_dim)), requires_grad=True)
+        self.input_head = nn.Conv2d(embed_dim, 3 * embed_dim, 1)
+        self.output_head = nn.Conv2d(embed_dim, embed_dim, 1)
+        self.qnorm = nn.LayerNorm(embed_dim // num_heads)
+        self.knorm = nn.LayerNorm(embed_dim // num_heads)
+        self.rel_pos_bias = RelativePositionBias(n_heads=num_heads)
+        if attn_scale:
+            self.attn_scale_factor_x = nn.Parameter(torch.ones((1, num_heads, 1, 1)), requires_grad=True)
+            self.attn_scale_factor_y = nn.Parameter(torch.ones((1, num_heads, 1, 1)), requires_grad=True)
+        if feat_scale:
+            self.low_freq_scalar = nn.Parameter(torch.zeros(embed_dim), requires_grad=True)
+            self.high_freq_scalar = nn.Parameter(torch.zeros(embed_dim), requires_grad=True)
+        self.drop_path = _make_drop_path(drop_path)
+        self.mlp = GeluMLP(embed_dim)
+        self.mlp_norm = nn.InstanceNorm2d(embed_dim, affine=True)
+
+    def stage_params(self):
+        a, f = self.attn_scale, self.feat_scale
+        return [self.gamma_att, self.gamma_mlp, self.attn_scale_factor_x if a else None, self.attn_scale_factor_y if a else None,
+                self.low_freq_scalar if f else None, self.high_freq_scalar if f else None, self.norm1.weight, self.norm1.bias,
+                self.norm2.weight, self.norm2.bias, self.input_head.weight, self.input_head.bias, self.output_head.weight,
+                self.output_head.bias, self.qnorm.weight, self.qnorm.bias, self.knorm.weight, self.knorm.bias,
+                self.rel_pos_bias.relative_attention_bias.weight, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight,
+                self.mlp.fc2.bias, self.mlp_norm.weight, self.mlp_norm.bias]
+
+    def forward_tokens(self, tok: torch.Tensor) -> torch.Tensor:
+        """tok: (B, T, h, w, E); frames are independent, so any leading (B, T) split of B*T frames is equivalent."""
+        _check_drop_path(self)
+        return ops.spatial_block(tok, self.num_heads, self.attn_scale, self.feat_scale, self.stage_params())
+
+    def forward(self, x):
+        """x: (B, emb, H, W) -> same."""
+        tok = ops.as_tokens(x.unsqueeze(1))
+        return ops.as_reference_layout(self.forward_tokens(tok))[:, 0]

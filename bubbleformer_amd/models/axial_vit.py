@@ -1,0 +1,100 @@
+"""SpaceTimeBlock, AViT and FiLMConditionedAViT (mirror of bubbleformer/models/axial_vit.py) on the HIP stages.
+
+Constructor signatures, sub-module names and ``state_dict`` keys are the reference's
+(axial_vit.py:23-46, 85-128, 173-215).  One extra keyword, ``compute_dtype`` (default torch.bfloat16; use
+torch.float32 for the exact-fp32 parity mode), selects the activation storage / MFMA type.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..layers import AttentionBlock, AxialAttentionBlock, FiLMMLP, HMLPDebed, HMLPEmbed
+from ._api import register_model
+
+__all__ = ["AViT", "FiLMConditionedAViT", "SpaceTimeBlock"]
+
+
+class SpaceTimeBlock(nn.Module):
+    """Temporal attention along T, then axial attention along W and H + MLP (axial_vit.py:48-65)."""
+
+    def __init__(self, embed_dim: int = 768, num_heads: int = 12, drop_path: float = 0.0, attn_scale: bool = True,
+                 feat_scale: bool = True):
+        super().__init__()
+        self.temporal = AttentionBlock(embed_dim=embed_dim, num_heads=num_heads, drop_path=drop_path, attn_scale=attn_scale)
+        self.spatial = AxialAttentionBlock(embed_dim=embed_dim, num_heads=num_heads, drop_path=drop_path, attn_scale=attn_scale,
+                                           feat_scale=feat_scale)
+
+    def forward_tokens(self, tok: torch.Tensor) -> torch.Tensor:
+        return self.spatial.forward_tokens(self.temporal.forward_tokens(tok))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x: (B, T, emb, H, W) -> same."""
+        return ops.as_reference_layout(self.forward_tokens(ops.as_tokens(x)))
+
+
+class _AxialBase(nn.Module):
+    def _build(self, input_fields, output_fields, patch_size, embed_dim, num_heads, processor_blocks, drop_path, attn_scale,
+               feat_scale, compute_dtype):
+        self.compute_dtype = compute_dtype if compute_dtype is not None else torch.bfloat16
+        self.patch_size = patch_size
+        self.embed = HMLPEmbed(patch_size=patch_size, in_channels=input_fields, embed_dim=embed_dim)
+        self.dp = np.linspace(0, drop_path, processor_blocks)
+
+    def _finish(self, output_fields, patch_size, embed_dim, num_heads, processor_blocks, attn_scale, feat_scale):
+        self.blocks = nn.ModuleList([
+            SpaceTimeBlock(embed_dim=embed_dim, num_heads=num_heads, drop_path=self.dp[i], attn_scale=attn_scale, feat_scale=feat_scale)
+            for i in range(processor_blocks)
+        ])
+        self.debed = HMLPDebed(patch_size=patch_size, embed_dim=embed_dim, out_channels=output_fields)
+
+    def _process(self, tok):
+        for blk in self.blocks:
+            tok = blk.forward_tokens(tok)
+        return tok
+
+
+@register_model("avit")
+class AViT(_AxialBase):
+    def __init__(self, input_fields: int = 3, output_fields: int = 3, time_window: int = 12, patch_size: int = 16,
+                 embed_dim: int = 768, num_heads: int = 12, processor_blocks: int = 12, drop_path: int = 0.2,
+                 attn_scale: bool = True, feat_scale: bool = True, compute_dtype=None):
+        super().__init__()
+        self.drop_path = drop_path
+        self._build(input_fields, output_fields, patch_size, embed_dim, num_heads, processor_blocks, drop_path, attn_scale,
+                    feat_scale, compute_dtype)
+        self._finish(output_fields, patch_size, embed_dim, num_heads, processor_blocks, attn_scale, feat_scale)
+
+    def tokens(self, x):
+        return self._process(self.embed.tokens(x, compute_dtype=self.compute_dtype))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x: (B, T, C, H, W) -> (B, T, C_out, H, W)."""
+        return self.debed.from_tokens(self.tokens(x))
+
+    def forward_loss(self, x, target):
+        return self.debed.loss_from_tokens(self.tokens(x), target)
+
+
+@register_model("filmavit")
+class FiLMConditionedAViT(_AxialBase):
+    def __init__(self, input_fields: int = 3, output_fields: int = 3, time_window: int = 12, patch_size: int = 16,
+                 embed_dim: int = 768, num_heads: int = 12, processor_blocks: int = 12, drop_path: int = 0.2,
+                 attn_scale: bool = True, feat_scale: bool = True, num_fluid_params: int = 8, compute_dtype=None):
+        super().__init__()
+        self._build(input_fields, output_fields, patch_size, embed_dim, num_heads, processor_blocks, drop_path, attn_scale,
+                    feat_scale, compute_dtype)
+        self.film_embed = FiLMMLP(num_fluid_params, embed_dim)
+        self._finish(output_fields, patch_size, embed_dim, num_heads, processor_blocks, attn_scale, feat_scale)
+
+    def tokens(self, x, fluid_params):
+        tok = self.embed.tokens(x, fluid_params, self.film_embed.film_params(), compute_dtype=self.compute_dtype)
+        return self._process(tok)
+
+    def forward(self, x: torch.Tensor, fluid_params: torch.Tensor) -> torch.Tensor:
+        """x: (B, T, C, H, W), fluid_params: (B, num_fluid_params) -> (B, T, C_out, H, W)."""
+        return self.debed.from_tokens(self.tokens(x, fluid_params))
+
+    def forward_loss(self, x, fluid_params, target):
+        """Fused debed + relative-L2 loss (utils/losses.py:67-94 as configured at modules.py:50): (loss, prediction)."""
+        return self.debed.loss_from_tokens(self.tokens(x, fluid_params), target)

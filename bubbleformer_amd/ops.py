@@ -1,0 +1,298 @@
+"""autograd bindings of the stage-level HIP entry points.
+
+Activations between stages are token-major tensors of shape (B, T, h, w, E) (contiguous) in the compute dtype
+(torch.float32 = exact-fp32 parity mode, torch.bfloat16 = throughput mode).  The reference's logical layout
+(B, T, E, h, w) is a zero-copy ``permute`` of that memory (see ``as_reference_layout`` / ``as_tokens``).
+
+Parameters stay ordinary fp32 ``nn.Parameter``s owned by the modules; every Function returns one gradient per
+parameter so autograd accumulation hooks (and therefore DDP bucket hooks) fire per stage during backward.
+"""
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+_SCRATCH = {}
+
+
+def _require_gpu(t: torch.Tensor) -> None:
+    if not t.is_cuda:
+        raise L.BubbleformerHipError(
+            "bubbleformer_amd runs only on a ROCm GPU (gfx950): got a tensor on %s; there is no CPU fallback" % t.device)
+
+
+def _dt(t: torch.dtype) -> int:
+    if t == torch.float32:
+        return L.BF_DTYPE_F32
+    if t == torch.bfloat16:
+        return L.BF_DTYPE_BF16
+    raise L.BubbleformerHipError(f"unsupported compute dtype {t}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def make_dims(dtype, B, T, h, w, E, heads, attn_scale=True, feat_scale=True, patch=0, cin=0, cout=0, nfluid=0) -> L.Dims:
+    return L.Dims(_dt(dtype), B, T, h, w, E, heads, int(bool(attn_scale)), int(bool(feat_scale)), patch, cin, cout, nfluid)
+
+
+def _dims_key(d: L.Dims):
+    return tuple(getattr(d, n) for n, _ in L.Dims._fields_)
+
+
+def scratch_for(d: L.Dims, device) -> torch.Tensor:
+    """One transient arena per (device, stream, problem shape); stage calls on a stream are ordered, so sharing is safe."""
+    key = (str(device), _stream(), _dims_key(d))
+    buf = _SCRATCH.get(key)
+    if buf is None:
+        n = L.lib().bf_scratch_bytes(C.byref(d))
+        if n < 0:
+            L.check(-1, "bf_scratch_bytes")
+        buf = torch.empty(n, dtype=torch.uint8, device=device)
+        _SCRATCH[key] = buf
+    return buf
+
+
+def _saved(nbytes: int, device, what: str) -> torch.Tensor:
+    if nbytes < 0:
+        L.check(-1, what)
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def _f32c(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if p is None:
+        return None
+    _require_gpu(p)
+    if p.dtype != torch.float32:
+        raise L.BubbleformerHipError("parameters must be fp32 (master weights); got %s" % p.dtype)
+    return p if p.is_contiguous() else p.contiguous()
+
+
+def _grad_views(params: Sequence[Optional[torch.Tensor]]):
+    """One zeroed flat fp32 buffer for a stage's parameter gradients, and per-parameter views into it."""
+    total = sum(((p.numel() + 3) // 4) * 4 for p in params if p is not None)
+    dev = next(p.device for p in params if p is not None)
+    flat = torch.zeros(total, dtype=torch.float32, device=dev)
+    views, off = [], 0
+    for p in params:
+        if p is None:
+            views.append(None)
+            continue
+        views.append(flat[off:off + p.numel()].view(p.shape))
+        off += ((p.numel() + 3) // 4) * 4
+    return flat, views
+
+
+def as_tokens(x: torch.Tensor) -> torch.Tensor:
+    """(..., E, h, w) reference layout -> (..., h, w, E) token-major contiguous (zero-copy when x is already a
+    permuted view of token-major memory)."""
+    nd = x.dim()
+    return x.permute(*range(nd - 3), nd - 2, nd - 1, nd - 3).contiguous()
+
+
+def as_reference_layout(tok: torch.Tensor) -> torch.Tensor:
+    """(..., h, w, E) token-major -> logical (..., E, h, w) view (no copy)."""
+    nd = tok.dim()
+    return tok.permute(*range(nd - 3), nd - 1, nd - 3, nd - 2)
+
+
+# ------------------------------------------------------------------------------------------------ processor blocks
+class _BlockFn(torch.autograd.Function):
+    """Shared driver for the temporal and the axial block."""
+
+    @staticmethod
+    def forward(ctx, x, kind, heads, attn_scale, feat_scale, *params):
+        _require_gpu(x)
+        x = x.contiguous()
+        B, T, h, w, E = x.shape
+        d = make_dims(x.dtype, B, T, h, w, E, heads, attn_scale, feat_scale)
+        lib = L.lib()
+        params = [_f32c(p) for p in params]
+        if kind == "temporal":
+            st = L.TemporalParams(*[_p(p) for p in params])
+            saved = _saved(lib.bf_temporal_saved_bytes(C.byref(d)), x.device, "bf_temporal_saved_bytes")
+            fwd = lib.bf_temporal_fwd
+        else:
+            st = L.SpatialParams(*[_p(p) for p in params])
+            saved = _saved(lib.bf_spatial_saved_bytes(C.byref(d)), x.device, "bf_spatial_saved_bytes")
+            fwd = lib.bf_spatial_fwd
+        out = torch.empty_like(x)
+        L.check(fwd(C.byref(d), C.byref(st), _p(x), _p(out), _p(saved), _p(scratch_for(d, x.device)), _stream()), f"bf_{kind}_fwd")
+        ctx.kind, ctx.cfg = kind, (heads, attn_scale, feat_scale)
+        ctx.save_for_backward(x, saved, *[p for p in params if p is not None])
+        ctx.mask = [p is not None for p in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, saved, *ps = ctx.saved_tensors
+        it = iter(ps)
+        params = [next(it) if m else None for m in ctx.mask]
+        heads, attn_scale, feat_scale = ctx.cfg
+        B, T, h, w, E = x.shape
+        d = make_dims(x.dtype, B, T, h, w, E, heads, attn_scale, feat_scale)
+        lib = L.lib()
+        dout = dout.contiguous()
+        flat, gviews = _grad_views(params)
+        if ctx.kind == "temporal":
+            st, gs, bwd = L.TemporalParams(*[_p(p) for p in params]), L.TemporalParams(*[_p(g) for g in gviews]), lib.bf_temporal_bwd
+        else:
+            st, gs, bwd = L.SpatialParams(*[_p(p) for p in params]), L.SpatialParams(*[_p(g) for g in gviews]), lib.bf_spatial_bwd
+        dx = torch.empty_like(x)
+        L.check(bwd(C.byref(d), C.byref(st), C.byref(gs), _p(x), _p(dout), _p(dx), _p(saved), _p(scratch_for(d, x.device)), _stream()),
+                f"bf_{ctx.kind}_bwd")
+        return (dx, None, None, None, None, *gviews)
+
+
+def temporal_block(x: torch.Tensor, heads: int, attn_scale: bool, params: List[Optional[torch.Tensor]]) -> torch.Tensor:
+    """x: (B, T, h, w, E) tokens.  params in ``_lib.TEMPORAL_FIELDS`` order (None where the reference has no parameter)."""
+    return _BlockFn.apply(x, "temporal", heads, attn_scale, True, *params)
+
+
+def spatial_block(x: torch.Tensor, heads: int, attn_scale: bool, feat_scale: bool, params: List[Optional[torch.Tensor]]) -> torch.Tensor:
+    """x: (B, T, h, w, E) tokens (frames = B*T).  params in ``_lib.SPATIAL_FIELDS`` order."""
+    return _BlockFn.apply(x, "spatial", heads, attn_scale, feat_scale, *params)
+
+
+# ------------------------------------------------------------------------------------------------ embed / debed
+def _stage_arrays(conv, inw, inb):
+    n = L.BF_MAX_STAGES
+    arr = lambda xs: (L.fp * n)(*([_p(t) for t in xs] + [None] * (n - len(xs))))
+    return arr(conv), arr(inw), arr(inb)
+
+
+class _EmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, fluid, compute_dtype, patch, embed_dim, nst, *params):
+        # params: conv_w[nst], in_w[nst], in_b[nst], then (film_ln_w, film_ln_b, film_w, film_b) or nothing
+        _require_gpu(x)
+        x = x.contiguous().float()
+        B, T, Cin, H, W = x.shape
+        if H % patch or W % patch:
+            raise L.BubbleformerHipError(f"input {H}x{W} is not a multiple of the patch size {patch}")
+        h, w = H // patch, W // patch
+        params = [_f32c(p) for p in params]
+        conv, inw, inb, film = params[:nst], params[nst:2 * nst], params[2 * nst:3 * nst], params[3 * nst:]
+        nfluid = 0
+        if film:
+            fluid = fluid.contiguous().float()
+            nfluid = fluid.shape[1]
+        d = make_dims(compute_dtype, B, T, h, w, embed_dim, 1, patch=patch, cin=Cin, cout=1, nfluid=nfluid)
+        lib = L.lib()
+        cw, iw, ib = _stage_arrays(conv, inw, inb)
+        st = L.EmbedParams(cw, iw, ib, *([_p(t) for t in film] if film else [None] * 4))
+        saved = _saved(lib.bf_embed_saved_bytes(C.byref(d)), x.device, "bf_embed_saved_bytes")
+        out = torch.empty((B, T, h, w, embed_dim), dtype=compute_dtype, device=x.device)
+        L.check(lib.bf_embed_fwd(C.byref(d), C.byref(st), _p(x), _p(fluid) if film else None, _p(out), _p(saved),
+                                 _p(scratch_for(d, x.device)), _stream()), "bf_embed_fwd")
+        ctx.cfg = (compute_dtype, patch, embed_dim, nst, nfluid, tuple(x.shape))
+        ctx.save_for_backward(saved, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        saved, *params = ctx.saved_tensors
+        compute_dtype, patch, E, nst, nfluid, xshape = ctx.cfg
+        B, T, Cin, H, W = xshape
+        h, w = H // patch, W // patch
+        d = make_dims(compute_dtype, B, T, h, w, E, 1, patch=patch, cin=Cin, cout=1, nfluid=nfluid)
+        lib = L.lib()
+        conv, inw, inb, film = params[:nst], params[nst:2 * nst], params[2 * nst:3 * nst], params[3 * nst:]
+        flat, gv = _grad_views(params)
+        cw, iw, ib = _stage_arrays(conv, inw, inb)
+        st = L.EmbedParams(cw, iw, ib, *([_p(t) for t in film] if film else [None] * 4))
+        gcw, giw, gib = _stage_arrays(gv[:nst], gv[nst:2 * nst], gv[2 * nst:3 * nst])
+        gs = L.EmbedParams(gcw, giw, gib, *([_p(t) for t in gv[3 * nst:]] if film else [None] * 4))
+        dout = dout.contiguous()
+        dx = torch.empty(xshape, dtype=torch.float32, device=dout.device) if ctx.needs_input_grad[0] else None
+        L.check(lib.bf_embed_bwd(C.byref(d), C.byref(st), C.byref(gs), _p(dout), _p(dx), _p(saved), _p(scratch_for(d, dout.device)),
+                                 _stream()), "bf_embed_bwd")
+        return (dx, None, None, None, None, None, *gv)
+
+
+def embed(x, fluid, compute_dtype, patch, embed_dim, conv_w, in_w, in_b, film_params=()):
+    """x: (B, T, C, H, W) fp32 clip -> (B, T, h, w, E) tokens.  film_params = (ln_w, ln_b, lin_w, lin_b) or ()."""
+    nst = len(conv_w)
+    return _EmbedFn.apply(x, fluid, compute_dtype, patch, embed_dim, nst, *conv_w, *in_w, *in_b, *film_params)
+
+
+class _DebedFn(torch.autograd.Function):
+    """tokens -> (B, T, Cout, H, W) fp32; with ``target`` also the fused relative-L2 loss."""
+
+    @staticmethod
+    def forward(ctx, x, target, patch, cout, nst, *params):
+        _require_gpu(x)
+        x = x.contiguous()
+        B, T, h, w, E = x.shape
+        params = [_f32c(p) for p in params]
+        conv, inw, inb = params[:nst], params[nst:2 * nst - 1], params[2 * nst - 1:]
+        d = make_dims(x.dtype, B, T, h, w, E, 1, patch=patch, cin=1, cout=cout)
+        lib = L.lib()
+        cw, iw, ib = _stage_arrays(conv, inw, inb)
+        st = L.DebedParams(cw, iw, ib)
+        saved = _saved(lib.bf_debed_saved_bytes(C.byref(d)), x.device, "bf_debed_saved_bytes")
+        pred = torch.empty((B, T, cout, h * patch, w * patch), dtype=torch.float32, device=x.device)
+        loss = torch.zeros((), dtype=torch.float32, device=x.device)
+        if target is not None:
+            target = target.contiguous().float()
+            if target.shape != pred.shape:
+                raise L.BubbleformerHipError(f"target shape {tuple(target.shape)} != prediction shape {tuple(pred.shape)}")
+        L.check(lib.bf_debed_fwd(C.byref(d), C.byref(st), _p(x), _p(pred), _p(target), _p(loss) if target is not None else None,
+                                 _p(saved), _p(scratch_for(d, x.device)), _stream()), "bf_debed_fwd")
+        ctx.cfg = (patch, cout, nst, target is not None)
+        ctx.save_for_backward(x, saved, pred, target if target is not None else pred, *params)
+        return pred, loss
+
+    @staticmethod
+    def backward(ctx, dpred, dloss):
+        x, saved, pred, target, *params = ctx.saved_tensors
+        patch, cout, nst, fused = ctx.cfg
+        B, T, h, w, E = x.shape
+        d = make_dims(x.dtype, B, T, h, w, E, 1, patch=patch, cin=1, cout=cout)
+        lib = L.lib()
+        conv, inw, inb = params[:nst], params[nst:2 * nst - 1], params[2 * nst - 1:]
+        flat, gv = _grad_views(params)
+        cw, iw, ib = _stage_arrays(conv, inw, inb)
+        st = L.DebedParams(cw, iw, ib)
+        gcw, giw, gib = _stage_arrays(gv[:nst], gv[nst:2 * nst - 1], gv[2 * nst - 1:])
+        gs = L.DebedParams(gcw, giw, gib)
+        dx = torch.empty_like(x)
+        if fused:
+            # loss path: d(pred) = dloss * coef[f, c] * (pred - target); an explicit dpred on top is not supported here
+            scale = dloss.contiguous().float().reshape(1)
+            L.check(lib.bf_debed_bwd(C.byref(d), C.byref(st), C.byref(gs), _p(x), None, _p(pred), _p(target), _p(scale), _p(dx),
+                                     _p(saved), _p(scratch_for(d, x.device)), _stream()), "bf_debed_bwd")
+        else:
+            dpred = dpred.contiguous().float()
+            L.check(lib.bf_debed_bwd(C.byref(d), C.byref(st), C.byref(gs), _p(x), _p(dpred), None, None, None, _p(dx), _p(saved),
+                                     _p(scratch_for(d, x.device)), _stream()), "bf_debed_bwd")
+        return (dx, None, None, None, None, *gv)
+
+
+def debed(x, patch, cout, conv_w, in_w, in_b):
+    """x: (B, T, h, w, E) tokens -> (B, T, Cout, H, W) fp32 prediction."""
+    pred, _ = _DebedFn.apply(x, None, patch, cout, len(conv_w), *conv_w, *in_w, *in_b)
+    return pred
+
+
+def debed_with_loss(x, target, patch, cout, conv_w, in_w, in_b):
+    """Fused debed + relative-L2 loss (LpLoss d=2, p=2, mean B, mean T, sum C).  Returns (loss, pred); only ``loss``
+    carries gradient (pred is produced for logging)."""
+    pred, loss = _DebedFn.apply(x, target, patch, cout, len(conv_w), *conv_w, *in_w, *in_b)
+    return loss, pred.detach()
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def adamw_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float, betas=(0.9, 0.999),
+           eps: float = 1e-8, weight_decay: float = 1e-2, grad_scale: float = 1.0) -> None:
+    """Fused AdamW over flat fp32 buffers (torch.optim.AdamW semantics, bubbleformer/modules.py:135-136)."""
+    _require_gpu(p)
+    L.check(L.lib().bf_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), int(step), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                             float(weight_decay), float(grad_scale), _stream()), "bf_adamw")

@@ -1,0 +1,208 @@
+/*
+ * bubbleformer_hip.h -- C ABI of libbubbleformer_hip.so (gfx950 / MI355X).
+ *
+ * The reference (HPCForge/Bubbleformer) has no FFI: its hot path is a Python
+ * nn.Module tree that dispatches stock ATen ops.  This header is the boundary a
+ * native replacement binds instead: plain device pointers, sizes and a HIP
+ * stream -- no torch types.  Every entry point is stream-ordered, performs no
+ * allocation and no device-wide synchronisation (hipGraph-capturable), and
+ * returns 0 on success or a negative code (bf_last_error() gives the text).
+ *
+ * Tensors.  Activations are token-major / channels-last: [N, C] with
+ * N = ((b*T + t)*h + y)*w + x.  `dtype` selects the activation storage type
+ * (BF_DTYPE_F32 = exact-fp32 parity mode on f32 MFMA; BF_DTYPE_BF16 = bf16
+ * storage + bf16 MFMA, fp32 accumulate and fp32 statistics).  Parameters and
+ * parameter gradients are always fp32 in the reference's state_dict layout.
+ *
+ * Reference interface each group of entry points replaces (file:line relative to
+ * the reference repository root):
+ *   bf_gemm .................. nn.Conv2d 1x1 / nn.Linear / k2s2 (transposed) conv GEMMs:
+ *                              layers/attention.py:78,121,210,299; linear_layers.py:25;
+ *                              layers/patching.py:36-44,92-100 (stages with C >= 8)
+ *   bf_in_stats / bf_in_bwd .. nn.InstanceNorm2d(affine): layers/attention.py:77,120,208,298,316
+ *   bf_attn_temporal_* ....... AttentionBlock.forward attention core: layers/attention.py:80-119
+ *   bf_attn_axial_* .......... AxialAttentionBlock.forward attention core: layers/attention.py:212-297
+ *   bf_embed_first_* ......... HMLPEmbed stage 0 (Conv2d k2s2 on NCHW input): layers/patching.py:36-44
+ *   bf_debed_last_* .......... HMLPDebed last stage + LpLoss: layers/patching.py:92-100, utils/losses.py:67-94
+ *   bf_film_* ................ FiLMMLP.forward: layers/linear_layers.py:63-77
+ *   bf_adamw ................. torch.optim.AdamW as configured at bubbleformer/modules.py:135-136
+ */
+#ifndef BUBBLEFORMER_HIP_H
+#define BUBBLEFORMER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* bf_stream_t; /* hipStream_t */
+
+enum { BF_DTYPE_F32 = 0, BF_DTYPE_BF16 = 1 };
+
+/* operand memory layouts for bf_gemm */
+enum { BF_LAY_KC = 0, /* [outer][k]   : reduction index contiguous      */
+       BF_LAY_XC = 1  /* [k][outer]   : outer index contiguous          */ };
+/* prologues applied to an operand element while it is staged (fp32 math) */
+enum { BF_PRO_NONE = 0, BF_PRO_AFFINE = 1, BF_PRO_AFFINE_GELU = 2, BF_PRO_GELU = 3 };
+/* what the epilogue combines with the accumulator */
+enum { BF_AUX_NONE = 0, BF_AUX_ADD = 1 /* += aux[m][n] */, BF_AUX_DGELU = 2 /* *= gelu'(aux[m][n]) */ };
+enum { BF_OUT_STORE = 0 /* store activation dtype */, BF_OUT_ATOMIC_F32 = 2 /* atomicAdd into fp32 */,
+       BF_OUT_STORE_F32 = 1 /* store fp32 */ };
+
+/* One GEMM operand.  Memory "rows" are tokens (or weight rows); "columns" are
+ * channels.  address(row, col) = rowbase(row) + (col / seglen) * segstride + col % seglen,
+ * rowbase(row) = row * ld, or, when gw > 0, the top-left pixel of a 2x2 patch:
+ * row = (f*gh + y)*gw + x  ->  ((f*2*gh + 2*y) * 2*gw + 2*x) * gc   (k2s2 patch gather / scatter). */
+typedef struct bf_operand {
+    const void* p;          /* activation dtype (weights: dtype of the GEMM) */
+    int64_t ld;
+    int32_t layout;         /* BF_LAY_* */
+    int32_t seglen;         /* 0 = no segmentation */
+    int64_t segstride;
+    int32_t gw, gh, gc;     /* 0 = plain rows */
+    int32_t pro;            /* BF_PRO_* */
+    const float* sc;        /* [frames][nch] scale  (AFFINE*) */
+    const float* sh;        /* [frames][nch] shift            */
+    int32_t rows_per_frame; /* frame = row / rows_per_frame   */
+    int32_t nch;            /* channel = col % nch            */
+} bf_operand;
+
+typedef struct bf_epilogue {
+    const float* bias;      /* [N] or NULL: v += bias[n]                    */
+    const float* colscale;  /* [N] or NULL: v  = v * colscale[n] + colshift[n] */
+    const float* colshift;  /* [N] or NULL                                   */
+    int32_t aux_mode;       /* BF_AUX_* */
+    const void* aux;        /* activation dtype, [M][ld_aux] */
+    int64_t ld_aux;
+    int32_t out_mode;       /* BF_OUT_* */
+    void* c;                /* output */
+    int64_t ldc;
+    int32_t seglen;         /* output scatter (same addressing as bf_operand) */
+    int64_t segstride;
+    int32_t gw, gh, gc;
+} bf_epilogue;
+
+/* C[M,N] (+)= epi( sum_k pro(A)[m,k] * pro(B)[n,k] ).  splitk > 1 requires BF_OUT_ATOMIC_F32. */
+int bf_gemm(int dtype, int M, int N, int K, const bf_operand* A, const bf_operand* B, const bf_epilogue* E,
+            int splitk, bf_stream_t stream);
+
+/* ---------------------------------------------------------------- kernel-level entry points (unit-testable) */
+
+/* InstanceNorm statistics over the S tokens of each frame, per channel (two-pass, fp32):
+ * mean/rstd [frames][C]; sc = rstd*w (*g), sh = (b - mean*rstd*w) (*g + gb): the affine the consumer GEMM applies.
+ * g/gb (optional): [frames/gdiv][C] post scale / shift (FiLM gamma/beta per batch element, or a layer scale). */
+int bf_in_stats(int dtype, const void* x, int frames, int S, int C, const float* w, const float* b, const float* g, int gdiv,
+                const float* gb, float* mean, float* rstd, float* sc, float* sh, bf_stream_t stream);
+/* out = [resid +] z * sc[f,c] + sh[f,c] */
+int bf_affine_apply(int dtype, const void* z, const void* resid, const float* sc, const float* sh, void* out, int64_t nrows,
+                    int S, int C, bf_stream_t stream);
+/* backward of y = act(xhat*w + b) [*g]; dx = ... [+ add]; dw/db/dg/dgb accumulate (fp32 atomics) */
+int bf_in_bwd(int dtype, const void* dy, const void* x, const void* add, void* dx, int frames, int S, int C, const float* mean,
+              const float* rstd, const float* w, const float* b, const float* g, int gdiv, int gelu, float* dw, float* db,
+              float* dg, float* dgb, bf_stream_t stream);
+/* out[c] += scale[c] * sum_rows x[row][c] */
+int bf_colsum(int dtype, const void* x, int64_t nrows, int C, const float* scale, float* out, bf_stream_t stream);
+
+/* Strided small-sequence attention on the head-interleaved QKV tensor [N][3E] (channel = head*3d + {q,k,v}*d + e):
+ * token(l) of sequence s = (s / inner) * outer_stride + (s % inner) * inner_stride + l * tok_stride.
+ * q/k LayerNorm(d) + q k^T d^-1/2 + T5 bias (emb [32][heads] or NULL) + softmax + high-frequency rescale
+ * (hscale [heads] or NULL) + P V.  out [N][E] = (accumulate ? out : 0) + out_scale * result. */
+int bf_attn_fwd(int dtype, const void* qkv, void* out, int64_t nseq, int L, int64_t inner, int64_t outer_stride,
+                int64_t inner_stride, int64_t tok_stride, int heads, int d, const float* qw, const float* qb, const float* kw,
+                const float* kb, const float* emb, const float* hscale, float out_scale, int accumulate, bf_stream_t stream);
+int bf_attn_bwd(int dtype, const void* qkv, const void* dout, void* dqkv, int64_t nseq, int L, int64_t inner,
+                int64_t outer_stride, int64_t inner_stride, int64_t tok_stride, int heads, int d, const float* qw,
+                const float* qb, const float* kw, const float* kb, const float* emb, const float* hscale, float* dqw,
+                float* dqb, float* dkw, float* dkb, float* demb, float* dhscale, float out_scale, int accumulate,
+                bf_stream_t stream);
+
+int bf_im2col_nchw(int dtype, const float* x, void* out, int frames, int C, int H, int W, int Kp, bf_stream_t stream);
+int bf_col2im_nchw(int dtype, const void* g, float* dx, int frames, int C, int H, int W, int Kp, bf_stream_t stream);
+int bf_pm2nchw(const float* pm, float* pred, const float* y, float* lossbuf, int frames, int Co, int h, int w, int Np,
+               bf_stream_t stream);
+int bf_lploss_finalize(const float* lossbuf, int frames, int Co, float* loss, float* coef, bf_stream_t stream);
+int bf_nchw2pm(int dtype, const float* dpred, const float* pred, const float* y, const float* coef, const float* gscale,
+               void* dpm, int frames, int Co, int h, int w, int Np, bf_stream_t stream);
+int bf_wprep(int dtype, int mode, const float* src, void* dst, int R, int K, int Kp, bf_stream_t stream);
+int bf_wgrad_unprep(int mode, const float* gsrc, float* gdst, int R, int K, int Kp, int transposed, bf_stream_t stream);
+/* gb: [2][B][E] (gamma block, beta block) */
+int bf_film_net_fwd(const float* cond, const float* lnw, const float* lnb, const float* W, const float* bias, float* gb,
+                    float* chat, float* crstd, int B, int P, int E2, bf_stream_t stream);
+int bf_film_net_bwd(const float* dgb, const float* chat, const float* lnw, const float* lnb, const float* W, float* dW,
+                    float* dbias, float* dlnw, float* dlnb, int B, int P, int E2, bf_stream_t stream);
+int bf_adamw(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float beta1, float beta2, float eps,
+             float wd, float gscale, bf_stream_t stream);
+
+/* ---------------------------------------------------------------- stage-level entry points (what the nn.Modules call) */
+
+typedef struct bf_dims {
+    int32_t dtype;              /* BF_DTYPE_* */
+    int32_t B, T, h, w;         /* batch, frames per clip, token grid */
+    int32_t E, heads;           /* embed dim, attention heads (d = E / heads) */
+    int32_t attn_scale, feat_scale;
+    int32_t patch;              /* patch size (power of two) */
+    int32_t cin, cout;          /* input / output fields */
+    int32_t nfluid;             /* FiLM parameters, 0 = unconditioned AViT */
+} bf_dims;
+
+/* Parameters of one AttentionBlock (layers/attention.py:25-64) in state_dict order; the gradient struct mirrors it. */
+typedef struct bf_temporal_params {
+    float *gamma, *attn_scale_factor, *norm1_w, *norm1_b, *norm2_w, *norm2_b, *input_head_w, *input_head_b,
+          *output_head_w, *output_head_b, *qnorm_w, *qnorm_b, *knorm_w, *knorm_b, *rel_pos_emb;
+} bf_temporal_params;
+/* Parameters of one AxialAttentionBlock (layers/attention.py:137-197) */
+typedef struct bf_spatial_params {
+    float *gamma_att, *gamma_mlp, *attn_scale_factor_x, *attn_scale_factor_y, *low_freq_scalar, *high_freq_scalar,
+          *norm1_w, *norm1_b, *norm2_w, *norm2_b, *input_head_w, *input_head_b, *output_head_w, *output_head_b,
+          *qnorm_w, *qnorm_b, *knorm_w, *knorm_b, *rel_pos_emb, *fc1_w, *fc1_b, *fc2_w, *fc2_b, *mlp_norm_w, *mlp_norm_b;
+} bf_spatial_params;
+/* HMLPEmbed (+ FiLMMLP): up to 5 stages (patch <= 32) */
+#define BF_MAX_STAGES 5
+typedef struct bf_embed_params {
+    float* conv_w[BF_MAX_STAGES];
+    float* in_w[BF_MAX_STAGES];
+    float* in_b[BF_MAX_STAGES];
+    float *film_ln_w, *film_ln_b, *film_w, *film_b;   /* NULL for AViT */
+} bf_embed_params;
+typedef struct bf_debed_params {
+    float* conv_w[BF_MAX_STAGES];
+    float* in_w[BF_MAX_STAGES];    /* last stage unused */
+    float* in_b[BF_MAX_STAGES];
+} bf_debed_params;
+
+/* Bytes of the per-stage activation record the forward fills and the backward reads, and of the transient scratch
+ * arena any stage call needs (forward or backward).  Both are plain device allocations owned by the caller. */
+int64_t bf_temporal_saved_bytes(const bf_dims* d);
+int64_t bf_spatial_saved_bytes(const bf_dims* d);
+int64_t bf_embed_saved_bytes(const bf_dims* d);
+int64_t bf_debed_saved_bytes(const bf_dims* d);
+int64_t bf_scratch_bytes(const bf_dims* d);
+
+/* x, out, dout, dx: [N][E] activations.  Gradients ACCUMULATE into `g` (zero it first). */
+int bf_temporal_fwd(const bf_dims* d, const bf_temporal_params* p, const void* x, void* out, void* saved, void* scratch, bf_stream_t s);
+int bf_temporal_bwd(const bf_dims* d, const bf_temporal_params* p, const bf_temporal_params* g, const void* x, const void* dout,
+                    void* dx, void* saved, void* scratch, bf_stream_t s);
+int bf_spatial_fwd(const bf_dims* d, const bf_spatial_params* p, const void* x, void* out, void* saved, void* scratch, bf_stream_t s);
+int bf_spatial_bwd(const bf_dims* d, const bf_spatial_params* p, const bf_spatial_params* g, const void* x, const void* dout,
+                   void* dx, void* saved, void* scratch, bf_stream_t s);
+/* x: (B*T, cin, H, W) fp32 clip; fluid: [B][nfluid] fp32 or NULL; out: [N][E].  dx_in (optional): d(loss)/d(clip). */
+int bf_embed_fwd(const bf_dims* d, const bf_embed_params* p, const float* x, const float* fluid, void* out, void* saved, void* scratch, bf_stream_t s);
+int bf_embed_bwd(const bf_dims* d, const bf_embed_params* p, const bf_embed_params* g, const void* dout, float* dx_in, void* saved,
+                 void* scratch, bf_stream_t s);
+/* x: [N][E]; pred: (B*T, cout, H, W) fp32.  If target != NULL the relative-L2 loss (utils/losses.py:67-94 as
+ * configured at modules.py:50) is fused: loss[0] and the per-(frame, channel) backward coefficients are produced. */
+int bf_debed_fwd(const bf_dims* d, const bf_debed_params* p, const void* x, float* pred, const float* target, float* loss,
+                 void* saved, void* scratch, bf_stream_t s);
+/* dpred: explicit (B*T, cout, H, W) fp32 gradient, or NULL to use the fused loss backward (pred, target, loss_scale[0] or 1). */
+int bf_debed_bwd(const bf_dims* d, const bf_debed_params* p, const bf_debed_params* g, const void* x, const float* dpred,
+                 const float* pred, const float* target, const float* loss_scale, void* dx, void* saved, void* scratch,
+                 bf_stream_t s);
+
+const char* bf_last_error(void);
+int bf_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

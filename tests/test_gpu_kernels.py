@@ -1,0 +1,123 @@
+"""GPU: kernel-level checks of the hand-written HIP pieces against plain torch fp32 references (through the C ABI)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def K():
+    from bubbleformer_amd import kernels
+    return kernels
+
+
+TOL = {torch.float32: 2e-6, torch.bfloat16: 1.2e-2}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K_", [(200, 136, 96), (128, 128, 64), (37 * 8, 24, 40), (1000, 392, 264)])
+def test_gemm_nt_plain_bias(K, dtype, M, N, K_):
+    from bubbleformer_amd import _lib as L
+    g = torch.Generator(device="cuda").manual_seed(1)
+    a = torch.randn(M, K_, device="cuda", generator=g).to(dtype)
+    w = torch.randn(N, K_, device="cuda", generator=g).to(dtype)
+    bias = torch.randn(N, device="cuda", generator=g)
+    c = torch.empty(M, N, device="cuda", dtype=dtype)
+    K.gemm(dtype, M, N, K_, K.operand(a, K_), K.operand(w, K_), K.epilogue(c, N, bias=bias))
+    ref = a.float() @ w.float().t() + bias
+    assert _rel(c.float(), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_dA_layout_xc_and_aux(K, dtype):
+    """dA = dC @ W with W [N][K] read as the XC operand; epilogue adds a residual / multiplies gelu'."""
+    from bubbleformer_amd import _lib as L
+    M, N, K_ = 264, 200, 136          # dC [M][N], W [N][K_] -> out [M][K_]
+    g = torch.Generator(device="cuda").manual_seed(2)
+    dc = torch.randn(M, N, device="cuda", generator=g).to(dtype)
+    w = torch.randn(N, K_, device="cuda", generator=g).to(dtype)
+    aux = torch.randn(M, K_, device="cuda", generator=g).to(dtype)
+    out = torch.empty(M, K_, device="cuda", dtype=dtype)
+    K.gemm(dtype, M, K_, N, K.operand(dc, N), K.operand(w, K_, layout=L.BF_LAY_XC), K.epilogue(out, K_, aux_mode=L.BF_AUX_ADD, aux=aux, ld_aux=K_))
+    ref = dc.float() @ w.float() + aux.float()
+    assert _rel(out.float(), ref) < TOL[dtype]
+    K.gemm(dtype, M, K_, N, K.operand(dc, N), K.operand(w, K_, layout=L.BF_LAY_XC), K.epilogue(out, K_, aux_mode=L.BF_AUX_DGELU, aux=aux, ld_aux=K_))
+    x = aux.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    ref = (dc.float() @ w.float()) * x.grad
+    assert _rel(out.float(), ref) < 2 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("splitk", [1, 5])
+def test_gemm_dW_layout_tn_splitk_prologue(K, dtype, splitk):
+    """dW[n][k] = sum_m dC[m][n] * (x[m][k]*sc[f,k]+sh[f,k]); both operands outer-contiguous (transposing LDS reads)."""
+    from bubbleformer_amd import _lib as L
+    Mtok, N, K_, S = 6 * 52, 136, 72, 52
+    g = torch.Generator(device="cuda").manual_seed(3)
+    dc = torch.randn(Mtok, N, device="cuda", generator=g).to(dtype)
+    x = torch.randn(Mtok, K_, device="cuda", generator=g).to(dtype)
+    sc = torch.randn(6, K_, device="cuda", generator=g)
+    sh = torch.randn(6, K_, device="cuda", generator=g)
+    out = torch.zeros(N, K_, device="cuda", dtype=torch.float32)
+    K.gemm(dtype, N, K_, Mtok, K.operand(dc, N, layout=L.BF_LAY_XC),
+           K.operand(x, K_, layout=L.BF_LAY_XC, pro=L.BF_PRO_AFFINE, sc=sc, sh=sh, rows_per_frame=S, nch=K_),
+           K.epilogue(out, K_, out_mode=L.BF_OUT_ATOMIC_F32), splitk=splitk)
+    xn = (x.float().view(6, S, K_) * sc[:, None] + sh[:, None]).view(Mtok, K_)
+    if dtype == torch.bfloat16:
+        xn = xn.bfloat16().float()
+    ref = dc.float().t() @ xn
+    assert _rel(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_patch_gather_and_scatter(K, dtype):
+    """k2s2 conv as a patch-gather GEMM and k2s2 transposed conv as a scatter-store GEMM vs torch conv ops."""
+    from bubbleformer_amd import _lib as L
+    Fr, H, W, Ci, Co = 3, 8, 12, 16, 24
+    g = torch.Generator(device="cuda").manual_seed(4)
+    img = torch.randn(Fr, H, W, Ci, device="cuda", generator=g).to(dtype)           # channels-last
+    wconv = torch.randn(Co, Ci, 2, 2, device="cuda", generator=g) * 0.2
+    wprep = wconv.permute(0, 2, 3, 1).reshape(Co, 4 * Ci).contiguous().to(dtype)   # [Co][(ky,kx,ci)]
+    gh, gw = H // 2, W // 2
+    P = Fr * gh * gw
+    out = torch.empty(P, Co, device="cuda", dtype=dtype)
+    K.gemm(dtype, P, Co, 4 * Ci, K.operand(img, Ci, gw=gw, gh=gh, gc=Ci, seglen=2 * Ci, segstride=2 * gw * Ci), K.operand(wprep, 4 * Ci),
+           K.epilogue(out, Co))
+    ref = torch.nn.functional.conv2d(img.float().permute(0, 3, 1, 2), wprep.float().view(Co, 2, 2, Ci).permute(0, 3, 1, 2), stride=2)
+    assert _rel(out.float().view(Fr, gh, gw, Co).permute(0, 3, 1, 2), ref) < TOL[dtype]
+    # transposed conv: x [Fr, gh, gw, Co] -> [Fr, H, W, Ci] with wt [Co][Ci][2][2]
+    wt = torch.randn(Co, Ci, 2, 2, device="cuda", generator=g) * 0.2
+    wtp = wt.permute(2, 3, 1, 0).reshape(4 * Ci, Co).contiguous().to(dtype)        # [(ky,kx,ci)][Co]
+    up = torch.empty(Fr, H, W, Ci, device="cuda", dtype=dtype)
+    K.gemm(dtype, P, 4 * Ci, Co, K.operand(out, Co), K.operand(wtp, Co),
+           K.epilogue(up, Ci, gw=gw, gh=gh, gc=Ci, seglen=2 * Ci, segstride=2 * gw * Ci))
+    ref = torch.nn.functional.conv_transpose2d(out.float().view(Fr, gh, gw, Co).permute(0, 3, 1, 2),
+                                               wtp.float().view(2, 2, Ci, Co).permute(3, 2, 0, 1), stride=2)
+    assert _rel(up.float().permute(0, 3, 1, 2), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_in_stats_two_pass(K, dtype):
+    Fr, S, Cc = 5, 37, 72
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = (torch.randn(Fr, S, Cc, device="cuda", generator=g) * 3 + 100.0).to(dtype)     # large mean: a one-pass variance would fail
+    w = torch.randn(Cc, device="cuda", generator=g)
+    b = torch.randn(Cc, device="cuda", generator=g)
+    mean, rstd, sc, sh = K.in_stats(x, Fr, S, Cc, w, b)
+    xf = x.float()
+    mu = xf.mean(1)
+    var = xf.var(1, unbiased=False)
+    assert _rel(mean, mu) < 1e-6
+    assert _rel(rstd, (var + 1e-5).rsqrt()) < 1e-5
+    # the folded affine x*sc + sh loses ~eps*|mean|/std relative accuracy by construction; activations have |mean|/std = O(1)
+    assert _rel(xf * sc[:, None] + sh[:, None], torch.nn.functional.instance_norm(xf.permute(0, 2, 1), weight=w, bias=b).permute(0, 2, 1)) < 2e-4
+    x2 = (x.float() - 97.0).to(dtype)
+    _, _, sc2, sh2 = K.in_stats(x2, Fr, S, Cc, w, b)
+    x2f = x2.float()
+    assert _rel(x2f * sc2[:, None] + sh2[:, None], torch.nn.functional.instance_norm(x2f.permute(0, 2, 1), weight=w, bias=b).permute(0, 2, 1)) < 5e-6
