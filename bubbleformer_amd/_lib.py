@@ -68,6 +68,8 @@ P = C.POINTER
 SIGNATURES = {
     "bf_last_error": (C.c_char_p, []),
     "bf_abi_version": (C.c_int, []),
+    "bf_prof_enable": (None, [C.c_int]),
+    "bf_prof_report": (C.c_int, [C.c_char_p, C.c_int]),
     "bf_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, P(Operand), P(Operand), P(Epilogue), C.c_int, vp]),
     "bf_in_stats": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, fp, fp, fp, C.c_int, fp, fp, fp, fp, fp, vp]),
     "bf_affine_apply": (C.c_int, [C.c_int, vp, vp, fp, fp, vp, i64, C.c_int, C.c_int, vp]),
@@ -129,6 +131,12 @@ def lib():
             raise BubbleformerHipError(
                 f"{LIB_PATH} is missing: build it with `make -C {CSRC}` (or __graft_entry__.build()). "
                 "bubbleformer_amd has no CPU / eager fallback.")
+        # PyTorch-ROCm ships its own libamdhip64; make sure THAT runtime instance is the one this library binds to
+        # (two HIP runtimes in one process do not share devices, streams or allocations).
+        import torch  # noqa: F401
+        tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(tl):
+            C.CDLL(tl, mode=C.RTLD_GLOBAL)
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)          # AttributeError if the library does not export a declared symbol

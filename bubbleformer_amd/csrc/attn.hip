@@ -367,6 +367,7 @@ extern "C" int bf_attn_fwd(int dtype, const void* qkv, void* out, int64_t nseq, 
     int WPB; size_t shm;
     if (int rc = dtype == BF_DTYPE_BF16 ? plan_waves(attn_fwd_kernel<bf16>, fpw, &WPB, &shm) : plan_waves(attn_fwd_kernel<float>, fpw, &WPB, &shm)) return rc;
     const long nprob = nseq * heads;
+    BfProfScope prof((hipStream_t)stream, "attn_fwd", 4.0 * nprob * L * L * d, (double)nprob * L * d * bf_esize(dtype) * (accumulate ? 5.0 : 4.0));
     const int grid = (int)std::min<long>((nprob + WPB - 1) / WPB, 256 * 8);
     if (dtype == BF_DTYPE_BF16)
         hipLaunchKernelGGL(attn_fwd_kernel<bf16>, dim3(grid), dim3(WPB * 64), shm, (hipStream_t)stream, (const bf16*)qkv, (bf16*)out, g, heads, d, p, out_scale, accumulate);
@@ -390,6 +391,7 @@ extern "C" int bf_attn_bwd(int dtype, const void* qkv, const void* dout, void* d
     int WPB; size_t shm;
     if (int rc = dtype == BF_DTYPE_BF16 ? plan_waves(attn_bwd_kernel<bf16>, fpw, &WPB, &shm) : plan_waves(attn_bwd_kernel<float>, fpw, &WPB, &shm)) return rc;
     const long nprob = nseq * heads;
+    BfProfScope prof((hipStream_t)stream, "attn_bwd", 10.0 * nprob * L * L * d, (double)nprob * L * d * bf_esize(dtype) * (accumulate ? 10.0 : 7.0));
     const int grid = (int)std::min<long>((nprob + WPB - 1) / WPB, 256 * 4);
     if (dtype == BF_DTYPE_BF16)
         hipLaunchKernelGGL(attn_bwd_kernel<bf16>, dim3(grid), dim3(WPB * 64), shm, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)dout, (bf16*)dqkv, g, heads, d, p, gr, out_scale, accumulate);

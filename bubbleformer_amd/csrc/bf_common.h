@@ -27,6 +27,16 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
         if (!(cond)) return bf_fail_msg(msg, __FILE__, __LINE__); \
     } while (0)
 
+// Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).  Off by default;
+// when off a scope costs one load of a global flag.
+int bf_prof_begin(hipStream_t st);
+void bf_prof_end(int idx, hipStream_t st, const char* name, double flops, double bytes);
+struct BfProfScope {
+    int idx; hipStream_t st; const char* name; double flops, bytes;
+    BfProfScope(hipStream_t s, const char* n, double f, double b) : idx(bf_prof_begin(s)), st(s), name(n), flops(f), bytes(b) {}
+    ~BfProfScope() { if (idx >= 0) bf_prof_end(idx, st, name, flops, bytes); }
+};
+
 int bf_fail(hipError_t e, const char* file, int line);
 int bf_fail_msg(const char* msg, const char* file, int line);
 

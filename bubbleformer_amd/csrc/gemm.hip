@@ -293,6 +293,12 @@ int launch(int M, int N, int K, const bf_operand* A, const bf_operand* B, const 
     splitk = bf_cdiv(K, kper);
     dim3 grid(bf_cdiv(M, BM), bf_cdiv(N, BN), splitk);
     const bool ax = A->layout == BF_LAY_XC, bx = B->layout == BF_LAY_XC;
+    const double es = sizeof(T);
+    const char* pname = sizeof(T) == 2 ? (ax ? "gemm_bf16_dW(xc,xc)" : bx ? "gemm_bf16_dA(kc,xc)" : "gemm_bf16_fwd(kc,kc)")
+                                       : (ax ? "gemm_f32_dW(xc,xc)" : bx ? "gemm_f32_dA(kc,xc)" : "gemm_f32_fwd(kc,kc)");
+    BfProfScope prof(st, pname, 2.0 * M * N * K,
+                     (double)M * K * es + (double)N * K * es + (double)M * N * (E->out_mode == BF_OUT_STORE ? es : 4.0) +
+                         (E->aux_mode != BF_AUX_NONE ? (double)M * N * es : 0.0));
     const bool ap = A->pro != BF_PRO_NONE, bp = B->pro != BF_PRO_NONE;
 #define BF_GEMM_GO(AX, BX, AP, BP) \
     hipLaunchKernelGGL((gemm_kernel<T, AX, BX, AP, BP>), grid, dim3(NT), 0, st, M, N, K, a, b, e, kper)

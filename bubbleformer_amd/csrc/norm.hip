@@ -239,6 +239,7 @@ extern "C" int bf_in_stats(int dtype, const void* x, int frames, int S, int C, c
     BF_REQUIRE(frames > 0 && S > 0 && C > 0, "bf_in_stats: empty");
     dim3 grid(frames, bf_cdiv(C, CPB));
     if (gdiv < 1) gdiv = 1;
+    BfProfScope prof((hipStream_t)stream, "in_stats", 0.0, (double)frames * S * C * bf_esize(dtype));
     if (dtype == BF_DTYPE_BF16) {
         BF_REQUIRE(chunk_ok<bf16>(C), "bf_in_stats: C must be a multiple of 8 (bf16)");
         hipLaunchKernelGGL(in_stats_kernel<bf16>, grid, dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh);
@@ -256,6 +257,7 @@ extern "C" int bf_affine_apply(int dtype, const void* z, const void* resid, cons
     const int ch = dtype == BF_DTYPE_BF16 ? 8 : 4;
     BF_REQUIRE(C % ch == 0, "bf_affine_apply: C must be a multiple of the 16-byte chunk");
     const long total = nrows * (C / ch);
+    BfProfScope prof((hipStream_t)stream, "affine_apply", 0.0, (double)nrows * C * bf_esize(dtype) * (resid ? 3.0 : 2.0));
     const int grid = (int)std::min<long>((total + NT - 1) / NT, 256 * 16);
     if (dtype == BF_DTYPE_BF16)
         hipLaunchKernelGGL(affine_apply_kernel<bf16>, dim3(grid), dim3(NT), 0, (hipStream_t)stream, (const bf16*)z, (const bf16*)resid, sc, sh, (bf16*)out, (long)nrows, S, C);
@@ -274,6 +276,7 @@ extern "C" int bf_in_bwd(int dtype, const void* dy, const void* x, const void* a
     dim3 grid(frames, bf_cdiv(C, CPB));
     if (gdiv < 1) gdiv = 1;
     hipStream_t st = (hipStream_t)stream;
+    BfProfScope prof(st, "in_bwd", 0.0, (double)frames * S * C * bf_esize(dtype) * (add ? 4.0 : 3.0));
 #define GO(T, G) hipLaunchKernelGGL((in_bwd_kernel<T, G>), grid, dim3(NT), 0, st, (const T*)dy, (const T*)x, (const T*)add, (T*)dx, S, C, mean, rstd, w, b, g, gdiv, dw, db, dg, dgb)
     if (dtype == BF_DTYPE_BF16) { if (gelu) GO(bf16, true); else GO(bf16, false); }
     else { if (gelu) GO(float, true); else GO(float, false); }
@@ -289,6 +292,7 @@ extern "C" int bf_colsum(int dtype, const void* x, int64_t nrows, int C, const f
     const int cb = bf_cdiv(C, CPB);
     long rpb = std::max<long>(64, (nrows * cb + 1023) / 1024);   // ~1024 blocks
     dim3 grid(bf_cdiv(nrows, rpb), cb);
+    BfProfScope prof((hipStream_t)stream, "colsum", 0.0, (double)nrows * C * bf_esize(dtype));
     if (dtype == BF_DTYPE_BF16)
         hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, (long)nrows, C, rpb, scale, out);
     else

@@ -1,0 +1,113 @@
+"""Data-parallel training step for the native FiLMAViT path.
+
+* ``FlatParams``   -- re-homes every parameter (and its gradient) of a module into ONE fp32 buffer each, in
+                      registration order, so the optimizer is a single fused kernel (csrc/patch.hip: adamw_kernel)
+                      and gradient buckets are contiguous slices.
+* ``BucketReducer``-- the data-parallel exchange (reference: Lightning's ``strategy="ddp"``, scripts/train.py:158-172):
+                      mean all-reduce of gradient buckets over ``torch.distributed`` (backend "nccl" = RCCL over xGMI),
+                      issued per bucket as soon as backward has produced every gradient in it (debed first, then
+                      blocks N-1 .. 0, then embed), overlapped with the rest of backward.  One process per GPU.
+* ``TrainStep``    -- forward (+ fused relative-L2 loss) -> backward -> bucket wait -> fused AdamW.
+Device agnostic where it can be (the reducer and the flat views are tested on CPU with gloo); the model itself
+only runs on the GPU.
+"""
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+class FlatParams:
+    def __init__(self, module: nn.Module, align: int = 64):
+        params = [p for p in module.parameters() if p.requires_grad]
+        self.params = params
+        offs, n = [], 0
+        for p in params:
+            offs.append(n)
+            n += (p.numel() + align - 1) // align * align
+        dev = params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.offsets, self.numel = offs, n
+        for p, o in zip(params, offs):
+            v = self.flat[o:o + p.numel()].view(p.shape)
+            v.copy_(p.data)
+            p.data = v
+            p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+
+class BucketReducer:
+    """Mean all-reduce of contiguous slices of a flat gradient buffer, launched from post-accumulate hooks."""
+
+    def __init__(self, flat: FlatParams, bucket_of: Sequence[int], group=None):
+        self.flat, self.group = flat, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        nb = max(bucket_of) + 1
+        self.lo = [None] * nb
+        self.hi = [None] * nb
+        self.count = [0] * nb
+        for p, o, b in zip(flat.params, flat.offsets, bucket_of):
+            self.lo[b] = o if self.lo[b] is None else min(self.lo[b], o)
+            self.hi[b] = o + p.numel() if self.hi[b] is None else max(self.hi[b], o + p.numel())
+            self.count[b] += 1
+        self.pending = [0] * nb
+        self.handles = []
+        self.enabled = self.world > 1
+        if self.enabled:
+            for p, b in zip(flat.params, bucket_of):
+                p.register_post_accumulate_grad_hook(self._make_hook(b))
+
+    def _make_hook(self, b):
+        def hook(_p):
+            self.pending[b] += 1
+            if self.pending[b] == self.count[b]:
+                self.pending[b] = 0
+                g = self.flat.grad[self.lo[b]:self.hi[b]]
+                self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return hook
+
+    def wait(self) -> float:
+        """Block the current stream on the outstanding buckets; returns the factor the optimizer must apply (1/world)."""
+        for h in self.handles:
+            h.wait()
+        self.handles.clear()
+        return 1.0 / self.world
+
+
+def stage_buckets(model: nn.Module) -> List[int]:
+    """Bucket index per parameter: one bucket per top-level stage / processor block (gradient-ready order is the
+    reverse of this list)."""
+    ids, names = [], {}
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        parts = name.split(".")
+        key = ".".join(parts[:2]) if parts[0] == "blocks" else parts[0]
+        ids.append(names.setdefault(key, len(names)))
+    return ids
+
+
+class TrainStep:
+    def __init__(self, model: nn.Module, lr: float = 2.5e-4, weight_decay: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8):
+        from . import ops
+        self.ops = ops
+        self.model = model
+        self.flat = FlatParams(model)
+        self.reducer = BucketReducer(self.flat, stage_buckets(model))
+        self.m = torch.zeros_like(self.flat.flat)
+        self.v = torch.zeros_like(self.flat.flat)
+        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.step_no = 0
+
+    def __call__(self, x, fluid, target) -> torch.Tensor:
+        self.flat.zero_grad()
+        loss, _ = self.model.forward_loss(x, fluid, target) if fluid is not None else self.model.forward_loss(x, target)
+        loss.backward()
+        gscale = self.reducer.wait()
+        self.step_no += 1
+        self.ops.adamw_(self.flat.flat, self.flat.grad, self.m, self.v, self.step_no, self.lr, self.betas, self.eps, self.wd, gscale)
+        return loss.detach()

@@ -199,6 +199,10 @@ int bf_debed_bwd(const bf_dims* d, const bf_debed_params* p, const bf_debed_para
                  const float* pred, const float* target, const float* loss_scale, void* dx, void* saved, void* scratch,
                  bf_stream_t s);
 
+/* Optional per-launch HIP-event timing on the launch stream (bench.py's roofline leg); off by default. */
+void bf_prof_enable(int on);
+int bf_prof_report(char* buf, int n);   /* JSON {kernel: {calls, ms, flops, bytes}}; bytes written or -1 */
+
 const char* bf_last_error(void);
 int bf_abi_version(void);
 
