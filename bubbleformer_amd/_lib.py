@@ -69,6 +69,7 @@ SIGNATURES = {
     "bf_last_error": (C.c_char_p, []),
     "bf_abi_version": (C.c_int, []),
     "bf_prof_enable": (None, [C.c_int]),
+    "bf_debug_force_generic_attn": (None, [C.c_int]),
     "bf_prof_report": (C.c_int, [C.c_char_p, C.c_int]),
     "bf_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, P(Operand), P(Operand), P(Epilogue), C.c_int, vp]),
     "bf_in_stats": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, fp, fp, fp, C.c_int, fp, fp, fp, fp, fp, vp]),
@@ -79,7 +80,7 @@ SIGNATURES = {
     "bf_attn_fwd": (C.c_int, [C.c_int, vp, vp, i64, C.c_int, i64, i64, i64, i64, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp, f32,
                               C.c_int, vp]),
     "bf_attn_bwd": (C.c_int, [C.c_int, vp, vp, vp, i64, C.c_int, i64, i64, i64, i64, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp,
-                              fp, fp, fp, fp, fp, fp, f32, C.c_int, vp]),
+                              fp, fp, fp, fp, fp, fp, f32, C.c_int, fp, i64, vp]),
     "bf_im2col_nchw": (C.c_int, [C.c_int, fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "bf_col2im_nchw": (C.c_int, [C.c_int, vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "bf_pm2nchw": (C.c_int, [fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -345,6 +345,8 @@ int plan_waves(K kernel, size_t floats_per_wave, int* wpb, size_t* shm) {
     return 0;
 }
 
+bool g_force_generic = false;
+
 int check_geo(const char* who, int dtype, int heads, int d, int L) {
     const int ch = dtype == BF_DTYPE_BF16 ? 8 : 4;
     if (heads < 1 || heads > 16) return bf_fail_msg("attention: heads must be in 1..16", who, 0);
@@ -355,12 +357,29 @@ int check_geo(const char* who, int dtype, int heads, int d, int L) {
 
 }  // namespace
 
+// attn_mfma.hip
+int bf_attn_fwd_mfma(const void* qkv, void* out, long nseq, int L, long inner, long outer_stride, long inner_stride, long tok_stride, int heads,
+                     int d, const float* qw, const float* qb, const float* kw, const float* kb, const float* emb, const float* hscale,
+                     float out_scale, int accumulate, hipStream_t st);
+int bf_attn_bwd_mfma(const void* qkv, const void* dout, void* dqkv, long nseq, int L, long inner, long outer_stride, long inner_stride,
+                     long tok_stride, int heads, int d, const float* qw, const float* qb, const float* kw, const float* kb, const float* emb,
+                     const float* hscale, float* dqw, float* dqb, float* dkw, float* dkb, float* demb, float* dhscale, float out_scale,
+                     int accumulate, float* ws, long ws_floats, hipStream_t st);
+static bool use_mfma(int dtype, int d) { return !g_force_generic && dtype == BF_DTYPE_BF16 && d % 32 == 0 && d <= 128; }
+
+extern "C" void bf_debug_force_generic_attn(int on) { g_force_generic = on != 0; }
+
 extern "C" int bf_attn_fwd(int dtype, const void* qkv, void* out, int64_t nseq, int L, int64_t inner, int64_t outer_stride,
                            int64_t inner_stride, int64_t tok_stride, int heads, int d, const float* qw, const float* qb,
                            const float* kw, const float* kb, const float* emb, const float* hscale, float out_scale,
                            int accumulate, bf_stream_t stream) {
     BF_REQUIRE(qkv && out && qw && qb && kw && kb && nseq > 0 && inner > 0, "bf_attn_fwd: bad arguments");
     if (int rc = check_geo("bf_attn_fwd", dtype, heads, d, L)) return rc;
+    if (use_mfma(dtype, d)) {
+        BfProfScope prof((hipStream_t)stream, "attn_fwd", 4.0 * nseq * heads * L * L * d, (double)nseq * heads * L * d * 2.0 * (accumulate ? 5.0 : 4.0));
+        return bf_attn_fwd_mfma(qkv, out, nseq, L, inner, outer_stride, inner_stride, tok_stride, heads, d, qw, qb, kw, kb, emb, hscale, out_scale,
+                                accumulate, (hipStream_t)stream);
+    }
     SeqGeo g{nseq, L, inner, outer_stride, inner_stride, tok_stride};
     AttnParams p{qw, qb, kw, kb, emb, hscale};
     const size_t fpw = 3 * L * (d + 1) + L * (L + 1) + 2 * L;
@@ -381,9 +400,14 @@ extern "C" int bf_attn_bwd(int dtype, const void* qkv, const void* dout, void* d
                            int64_t outer_stride, int64_t inner_stride, int64_t tok_stride, int heads, int d, const float* qw,
                            const float* qb, const float* kw, const float* kb, const float* emb, const float* hscale,
                            float* dqw, float* dqb, float* dkw, float* dkb, float* demb, float* dhscale, float out_scale,
-                           int accumulate, bf_stream_t stream) {
+                           int accumulate, float* ws, int64_t ws_floats, bf_stream_t stream) {
     BF_REQUIRE(qkv && dout && dqkv && qw && qb && kw && kb && nseq > 0 && inner > 0, "bf_attn_bwd: bad arguments");
     if (int rc = check_geo("bf_attn_bwd", dtype, heads, d, L)) return rc;
+    if (use_mfma(dtype, d)) {
+        BfProfScope prof((hipStream_t)stream, "attn_bwd", 10.0 * nseq * heads * L * L * d, (double)nseq * heads * L * d * 2.0 * (accumulate ? 10.0 : 7.0));
+        return bf_attn_bwd_mfma(qkv, dout, dqkv, nseq, L, inner, outer_stride, inner_stride, tok_stride, heads, d, qw, qb, kw, kb, emb, hscale, dqw,
+                                dqb, dkw, dkb, demb, dhscale, out_scale, accumulate, ws, (long)ws_floats, (hipStream_t)stream);
+    }
     SeqGeo g{nseq, L, inner, outer_stride, inner_stride, tok_stride};
     AttnParams p{qw, qb, kw, kb, emb, hscale};
     AttnGrads gr{dqw, dqb, dkw, dkb, demb, dhscale};

@@ -1,0 +1,585 @@
+// bf16 MFMA small-sequence attention (L <= 32, head dim d in {32, 64, 96, 128}) for the factored space-time blocks.
+//
+// One wavefront owns one (sequence, head) problem; everything but V (forward) / Qn, Kn, dO (backward) stays in
+// registers.  v_mfma_f32_16x16x32_bf16 is used in the orientation that leaves the softmax axis (keys) inside a
+// lane quad {l, l+16, l+32, l+48}:
+//     S^T[j][i]  = sum_e Kn[j][e] Qn[i][e]          A = Kn rows, B = Qn rows (both straight from global, 16-byte loads)
+//       -> lane (i = l & 15) holds keys j = 4*(l >> 4) + r, r = 0..3 (per 16-key block)
+//     O^T[e][i]  = sum_j V[j][e] A[i][j]            A = V^T via ds_read_b64_tr_b16 on the LDS V tile, B = the P registers as they stand:
+//       MFMA k-slot (g, jj) := key 4g + jj (block 0, jj < 4) / key 16 + 4g + jj - 4 (block 1, jj >= 4)
+//       -> lane holds 4 consecutive channels of one query: 8-byte stores.
+// q/k LayerNorm runs in the operand layout (a row's 64 channels sit in the 4 lanes of a quad: two __shfl_xor).
+// Backward recomputes P, forms dA^T the same way (A = V rows, B = dO rows), then
+//     dQn^T[e][i] = sum_j Kn[j][e] dS[i][j]         A = Kn^T (tr read), B = dS registers
+//     dKn^T[e][j] = sum_i Qn[i][e] dS[i][j]         A = Qn^T (tr read), B = dS^T through a small LDS transpose
+//     dV^T[e][j]  = sum_i dO[i][e] A[i][j]          A = dO^T (tr read), B = A^T through the same transpose
+// and finishes LayerNorm backward in the operand layout after one LDS re-layout (16-byte global stores).
+#include "bf_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+
+__device__ __forceinline__ void wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ int t5b(int n) {   // n = query - key  (see attn.hip)
+    const int a = n < 0 ? -n : n;
+    int b;
+    if (a < 8) b = a; else if (a < 10) b = 8; else if (a < 12) b = 9; else if (a < 14) b = 10; else if (a < 16) b = 11;
+    else if (a < 20) b = 12; else if (a < 23) b = 13; else if (a < 27) b = 14; else b = 15;
+    return b + (n < 0 ? 16 : 0);
+}
+__device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
+__device__ __forceinline__ float quad_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64)); return v; }
+
+struct Geo { long nseq; int L; long inner, outer_stride, inner_stride, tok_stride; };
+struct Par { const float *qw, *qb, *kw, *kb, *emb, *hscale; };
+struct Grd { float *dqw, *dqb, *dkw, *dkb, *demb, *dhscale; };
+
+// transposing read of a 4-row x 16-col block of a bf16 LDS tile (row stride ld elements): lane i16 of the 16-lane group gets
+// column c0 + i16 of rows r0..r0+3
+__device__ __forceinline__ s16x4 tr4(const bf16* tile, int ld, int r0, int c0, int lane) {
+    const int i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tile + (r0 + q) * ld + c0 + 4 * p));
+}
+__device__ __forceinline__ bf16x8 cat(s16x4 lo, s16x4 hi) {
+    s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+__device__ __forceinline__ short bfbits(float x) { return __builtin_bit_cast(short, (bf16)x); }
+
+// Load one 16-row block of q (part 0) / k (1) / v (2) rows as fp32 in the operand layout:
+// lane (i = l & 15, g = l >> 4) gets channels 32*s + 8*g + jj of row i.
+template <int KS>
+__device__ __forceinline__ void load_rows_f32(const bf16* __restrict__ base, long row_stride, int col0, long tok0, long tok_stride, int L, int blk,
+                                              int lane, float (&x)[KS][8]) {
+    const int i = blk * 16 + (lane & 15), g = lane >> 4;
+    const int ic = i < L ? i : L - 1;
+    const bf16* p = base + (tok0 + ic * tok_stride) * row_stride + col0 + 8 * g;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(p + 32 * s);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[s][j] = (float)v[j];
+    }
+}
+// LayerNorm statistics of the row held by a lane quad; x becomes xhat, returns rstd
+template <int KS>
+__device__ __forceinline__ float ln_quad(float (&x)[KS][8], int d) {
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < KS; ++a)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += x[a][j];
+    const float mu = quad_sum(s) / (float)d;
+    float v = 0.f;
+#pragma unroll
+    for (int a = 0; a < KS; ++a)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float t = x[a][j] - mu; v += t * t; }
+    const float r = rsqrtf(quad_sum(v) / (float)d + BF_IN_EPS);
+#pragma unroll
+    for (int a = 0; a < KS; ++a)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[a][j] = (x[a][j] - mu) * r;
+    return r;
+}
+template <int KS>
+__device__ __forceinline__ void affine_frag(const float (&xh)[KS][8], const float* __restrict__ w, const float* __restrict__ b, float mul, int lane,
+                                            bf16x8 (&f)[KS]) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = 32 * s + 8 * g + j;
+            f[s][j] = (bf16)((xh[s][j] * w[e] + b[e]) * mul);
+        }
+}
+
+// scores^T for all (key block, query block) pairs -> softmax over keys -> P (and the rescaled A) in registers.
+// sc[jb][ib][r]: lane (i = 16*ib + (l & 15)) x key j = 16*jb + 4*(l >> 4) + r
+template <int NB, int KS>
+__device__ __forceinline__ void scores_softmax(const bf16x8 (&kf)[NB][KS], const bf16x8 (&qf)[NB][KS], const Par& p, int head, int heads, int L,
+                                               int lane, float (&P)[NB][NB][4], float (&A)[NB][NB][4]) {
+    const int g = lane >> 4, i16 = lane & 15;
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+        for (int ib = 0; ib < NB; ++ib) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jb][s], qf[ib][s], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * ib + i16, j = 16 * jb + 4 * g + r;
+                float v = acc[r];
+                if (p.emb) v += p.emb[t5b(i - j) * heads + head];
+                P[jb][ib][r] = j < L ? v : -INFINITY;
+            }
+        }
+    const float invL = 1.0f / (float)L;
+    const float hs = p.hscale ? p.hscale[head] : 1.f;
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, P[jb][ib][r]);
+        m = quad_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float e = __expf(P[jb][ib][r] - m); P[jb][ib][r] = e; sum += e; }
+        const float inv = 1.f / quad_sum(sum);
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * jb + 4 * g + r;
+                const float pr = P[jb][ib][r] * inv;
+                P[jb][ib][r] = pr;
+                A[jb][ib][r] = j < L ? (p.hscale ? invL + (pr - invL) * hs : pr) : 0.f;
+            }
+    }
+}
+// registers (key blocks x 4) of one query block -> the B operand whose k-slot (g, jj) is key 4g+jj / 16+4g+jj-4
+template <int NB>
+__device__ __forceinline__ bf16x8 pack_keys(const float (&X)[NB][NB][4], int ib) {
+    s16x8 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { r[j] = bfbits(X[0][ib][j]); r[4 + j] = NB > 1 ? bfbits(X[NB - 1][ib][j]) : (short)0; }
+    return __builtin_bit_cast(bf16x8, r);
+}
+// A operand = tile^T for that k-slot order: rows 4g..4g+3 of block 0 and of block 1, columns 16t + (l & 15)
+template <int NB>
+__device__ __forceinline__ bf16x8 tr_keys(const bf16* tile, int ld, int t, int lane) {
+    const int g = lane >> 4;
+    const s16x4 lo = tr4(tile, ld, 4 * g, 16 * t, lane);
+    s16x4 hi = {0, 0, 0, 0};
+    if (NB > 1) hi = tr4(tile, ld, 16 + 4 * g, 16 * t, lane);
+    return cat(lo, hi);
+}
+// A operand = tile^T in natural k order (k = row 8g .. 8g+7).  A 16-row tile (NB == 1) has no rows 16..31: those
+// k-slots read (in-bounds) rows again and are then forced to zero -- every lane still executes the transposing read.
+template <int NB>
+__device__ __forceinline__ bf16x8 tr_nat(const bf16* tile, int ld, int t, int lane) {
+    const int g = lane >> 4;
+    const int r0 = NB == 1 ? 8 * (g & 1) : 8 * g;
+    bf16x8 f = cat(tr4(tile, ld, r0, 16 * t, lane), tr4(tile, ld, r0 + 4, 16 * t, lane));
+    if (NB == 1 && g >= 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (bf16)0.f;
+    }
+    return f;
+}
+
+// stage L rows of `width` channels (global, 16-byte chunks) into a bf16 LDS tile [16*NB][ld]; rows >= L are zeroed
+template <int NB>
+__device__ __forceinline__ void stage_tile(const bf16* __restrict__ base, long row_stride, int col0, long tok0, long tok_stride, int L, int d,
+                                           bf16* tile, int ld, int lane) {
+    const int cpr = d / 8;
+    for (int c = lane; c < 16 * NB * cpr; c += 64) {
+        const int row = c / cpr, e0 = (c % cpr) * 8;
+        bf16x8 v;
+        if (row < L) v = *reinterpret_cast<const bf16x8*>(base + (tok0 + row * tok_stride) * row_stride + col0 + e0);
+        else
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (bf16)0.f;
+        *reinterpret_cast<bf16x8*>(tile + row * ld + e0) = v;
+    }
+}
+
+template <int NB, int KS>
+__global__ void __launch_bounds__(256) attn_fwd_mfma(const bf16* __restrict__ qkv, bf16* __restrict__ out, Geo g, int heads, Par p, float out_scale,
+                                                     int accumulate) {
+    constexpr int D = 32 * KS, LD = D + 16, NT16 = D / 16;
+    extern __shared__ __attribute__((aligned(16))) bf16 smem_fwd[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    bf16* vt = smem_fwd + wave * (16 * NB * LD);
+    const int E = heads * D, L = g.L;
+    const float scale = rsqrtf((float)D);
+    const long nprob = g.nseq * heads;
+    const int gq = lane >> 4, i16 = lane & 15;
+    for (long pr = (long)blockIdx.x * wpb + wave; pr < nprob; pr += (long)gridDim.x * wpb) {
+        const long s = pr / heads;
+        const int head = (int)(pr % heads);
+        const long tok0 = (s / g.inner) * g.outer_stride + (s % g.inner) * g.inner_stride;
+        const bf16* hb = qkv + head * 3 * D;
+        stage_tile<NB>(hb, 3L * E, 2 * D, tok0, g.tok_stride, L, D, vt, LD, lane);
+        bf16x8 qf[NB][KS], kf[NB][KS];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            float x[KS][8];
+            load_rows_f32<KS>(hb, 3L * E, 0, tok0, g.tok_stride, L, b, lane, x);
+            ln_quad<KS>(x, D);
+            affine_frag<KS>(x, p.qw, p.qb, scale, lane, qf[b]);
+            load_rows_f32<KS>(hb, 3L * E, D, tok0, g.tok_stride, L, b, lane, x);
+            ln_quad<KS>(x, D);
+            affine_frag<KS>(x, p.kw, p.kb, 1.f, lane, kf[b]);
+        }
+        float P[NB][NB][4], A[NB][NB][4];
+        scores_softmax<NB, KS>(kf, qf, p, head, heads, L, lane, P, A);
+        wsync();   // V tile visible to the wave
+#pragma unroll
+        for (int ib = 0; ib < NB; ++ib) {
+            const bf16x8 pa = pack_keys<NB>(A, ib);
+            const int i = 16 * ib + i16;
+#pragma unroll
+            for (int t = 0; t < NT16; ++t) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_keys<NB>(vt, LD, t, lane), pa, o, 0, 0, 0);
+                if (i < L) {
+                    bf16* dst = out + (tok0 + i * g.tok_stride) * (long)E + head * D + 16 * t + 4 * gq;
+                    float v[4] = {o[0] * out_scale, o[1] * out_scale, o[2] * out_scale, o[3] * out_scale};
+                    if (accumulate) {
+                        const bf16x4 old = *reinterpret_cast<const bf16x4*>(dst);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)old[r];
+                    }
+                    const bf16x4 w4 = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                    *reinterpret_cast<bf16x4*>(dst) = w4;
+                }
+            }
+        }
+        wsync();   // before the next problem overwrites the V tile
+    }
+}
+
+template <int NB, int KS>
+__global__ void __launch_bounds__(256) attn_bwd_mfma(const bf16* __restrict__ qkv, const bf16* __restrict__ dout, bf16* __restrict__ dqkv, Geo g,
+                                                     int heads, Par p, Grd gr, float out_scale, int accumulate, float* __restrict__ ws) {
+    constexpr int D = 32 * KS, LD = D + 16, NT16 = D / 16, R = 16 * NB, LDP = 32 + 8, LDF = D + 4;
+    extern __shared__ __attribute__((aligned(16))) bf16 smem_bwd[];
+    __shared__ float s_demb[32 * 16];
+    __shared__ float s_dhs[16];
+    __shared__ float s_ln[4 * 32 * KS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    // per-wave: Qn, Kn, dO tiles [R][LD] bf16; A^T and dS^T tiles [R][LDP] bf16 ([key j][query i]); fp32 re-layout buffer aliases the tiles
+    constexpr int PER_WAVE = 3 * R * LD + 2 * R * LDP;
+    static_assert(3 * R * LD * 2 >= R * LDF * 4, "re-layout buffer must fit in the operand tiles");
+    bf16* qn_t = smem_bwd + wave * PER_WAVE;
+    bf16* kn_t = qn_t + R * LD;
+    bf16* do_t = kn_t + R * LD;
+    bf16* at_t = do_t + R * LD;
+    bf16* ds_t = at_t + R * LDP;
+    float* relay = reinterpret_cast<float*>(qn_t);
+    for (int i = threadIdx.x; i < 32 * 16; i += blockDim.x) s_demb[i] = 0.f;
+    if (threadIdx.x < 16) s_dhs[threadIdx.x] = 0.f;
+    for (int i = threadIdx.x; i < 4 * D; i += blockDim.x) s_ln[i] = 0.f;
+    __syncthreads();
+    const int E = heads * D, L = g.L;
+    const float scale = rsqrtf((float)D);
+    const long nprob = g.nseq * heads;
+    const int gq = lane >> 4, i16 = lane & 15;
+    float a_qw[KS][8], a_qb[KS][8], a_kw[KS][8], a_kb[KS][8];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a_qw[s][j] = a_qb[s][j] = a_kw[s][j] = a_kb[s][j] = 0.f;
+
+    for (long pr = (long)blockIdx.x * wpb + wave; pr < nprob; pr += (long)gridDim.x * wpb) {
+        const long s = pr / heads;
+        const int head = (int)(pr % heads);
+        const long tok0 = (s / g.inner) * g.outer_stride + (s % g.inner) * g.inner_stride;
+        const bf16* hb = qkv + head * 3 * D;
+        float xq[NB][KS][8], xk[NB][KS][8], rq[NB], rk[NB];
+        bf16x8 qf[NB][KS], kf[NB][KS], vf[NB][KS], df[NB][KS];
+        stage_tile<NB>(dout + head * D, (long)E, 0, tok0, g.tok_stride, L, D, do_t, LD, lane);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            load_rows_f32<KS>(hb, 3L * E, 0, tok0, g.tok_stride, L, b, lane, xq[b]);
+            rq[b] = ln_quad<KS>(xq[b], D);
+            affine_frag<KS>(xq[b], p.qw, p.qb, scale, lane, qf[b]);
+            load_rows_f32<KS>(hb, 3L * E, D, tok0, g.tok_stride, L, b, lane, xk[b]);
+            rk[b] = ln_quad<KS>(xk[b], D);
+            affine_frag<KS>(xk[b], p.kw, p.kb, 1.f, lane, kf[b]);
+            // V and dO rows straight into operand registers (rows >= L are clamped duplicates; their products are masked / never stored)
+            const int i = b * 16 + i16, ic = i < L ? i : L - 1;
+            const bf16* vp = hb + (tok0 + ic * g.tok_stride) * 3L * E + 2 * D + 8 * gq;
+            const bf16* dp = dout + (tok0 + ic * g.tok_stride) * (long)E + head * D + 8 * gq;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                vf[b][ks] = *reinterpret_cast<const bf16x8*>(vp + 32 * ks);
+                df[b][ks] = *reinterpret_cast<const bf16x8*>(dp + 32 * ks);
+            }
+            // Qn (with the d^-1/2 fold) and Kn tiles for the transposed operands
+            const int row = b * 16 + i16;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 zq = qf[b][ks], zk = kf[b][ks];
+                if (row >= L) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { zq[j] = (bf16)0.f; zk[j] = (bf16)0.f; }
+                }
+                *reinterpret_cast<bf16x8*>(qn_t + row * LD + 32 * ks + 8 * gq) = zq;
+                *reinterpret_cast<bf16x8*>(kn_t + row * LD + 32 * ks + 8 * gq) = zk;
+            }
+        }
+        float P[NB][NB][4], A[NB][NB][4], dA[NB][NB][4];
+        scores_softmax<NB, KS>(kf, qf, p, head, heads, L, lane, P, A);
+        // dA^T[j][i] = sum_e V[j][e] dO[i][e] * out_scale
+        const float hs = p.hscale ? p.hscale[head] : 1.f;
+        const float invL = 1.0f / (float)L;
+        float dhs = 0.f;
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+            for (int ib = 0; ib < NB; ++ib) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[jb][ks], df[ib][ks], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * ib + i16, j = 16 * jb + 4 * gq + r;
+                    float v = (i < L && j < L) ? acc[r] * out_scale : 0.f;
+                    if (p.hscale) { dhs += (P[jb][ib][r] - invL) * v; v *= hs; }
+                    dA[jb][ib][r] = v;     // now dP
+                }
+            }
+        // dS = P * (dP - sum_j P dP)
+#pragma unroll
+        for (int ib = 0; ib < NB; ++ib) {
+            float dot = 0.f;
+#pragma unroll
+            for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dot += P[jb][ib][r] * dA[jb][ib][r];
+            dot = quad_sum(dot);
+#pragma unroll
+            for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * ib + i16, j = 16 * jb + 4 * gq + r;
+                    const float v = (i < L && j < L) ? P[jb][ib][r] * (dA[jb][ib][r] - dot) : 0.f;
+                    dA[jb][ib][r] = v;     // now dS
+                    if (gr.demb && i < L && j < L) atomicAdd(&s_demb[t5b(i - j) * 16 + head], v);
+                    if (i >= L) A[jb][ib][r] = 0.f;
+                    // transposed copies [key j][query i] for the products that reduce over queries
+                    at_t[j * LDP + i] = (bf16)A[jb][ib][r];
+                    ds_t[j * LDP + i] = (bf16)v;
+                }
+        }
+        if (p.hscale && gr.dhscale) {
+            dhs = wave_sum(dhs);
+            if (lane == 0) atomicAdd(&s_dhs[head], dhs);
+        }
+        if (NB == 1) {      // k-slots 16..31 of the natural-order operands must read zeros
+            for (int c = lane; c < 16 * 16; c += 64) { at_t[(c >> 4) * LDP + 16 + (c & 15)] = (bf16)0.f; ds_t[(c >> 4) * LDP + 16 + (c & 15)] = (bf16)0.f; }
+        }
+        wsync();
+        // ---- dV^T[e][j] = sum_i dO[i][e] A[i][j]   and   dKn^T[e][j] = sum_i Qn[i][e] dS[i][j]      (k = query i, natural order)
+        // ---- dQn^T[e][i] = sum_j Kn[j][e] dS[i][j]                                                (k-slots in key order)
+        float dq[NB][NT16][4], dk[NB][NT16][4];
+#pragma unroll
+        for (int t = 0; t < NT16; ++t) {
+            const bf16x8 doT = tr_nat<NB>(do_t, LD, t, lane);
+            const bf16x8 qnT = tr_nat<NB>(qn_t, LD, t, lane);
+            const bf16x8 knT = tr_keys<NB>(kn_t, LD, t, lane);
+#pragma unroll
+            for (int jb = 0; jb < NB; ++jb) {
+                // B operands: row (key) j = 16*jb + (l & 15), 8 consecutive queries 8g..8g+7
+                const bf16x8 aB = *reinterpret_cast<const bf16x8*>(at_t + (16 * jb + i16) * LDP + 8 * gq);
+                const bf16x8 sB = *reinterpret_cast<const bf16x8*>(ds_t + (16 * jb + i16) * LDP + 8 * gq);
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doT, aB, z, 0, 0, 0);
+                const f32x4 dkk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qnT, sB, z, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dk[jb][t][r] = dkk[r];     // Qn tile carries d^-1/2 already
+                const int j = 16 * jb + i16;
+                if (j < L) {    // dV: lane (key j, channels 16t + 4g + r) -> 8-byte store
+                    bf16* dst = dqkv + (tok0 + j * g.tok_stride) * 3L * E + head * 3 * D + 2 * D + 16 * t + 4 * gq;
+                    float v[4] = {dv[0] * out_scale, dv[1] * out_scale, dv[2] * out_scale, dv[3] * out_scale};
+                    if (accumulate) {
+                        const bf16x4 old = *reinterpret_cast<const bf16x4*>(dst);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)old[r];
+                    }
+                    const bf16x4 w4 = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                    *reinterpret_cast<bf16x4*>(dst) = w4;
+                }
+            }
+#pragma unroll
+            for (int ib = 0; ib < NB; ++ib) {
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 dqq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(knT, pack_keys<NB>(dA, ib), z, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dq[ib][t][r] = dqq[r] * scale;
+            }
+        }
+        wsync();   // all transposed reads of the tiles are done: the tiles become the fp32 re-layout buffer
+        // ---- LayerNorm backward in the operand layout, q then k
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int t = 0; t < NT16; ++t) {
+                    const float4 v4 = part == 0 ? make_float4(dq[b][t][0], dq[b][t][1], dq[b][t][2], dq[b][t][3])
+                                                : make_float4(dk[b][t][0], dk[b][t][1], dk[b][t][2], dk[b][t][3]);
+                    *reinterpret_cast<float4*>(relay + (16 * b + i16) * LDF + 16 * t + 4 * gq) = v4;
+                }
+            wsync();
+            const float* w = part == 0 ? p.qw : p.kw;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int row = 16 * b + i16;
+                float dn[KS][8];
+                float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const float4 lo = *reinterpret_cast<const float4*>(relay + row * LDF + 32 * ks + 8 * gq);
+                    const float4 hi = *reinterpret_cast<const float4*>(relay + row * LDF + 32 * ks + 8 * gq + 4);
+                    const float raw[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float xh = part == 0 ? xq[b][ks][j] : xk[b][ks][j];
+                        const float d0 = row < L ? raw[j] : 0.f;
+                        if (part == 0) { a_qw[ks][j] += d0 * xh; a_qb[ks][j] += d0; } else { a_kw[ks][j] += d0 * xh; a_kb[ks][j] += d0; }
+                        const float gg = d0 * w[32 * ks + 8 * gq + j];
+                        dn[ks][j] = gg;
+                        m1 += gg; m2 += gg * xh;
+                    }
+                }
+                m1 = quad_sum(m1) / (float)D;
+                m2 = quad_sum(m2) / (float)D;
+                const float rs = part == 0 ? rq[b] : rk[b];
+                if (row < L) {
+                    bf16* dst = dqkv + (tok0 + row * g.tok_stride) * 3L * E + head * 3 * D + part * D + 8 * gq;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        bf16x8 o;
+                        bf16x8 old;
+                        if (accumulate) old = *reinterpret_cast<const bf16x8*>(dst + 32 * ks);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float xh = part == 0 ? xq[b][ks][j] : xk[b][ks][j];
+                            float v = rs * (dn[ks][j] - m1 - xh * m2);
+                            if (accumulate) v += (float)old[j];
+                            o[j] = (bf16)v;
+                        }
+                        *reinterpret_cast<bf16x8*>(dst + 32 * ks) = o;
+                    }
+                }
+            }
+            wsync();
+        }
+    }
+    // ---- flush parameter gradients.  Thousands of waves adding to the same few hundred addresses serialise at the
+    // memory side, so: lane-group shuffle reduce -> block reduce in LDS -> ONE row of plain stores per block into the
+    // workspace (summed by attn_ws_reduce), or atomics when no workspace is given.
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v[4] = {a_qw[ks][j], a_qb[ks][j], a_kw[ks][j], a_kb[ks][j]};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) v[q] += __shfl_xor(v[q], o, 64);
+            }
+            if (i16 == 0) {
+                const int e = 32 * ks + 8 * gq + j;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) atomicAdd(&s_ln[q * D + e], v[q]);
+            }
+        }
+    __syncthreads();
+    const int nvals = 4 * D + 32 * heads + heads;
+    for (int i = threadIdx.x; i < nvals; i += blockDim.x) {
+        float val;
+        float* dst;
+        if (i < 4 * D) { val = s_ln[i]; const int q = i / D, e = i % D; dst = (q == 0 ? gr.dqw : q == 1 ? gr.dqb : q == 2 ? gr.dkw : gr.dkb); if (dst) dst += e; }
+        else if (i < 4 * D + 32 * heads) { const int t = i - 4 * D; val = s_demb[(t / heads) * 16 + (t % heads)]; dst = gr.demb ? gr.demb + t : nullptr; }
+        else { const int t = i - 4 * D - 32 * heads; val = s_dhs[t]; dst = gr.dhscale ? gr.dhscale + t : nullptr; }
+        if (ws) ws[(long)blockIdx.x * nvals + i] = val;
+        else if (dst && val != 0.f) atomicAdd(dst, val);
+    }
+}
+
+// dst += sum over workspace rows
+__global__ void attn_ws_reduce(const float* __restrict__ ws, int rows, int D, int heads, Grd gr) {
+    const int nvals = 4 * D + 32 * heads + heads;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvals) return;
+    float acc = 0.f;
+    for (int r = 0; r < rows; ++r) acc += ws[(long)r * nvals + i];
+    float* dst;
+    if (i < 4 * D) { const int q = i / D, e = i % D; dst = (q == 0 ? gr.dqw : q == 1 ? gr.dqb : q == 2 ? gr.dkw : gr.dkb); if (dst) dst += e; }
+    else if (i < 4 * D + 32 * heads) dst = gr.demb ? gr.demb + (i - 4 * D) : nullptr;
+    else dst = gr.dhscale ? gr.dhscale + (i - 4 * D - 32 * heads) : nullptr;
+    if (dst) *dst += acc;
+}
+
+template <typename K>
+int set_lds(K kernel, size_t shm) {
+    if (shm > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return bf_fail(e, __FILE__, __LINE__);
+    }
+    return 0;
+}
+
+template <int NB, int KS>
+int go_fwd(const bf16* qkv, bf16* out, Geo g, int heads, Par p, float out_scale, int accumulate, hipStream_t st) {
+    constexpr int D = 32 * KS;
+    const int wpb = 4;
+    const size_t shm = (size_t)wpb * 16 * NB * (D + 16) * sizeof(bf16);
+    const long nprob = g.nseq * heads;
+    const int grid = (int)std::min<long>((nprob + wpb - 1) / wpb, 256L * 8);
+    hipLaunchKernelGGL((attn_fwd_mfma<NB, KS>), dim3(grid), dim3(wpb * 64), shm, st, qkv, out, g, heads, p, out_scale, accumulate);
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+template <int NB, int KS>
+int go_bwd(const bf16* qkv, const bf16* dout, bf16* dqkv, Geo g, int heads, Par p, Grd gr, float out_scale, int accumulate, float* ws,
+           long ws_floats, hipStream_t st) {
+    constexpr int D = 32 * KS, R = 16 * NB;
+    const int wpb = NB == 1 ? 4 : 2;
+    const size_t shm = (size_t)wpb * (3 * R * (D + 16) + 2 * R * 40) * sizeof(bf16);
+    if (int rc = set_lds(attn_bwd_mfma<NB, KS>, shm)) return rc;
+    const long nprob = g.nseq * heads;
+    const int nvals = 4 * D + 32 * heads + heads;
+    long grid = std::min<long>((nprob + wpb - 1) / wpb, 256L * 4);
+    if (ws && ws_floats < grid * nvals) { grid = ws_floats / nvals; if (grid < 1) ws = nullptr; }
+    hipLaunchKernelGGL((attn_bwd_mfma<NB, KS>), dim3((int)grid), dim3(wpb * 64), shm, st, qkv, dout, dqkv, g, heads, p, gr, out_scale, accumulate, ws);
+    BF_CHECK_LAUNCH();
+    if (ws) {
+        hipLaunchKernelGGL(attn_ws_reduce, dim3(bf_cdiv(nvals, 256)), dim3(256), 0, st, (const float*)ws, (int)grid, D, heads, gr);
+        BF_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+}  // namespace
+
+// dispatched from bf_attn_fwd / bf_attn_bwd (attn.hip) for bf16 with d in {32, 64, 96, 128}
+int bf_attn_fwd_mfma(const void* qkv, void* out, long nseq, int L, long inner, long outer_stride, long inner_stride, long tok_stride, int heads,
+                     int d, const float* qw, const float* qb, const float* kw, const float* kb, const float* emb, const float* hscale,
+                     float out_scale, int accumulate, hipStream_t st) {
+    Geo g{nseq, L, inner, outer_stride, inner_stride, tok_stride};
+    Par p{qw, qb, kw, kb, emb, hscale};
+    const int nb = L <= 16 ? 1 : 2, ks = d / 32;
+#define GO(NB, KS) if (nb == NB && ks == KS) return go_fwd<NB, KS>((const bf16*)qkv, (bf16*)out, g, heads, p, out_scale, accumulate, st)
+    GO(1, 1); GO(1, 2); GO(1, 3); GO(1, 4); GO(2, 1); GO(2, 2); GO(2, 3); GO(2, 4);
+#undef GO
+    return bf_fail_msg("bf_attn_fwd_mfma: unsupported shape", __FILE__, __LINE__);
+}
+int bf_attn_bwd_mfma(const void* qkv, const void* dout, void* dqkv, long nseq, int L, long inner, long outer_stride, long inner_stride,
+                     long tok_stride, int heads, int d, const float* qw, const float* qb, const float* kw, const float* kb, const float* emb,
+                     const float* hscale, float* dqw, float* dqb, float* dkw, float* dkb, float* demb, float* dhscale, float out_scale,
+                     int accumulate, float* ws, long ws_floats, hipStream_t st) {
+    Geo g{nseq, L, inner, outer_stride, inner_stride, tok_stride};
+    Par p{qw, qb, kw, kb, emb, hscale};
+    Grd gr{dqw, dqb, dkw, dkb, demb, dhscale};
+    const int nb = L <= 16 ? 1 : 2, ks = d / 32;
+#define GO(NB, KS) if (nb == NB && ks == KS) return go_bwd<NB, KS>((const bf16*)qkv, (const bf16*)dout, (bf16*)dqkv, g, heads, p, gr, out_scale, accumulate, ws, ws_floats, st)
+    GO(1, 1); GO(1, 2); GO(1, 3); GO(1, 4); GO(2, 1); GO(2, 2); GO(2, 3); GO(2, 4);
+#undef GO
+    return bf_fail_msg("bf_attn_bwd_mfma: unsupported shape", __FILE__, __LINE__);
+}

@@ -191,7 +191,8 @@ struct SpatialSaved {
 
 // transient scratch (backward is the larger user)
 struct Scratch {
-    float *G, *csum, *zeros, *ones, *wg;   // wg: prepared-layout weight gradient scratch
+    float *G, *csum, *zeros, *ones, *wg, *attn_ws;   // wg: prepared-layout weight gradient scratch
+    static constexpr long ATTN_WS_FLOATS = 1024L * (4 * 128 + 32 * 16 + 16);
     void *t1, *t3, *t4, *t1b;
     size_t bytes;
     Scratch(const D& d, void* base) {
@@ -205,6 +206,7 @@ struct Scratch {
         zeros = a.f32((size_t)4 * d.E);
         ones = a.f32((size_t)4 * d.E);
         wg = a.f32(wgn);
+        attn_ws = a.f32(ATTN_WS_FLOATS);
         // activation-sized transients; embed/debed stages work at up to (patch/2)^2 * N pixels of E/4 (or cin/cout) channels
         size_t tok = (size_t)d.N * d.E;
         size_t big = tok * 4;
@@ -342,7 +344,7 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
                   g->norm2_w, g->norm2_b, nullptr, nullptr, st));
     TRY(bf_attn_bwd(d.dtype, sv.qkv, dO, dqkv, (long)d.B * d.S, d.T, d.S, (long)d.T * d.S, 1, d.S, d.heads, d.d, p->qnorm_w, p->qnorm_b,
                     p->knorm_w, p->knorm_b, p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor : nullptr, g->qnorm_w, g->qnorm_b,
-                    g->knorm_w, g->knorm_b, g->rel_pos_emb, d.attn_scale ? g->attn_scale_factor : nullptr, 1.f, 0, st));
+                    g->knorm_w, g->knorm_b, g->rel_pos_emb, d.attn_scale ? g->attn_scale_factor : nullptr, 1.f, 0, sc.attn_ws, Scratch::ATTN_WS_FLOATS, st));
     void* dxn = sc.t1;      // don is dead
     TRY(linear_bwd(d, sc, dqkv, 3 * d.E, x, d.E, BF_PRO_AFFINE, sv.sc1, sv.sh1, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st));
     TRY(bf_in_bwd(d.dtype, dxn, x, dout, dx, (int)d.F, (int)d.S, d.E, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, nullptr, 1, 0,
@@ -439,10 +441,10 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     void* dqkv = sc.t3;
     TRY(bf_attn_bwd(d.dtype, sv.qkv, dO, dqkv, d.F * d.h, d.w, 1, d.w, 0, 1, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
                     p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_x : nullptr, g->qnorm_w, g->qnorm_b, g->knorm_w, g->knorm_b,
-                    g->rel_pos_emb, d.attn_scale ? g->attn_scale_factor_x : nullptr, 0.5f, 0, st));
+                    g->rel_pos_emb, d.attn_scale ? g->attn_scale_factor_x : nullptr, 0.5f, 0, sc.attn_ws, Scratch::ATTN_WS_FLOATS, st));
     TRY(bf_attn_bwd(d.dtype, sv.qkv, dO, dqkv, d.F * d.w, d.h, d.w, d.S, 1, d.w, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
                     p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_y : nullptr, g->qnorm_w, g->qnorm_b, g->knorm_w, g->knorm_b,
-                    g->rel_pos_emb, d.attn_scale ? g->attn_scale_factor_y : nullptr, 0.5f, 1, st));
+                    g->rel_pos_emb, d.attn_scale ? g->attn_scale_factor_y : nullptr, 0.5f, 1, sc.attn_ws, Scratch::ATTN_WS_FLOATS, st));
     void* dxn = sc.t1;      // don is dead
     TRY(linear_bwd(d, sc, dqkv, 3 * d.E, x, d.E, BF_PRO_AFFINE, sv.sc1, sv.sh1, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st));
     TRY(bf_in_bwd(d.dtype, dxn, x, dx1, dx, (int)d.F, (int)d.S, d.E, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, nullptr, 1, 0,

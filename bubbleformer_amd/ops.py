@@ -90,6 +90,36 @@ def _grad_views(params: Sequence[Optional[torch.Tensor]]):
     return flat, views
 
 
+# "direct gradient" mode (used by trainer.TrainStep): when every parameter of a stage has a registered fp32 gradient
+# slot (a view into the flat gradient buffer), the kernels accumulate straight into it and autograd gets None -- no
+# per-parameter temporaries, no 500 tiny accumulate kernels per step.  `on_ready` tells the bucket reducer that a
+# stage's gradients are enqueued on the current stream.  Outside this mode gradients are returned to autograd as usual
+# (so DDP / optimizer hooks of an unmodified training script still fire).
+_DIRECT = {"slots": None, "on_ready": None}
+
+
+def set_direct_grad_slots(slots, on_ready=None) -> None:
+    """slots: {param.data_ptr(): fp32 gradient view} or None to switch the mode off."""
+    _DIRECT["slots"] = slots
+    _DIRECT["on_ready"] = on_ready
+
+
+def _stage_grads(params: Sequence[Optional[torch.Tensor]]):
+    """-> (gradient tensors the kernels accumulate into, what to hand back to autograd)"""
+    slots = _DIRECT["slots"]
+    if slots is not None:
+        gs = [None if p is None else slots.get(p.data_ptr()) for p in params]
+        if all((p is None) == (g is None) for p, g in zip(params, gs)):
+            return gs, [None] * len(params), True
+    _, views = _grad_views(params)
+    return views, views, False
+
+
+def _stage_done(params, direct: bool) -> None:
+    if direct and _DIRECT["on_ready"] is not None:
+        _DIRECT["on_ready"]([p.data_ptr() for p in params if p is not None])
+
+
 def as_tokens(x: torch.Tensor) -> torch.Tensor:
     """(..., E, h, w) reference layout -> (..., h, w, E) token-major contiguous (zero-copy when x is already a
     permuted view of token-major memory)."""
@@ -140,7 +170,7 @@ class _BlockFn(torch.autograd.Function):
         d = make_dims(x.dtype, B, T, h, w, E, heads, attn_scale, feat_scale)
         lib = L.lib()
         dout = dout.contiguous()
-        flat, gviews = _grad_views(params)
+        gviews, ret, direct = _stage_grads(params)
         if ctx.kind == "temporal":
             st, gs, bwd = L.TemporalParams(*[_p(p) for p in params]), L.TemporalParams(*[_p(g) for g in gviews]), lib.bf_temporal_bwd
         else:
@@ -148,7 +178,8 @@ class _BlockFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         L.check(bwd(C.byref(d), C.byref(st), C.byref(gs), _p(x), _p(dout), _p(dx), _p(saved), _p(scratch_for(d, x.device)), _stream()),
                 f"bf_{ctx.kind}_bwd")
-        return (dx, None, None, None, None, *gviews)
+        _stage_done(params, direct)
+        return (dx, None, None, None, None, *ret)
 
 
 def temporal_block(x: torch.Tensor, heads: int, attn_scale: bool, params: List[Optional[torch.Tensor]]) -> torch.Tensor:
@@ -205,7 +236,7 @@ class _EmbedFn(torch.autograd.Function):
         d = make_dims(compute_dtype, B, T, h, w, E, 1, patch=patch, cin=Cin, cout=1, nfluid=nfluid)
         lib = L.lib()
         conv, inw, inb, film = params[:nst], params[nst:2 * nst], params[2 * nst:3 * nst], params[3 * nst:]
-        flat, gv = _grad_views(params)
+        gv, ret, direct = _stage_grads(params)
         cw, iw, ib = _stage_arrays(conv, inw, inb)
         st = L.EmbedParams(cw, iw, ib, *([_p(t) for t in film] if film else [None] * 4))
         gcw, giw, gib = _stage_arrays(gv[:nst], gv[nst:2 * nst], gv[2 * nst:3 * nst])
@@ -214,7 +245,8 @@ class _EmbedFn(torch.autograd.Function):
         dx = torch.empty(xshape, dtype=torch.float32, device=dout.device) if ctx.needs_input_grad[0] else None
         L.check(lib.bf_embed_bwd(C.byref(d), C.byref(st), C.byref(gs), _p(dout), _p(dx), _p(saved), _p(scratch_for(d, dout.device)),
                                  _stream()), "bf_embed_bwd")
-        return (dx, None, None, None, None, None, *gv)
+        _stage_done(params, direct)
+        return (dx, None, None, None, None, None, *ret)
 
 
 def embed(x, fluid, compute_dtype, patch, embed_dim, conv_w, in_w, in_b, film_params=()):
@@ -258,7 +290,7 @@ class _DebedFn(torch.autograd.Function):
         d = make_dims(x.dtype, B, T, h, w, E, 1, patch=patch, cin=1, cout=cout)
         lib = L.lib()
         conv, inw, inb = params[:nst], params[nst:2 * nst - 1], params[2 * nst - 1:]
-        flat, gv = _grad_views(params)
+        gv, ret, direct = _stage_grads(params)
         cw, iw, ib = _stage_arrays(conv, inw, inb)
         st = L.DebedParams(cw, iw, ib)
         gcw, giw, gib = _stage_arrays(gv[:nst], gv[nst:2 * nst - 1], gv[2 * nst - 1:])
@@ -273,7 +305,8 @@ class _DebedFn(torch.autograd.Function):
             dpred = dpred.contiguous().float()
             L.check(lib.bf_debed_bwd(C.byref(d), C.byref(st), C.byref(gs), _p(x), _p(dpred), None, None, None, _p(dx), _p(saved),
                                      _p(scratch_for(d, x.device)), _stream()), "bf_debed_bwd")
-        return (dx, None, None, None, None, *gv)
+        _stage_done(params, direct)
+        return (dx, None, None, None, None, *ret)
 
 
 def debed(x, patch, cout, conv_w, in_w, in_b):

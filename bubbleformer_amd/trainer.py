@@ -61,14 +61,25 @@ class BucketReducer:
             for p, b in zip(flat.params, bucket_of):
                 p.register_post_accumulate_grad_hook(self._make_hook(b))
 
-    def _make_hook(self, b):
-        def hook(_p):
-            self.pending[b] += 1
-            if self.pending[b] == self.count[b]:
-                self.pending[b] = 0
+        self.bucket_of_ptr = {p.data_ptr(): b for p, b in zip(flat.params, bucket_of)}
+
+    def _arrived(self, b):
+        self.pending[b] += 1
+        if self.pending[b] == self.count[b]:
+            self.pending[b] = 0
+            if self.enabled:
                 g = self.flat.grad[self.lo[b]:self.hi[b]]
                 self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _make_hook(self, b):
+        def hook(_p):
+            self._arrived(b)
         return hook
+
+    def stage_ready(self, ptrs):
+        """Direct-gradient mode: the stage's kernels (accumulating into the flat buffer) are enqueued on the current stream."""
+        for ptr in ptrs:
+            self._arrived(self.bucket_of_ptr[ptr])
 
     def wait(self) -> float:
         """Block the current stream on the outstanding buckets; returns the factor the optimizer must apply (1/world)."""
@@ -98,6 +109,7 @@ class TrainStep:
         self.model = model
         self.flat = FlatParams(model)
         self.reducer = BucketReducer(self.flat, stage_buckets(model))
+        self.slots = {p.data_ptr(): p.grad for p in self.flat.params}
         self.m = torch.zeros_like(self.flat.flat)
         self.v = torch.zeros_like(self.flat.flat)
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
@@ -105,9 +117,17 @@ class TrainStep:
 
     def __call__(self, x, fluid, target) -> torch.Tensor:
         self.flat.zero_grad()
-        loss, _ = self.model.forward_loss(x, fluid, target) if fluid is not None else self.model.forward_loss(x, target)
-        loss.backward()
+        self.ops.set_direct_grad_slots(self.slots, self.reducer.stage_ready)
+        try:
+            loss = self._fwd_bwd(x, fluid, target)
+        finally:
+            self.ops.set_direct_grad_slots(None)
         gscale = self.reducer.wait()
         self.step_no += 1
         self.ops.adamw_(self.flat.flat, self.flat.grad, self.m, self.v, self.step_no, self.lr, self.betas, self.eps, self.wd, gscale)
         return loss.detach()
+
+    def _fwd_bwd(self, x, fluid, target):
+        loss, _ = self.model.forward_loss(x, fluid, target) if fluid is not None else self.model.forward_loss(x, target)
+        loss.backward()
+        return loss

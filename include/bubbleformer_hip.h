@@ -115,7 +115,11 @@ int bf_attn_bwd(int dtype, const void* qkv, const void* dout, void* dqkv, int64_
                 int64_t outer_stride, int64_t inner_stride, int64_t tok_stride, int heads, int d, const float* qw,
                 const float* qb, const float* kw, const float* kb, const float* emb, const float* hscale, float* dqw,
                 float* dqb, float* dkw, float* dkb, float* demb, float* dhscale, float out_scale, int accumulate,
+                float* ws, int64_t ws_floats, /* optional workspace for the block-partial parameter gradients (NULL: atomics) */
                 bf_stream_t stream);
+
+/* test hook: route bf16 attention through the generic fp32-VALU kernel instead of the MFMA kernel */
+void bf_debug_force_generic_attn(int on);
 
 int bf_im2col_nchw(int dtype, const float* x, void* out, int frames, int C, int H, int W, int Kp, bf_stream_t stream);
 int bf_col2im_nchw(int dtype, const void* g, float* dx, int frames, int C, int H, int W, int Kp, bf_stream_t stream);

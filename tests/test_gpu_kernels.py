@@ -121,3 +121,62 @@ def test_in_stats_two_pass(K, dtype):
     _, _, sc2, sh2 = K.in_stats(x2, Fr, S, Cc, w, b)
     x2f = x2.float()
     assert _rel(x2f * sc2[:, None] + sh2[:, None], torch.nn.functional.instance_norm(x2f.permute(0, 2, 1), weight=w, bias=b).permute(0, 2, 1)) < 5e-6
+
+
+def _attn_call(L_lib, qkv, dout, geo, heads, d, prm, generic):
+    """Run attention fwd + bwd through the C ABI; returns (out, dqkv, param grads)."""
+    import ctypes as C
+    from bubbleformer_amd.ops import _dt, _p, _stream
+    from bubbleformer_amd import _lib as L
+    h = L.lib()
+    h.bf_debug_force_generic_attn(1 if generic else 0)
+    try:
+        N = qkv.shape[0]
+        E = heads * d
+        out = torch.zeros(N, E, device="cuda", dtype=qkv.dtype)
+        dqkv = torch.zeros_like(qkv)
+        grads = [torch.zeros_like(t) for t in prm]
+        nseq, Lq, inner, ostr, istr, tstr = geo
+        L.check(h.bf_attn_fwd(_dt(qkv.dtype), _p(qkv), _p(out), nseq, Lq, inner, ostr, istr, tstr, heads, d, *[_p(t) for t in prm], 0.5, 0, _stream()), "fwd")
+        L.check(h.bf_attn_bwd(_dt(qkv.dtype), _p(qkv), _p(dout), _p(dqkv), nseq, Lq, inner, ostr, istr, tstr, heads, d, *[_p(t) for t in prm],
+                              *[_p(t) for t in grads], 0.5, 0, None, 0, _stream()), "bwd")
+        torch.cuda.synchronize()
+        return out, dqkv, grads
+    finally:
+        h.bf_debug_force_generic_attn(0)
+
+
+@pytest.mark.parametrize("L,d,heads", [(12, 64, 6), (16, 64, 6), (24, 64, 2), (32, 64, 3), (7, 32, 2), (20, 128, 1)])
+@pytest.mark.parametrize("axis", ["contig", "strided"])
+def test_attention_mfma_matches_generic_and_fp32(L, d, heads, axis):
+    """bf16 MFMA attention (fwd + bwd) vs (a) the generic fp32-VALU kernel on the same bf16 inputs, (b) the generic
+    kernel on fp32 copies of the inputs (the parity-mode kernel, itself pinned by the golden model tests)."""
+    g = torch.Generator(device="cuda").manual_seed(100 + L + d)
+    E = heads * d
+    inner_n = 5
+    if axis == "contig":          # sequences of L contiguous tokens
+        nseq = 14
+        geo = (nseq, L, 1, L, 0, 1)
+    else:                         # token = (s / inner) * L * inner + s % inner + l * inner
+        nseq = 3 * inner_n
+        geo = (nseq, L, inner_n, L * inner_n, 1, inner_n)
+    N = nseq * L
+    qkv = (torch.randn(N, 3 * E, device="cuda", generator=g) * 1.5).bfloat16()
+    dout = torch.randn(N, E, device="cuda", generator=g).bfloat16()
+    prm = [1 + 0.2 * torch.randn(d, device="cuda", generator=g), 0.2 * torch.randn(d, device="cuda", generator=g),
+           1 + 0.2 * torch.randn(d, device="cuda", generator=g), 0.2 * torch.randn(d, device="cuda", generator=g),
+           0.5 * torch.randn(32, heads, device="cuda", generator=g), 1 + 0.3 * torch.randn(heads, device="cuda", generator=g)]
+    o_m, dq_m, g_m = _attn_call(None, qkv, dout, geo, heads, d, prm, generic=False)
+    o_g, dq_g, g_g = _attn_call(None, qkv, dout, geo, heads, d, prm, generic=True)
+    o_f, dq_f, g_f = _attn_call(None, qkv.float(), dout.float(), geo, heads, d, prm, generic=True)
+    assert torch.isfinite(o_m.float()).all() and torch.isfinite(dq_m.float()).all()
+    assert _rel(o_m.float(), o_f) < 1.5e-2 and _rel(o_g.float(), o_f) < 1.5e-2
+    parts = lambda t: t.float().view(N, heads, 3, d)
+    for pi, pn in enumerate("qkv"):
+        e = _rel(parts(dq_m)[:, :, pi], parts(dq_f)[:, :, pi])
+        assert e < 3e-2, (pn, e)
+    for a, b, name in zip(g_m, g_f, ("dqw", "dqb", "dkw", "dkb", "demb", "dhscale")):
+        if name == "dkb":     # structurally zero (softmax is shift invariant): bf16 rounding noise around 0, absolute bound
+            assert float((a - b).norm()) < 1e-2 * float(g_f[0].norm()), (name, float((a - b).norm()), float(g_f[0].norm()))
+        else:
+            assert float((a - b).norm()) / float(b.norm()) < (1e-1 if name == "dhscale" else 5e-2), (name, float((a - b).norm()) / float(b.norm()))
