@@ -502,18 +502,25 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma(const bf16* __restrict__ qk
     }
 }
 
-// dst += sum over workspace rows
-__global__ void attn_ws_reduce(const float* __restrict__ ws, int rows, int D, int heads, Grd gr) {
+// dst += sum over workspace rows.  grid (ceil(nvals / 64), row slices); 4 row groups per block; a handful of atomics per value.
+__global__ void __launch_bounds__(256) attn_ws_reduce(const float* __restrict__ ws, int rows, int D, int heads, Grd gr) {
+    __shared__ float red[4][64];
     const int nvals = 4 * D + 32 * heads + heads;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nvals) return;
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int per = (rows + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
     float acc = 0.f;
-    for (int r = 0; r < rows; ++r) acc += ws[(long)r * nvals + i];
+    if (i < nvals)
+        for (int r = r0 + rg; r < r1; r += 4) acc += ws[(long)r * nvals + i];
+    red[rg][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rg != 0 || i >= nvals) return;
+    acc = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
     float* dst;
     if (i < 4 * D) { const int q = i / D, e = i % D; dst = (q == 0 ? gr.dqw : q == 1 ? gr.dqb : q == 2 ? gr.dkw : gr.dkb); if (dst) dst += e; }
     else if (i < 4 * D + 32 * heads) dst = gr.demb ? gr.demb + (i - 4 * D) : nullptr;
     else dst = gr.dhscale ? gr.dhscale + (i - 4 * D - 32 * heads) : nullptr;
-    if (dst) *dst += acc;
+    if (dst && acc != 0.f) atomicAdd(dst, acc);
 }
 
 template <typename K>
@@ -545,12 +552,12 @@ int go_bwd(const bf16* qkv, const bf16* dout, bf16* dqkv, Geo g, int heads, Par 
     if (int rc = set_lds(attn_bwd_mfma<NB, KS>, shm)) return rc;
     const long nprob = g.nseq * heads;
     const int nvals = 4 * D + 32 * heads + heads;
-    long grid = std::min<long>((nprob + wpb - 1) / wpb, 256L * 4);
+    long grid = std::min<long>((nprob + wpb - 1) / wpb, 256L * 2);
     if (ws && ws_floats < grid * nvals) { grid = ws_floats / nvals; if (grid < 1) ws = nullptr; }
     hipLaunchKernelGGL((attn_bwd_mfma<NB, KS>), dim3((int)grid), dim3(wpb * 64), shm, st, qkv, dout, dqkv, g, heads, p, gr, out_scale, accumulate, ws);
     BF_CHECK_LAUNCH();
     if (ws) {
-        hipLaunchKernelGGL(attn_ws_reduce, dim3(bf_cdiv(nvals, 256)), dim3(256), 0, st, (const float*)ws, (int)grid, D, heads, gr);
+        hipLaunchKernelGGL(attn_ws_reduce, dim3(bf_cdiv(nvals, 64), 16), dim3(256), 0, st, (const float*)ws, (int)grid, D, heads, gr);
         BF_CHECK_LAUNCH();
     }
     return 0;

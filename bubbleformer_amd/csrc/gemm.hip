@@ -15,10 +15,14 @@
 // consecutive output COLUMNS of one row: 8-/16-byte epilogue stores and vector bias loads.
 // XC (outer-contiguous) bf16 tiles are read with the gfx950 transposing LDS read (ds_read_b64_tr_b16).
 #include "bf_common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, NT = 256;
+constexpr int BN = 128, NT = 256;
+#ifndef BF_GEMM_DEFAULT_STAGES
+#define BF_GEMM_DEFAULT_STAGES 1
+#endif
 
 template <typename T> struct GemmCfg;
 template <> struct GemmCfg<bf16> { static constexpr int BK = 64, KSTEP = 32, PADK = 8, PADX = 8; };
@@ -30,81 +34,139 @@ struct OpDev {
 };
 struct EpiDev {
     const float* bias; const float* colscale; const float* colshift; int aux_mode; const void* aux; long ld_aux;
-    int out_mode; void* c; long ldc; int seglen; long segstride; int gw, gh, gc;
+    int out_mode; void* c; long ldc; int seglen; long segstride; int gw, gh, gc; void* gelu_out;
 };
 
-__device__ __forceinline__ long row_base(long row, long ld, int gw, int gh, int gc) {
-    if (gw <= 0) return row * ld;
-    const int x = (int)(row % gw);
-    const long t = row / gw;
-    const int y = (int)(t % gh);
-    const long f = t / gh;
-    return ((f * 2 * gh + 2 * y) * (2L * gw) + 2 * x) * gc;
+__device__ __forceinline__ long row_base(int row, long ld, int gw, int gh, int gc) {
+    if (gw <= 0) return (long)row * ld;
+    const unsigned ur = (unsigned)row;
+    const unsigned x = ur % (unsigned)gw, t = ur / (unsigned)gw;
+    const unsigned y = t % (unsigned)gh, f = t / (unsigned)gh;
+    return ((long)(f * 2u * gh + 2u * y) * (2L * gw) + 2 * x) * gc;
 }
 __device__ __forceinline__ long col_off(int col, int seglen, long segstride) {
     if (seglen <= 0) return col;
-    return (long)(col / seglen) * segstride + (col % seglen);
+    const unsigned q = (unsigned)col / (unsigned)seglen;
+    return (long)q * segstride + (col - (int)q * seglen);
+}
+
+// Prologue table: the per-(frame, channel) scale/shift an operand needs, staged once per block into LDS.
+constexpr int TAB = 2048;   // floats per array (sc, sh): 16 KiB together
+struct ProTab {
+    const float* sc; const float* sh;   // LDS (ok) or global (fallback)
+    int f_lo, c_lo, cw; bool ok;
+};
+// rows [r_lo, r_hi] of the operand (memory rows = tokens), channels [c_lo, c_lo + cw)
+__device__ __forceinline__ ProTab stage_table(const OpDev& op, long r_lo, long r_hi, int c_lo, int cw, float* lds_sc, float* lds_sh, int tid) {
+    ProTab t;
+    t.f_lo = (int)(r_lo / op.rpf);
+    const int nf = (int)(r_hi / op.rpf) - t.f_lo + 1;
+    t.c_lo = c_lo; t.cw = cw;
+    t.ok = (op.pro == BF_PRO_AFFINE || op.pro == BF_PRO_AFFINE_GELU) && (long)nf * cw <= TAB;
+    if (t.ok) {
+        for (int i = tid; i < nf * cw; i += NT) {
+            const int fi = i / cw, c = c_lo + i % cw;
+            const bool v = c < op.nch;
+            lds_sc[i] = v ? op.sc[(long)(t.f_lo + fi) * op.nch + c] : 0.f;
+            lds_sh[i] = v ? op.sh[(long)(t.f_lo + fi) * op.nch + c] : 0.f;
+        }
+        t.sc = lds_sc; t.sh = lds_sh;
+    } else {
+        t.sc = op.sc; t.sh = op.sh;
+    }
+    return t;
 }
 
 // Stage one operand tile.  TR x TC elements, row-major in LDS with leading dim LDT.
-// KC: rows = outer index (BM/BN), cols = k.  XC: rows = k, cols = outer index.
-template <typename T, int TR, int TC, int LDT, bool PRO>
+// KC: rows = outer index (BM/BN, fixed for the block), cols = k (advance per K-tile).
+// XC: rows = k (advance per K-tile), cols = outer index (fixed for the block).
+// The fixed half of every chunk address is computed once (setup); issue() adds the moving half and puts the 16-byte
+// loads in flight; commit() (later) applies the prologue and writes LDS.  32-bit index math throughout.
+template <typename T, int TR, int TC, int LDT, bool XC>
 struct Stager {
     static constexpr int CH = Chunk<T>::N;
     static constexpr int CPR = TC / CH;
-    static constexpr int NCH = TR * TC / CH / NT;   // chunks per thread
+    static constexpr int NCH = TR * TC / CH / NT;   // chunks per thread; chunk i sits at tile row r0 + (NT / CPR) * i, tile col cc
+    static constexpr int RSTEP = NT / CPR;
     Chunk<T> data[NCH];
-    float sc[PRO ? NCH : 1][CH], sh[PRO ? NCH : 1][CH];
-    bool valid[NCH];
+    unsigned valid;
+    int k0;
+};
+template <typename T, int TR, int TC, int LDT, bool XC>
+struct StagerFixed {
+    static constexpr int CH = Chunk<T>::N;
+    static constexpr int CPR = TC / CH;
+    static constexpr int NCH = TR * TC / CH / NT;
+    static constexpr int RSTEP = NT / CPR;
+    long fixed[XC ? 1 : NCH];      // KC: row_base per chunk row; XC: col_off of the thread's column
+    int fidx[XC ? 1 : NCH];        // KC: frame of each chunk row (prologue)
+    unsigned ok;                   // KC: bit i = row in range; XC: bit 0 = column in range
+    int r0, cc;
 
-    // row0/col0: global row / col of the tile origin; nrows/ncols: global extents
-    __device__ __forceinline__ void issue(const OpDev& op, long row0, long nrows, int col0, int ncols, int tid) {
+    __device__ __forceinline__ void setup(const OpDev& op, int outer0, int nouter, int tid) {
+        r0 = tid / CPR; cc = (tid % CPR) * CH;
+        ok = 0u;
+        if constexpr (!XC) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int row = outer0 + r0 + RSTEP * i;
+                const bool v = row < nouter;
+                ok |= (v ? 1u : 0u) << i;
+                fixed[i] = v ? row_base(row, op.ld, op.gw, op.gh, op.gc) : 0;
+                fidx[i] = row / op.rpf;
+            }
+        } else {
+            const int col = outer0 + cc;
+            ok = col < nouter ? 1u : 0u;
+            fixed[0] = col_off(col, op.seglen, op.segstride);
+            fidx[0] = 0;
+        }
+    }
+    __device__ __forceinline__ void issue(Stager<T, TR, TC, LDT, XC>& s, const OpDev& op, int k0, int kend) const {
         const T* base = reinterpret_cast<const T*>(op.p);
+        s.k0 = k0; s.valid = 0u;
+        if constexpr (!XC) {
+            const int col = k0 + cc;
+            const bool cv = col < kend;
+            const long co = col_off(col, op.seglen, op.segstride);
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = tid + NT * i;
-            const int r = c / CPR, cc = (c % CPR) * CH;
-            const long row = row0 + r;
-            const int col = col0 + cc;
-            valid[i] = (row < nrows) && (col < ncols);
-            if (valid[i]) {
-                const long a = row_base(row, op.ld, op.gw, op.gh, op.gc) + col_off(col, op.seglen, op.segstride);
-                data[i].load(base + a);
-                if (PRO && (op.pro == BF_PRO_AFFINE || op.pro == BF_PRO_AFFINE_GELU)) {
-                    const long f = row / op.rpf;
-                    const int ch = col % op.nch;
-                    const float* s = op.sc + f * op.nch + ch;
-                    const float* h = op.sh + f * op.nch + ch;
+            for (int i = 0; i < NCH; ++i) {
+                if (cv && ((ok >> i) & 1u)) { s.valid |= 1u << i; s.data[i].load(base + fixed[i] + co); }
+                else s.data[i].zero();
+            }
+        } else {
 #pragma unroll
-                    for (int j = 0; j < CH; j += 4) {
-                        const float4 a4 = *reinterpret_cast<const float4*>(s + j);
-                        const float4 b4 = *reinterpret_cast<const float4*>(h + j);
-                        constexpr int ii_dummy = 0; (void)ii_dummy;
-                        const int ii = PRO ? i : 0;
-                        sc[ii][j] = a4.x; sc[ii][j + 1] = a4.y; sc[ii][j + 2] = a4.z; sc[ii][j + 3] = a4.w;
-                        sh[ii][j] = b4.x; sh[ii][j + 1] = b4.y; sh[ii][j + 2] = b4.z; sh[ii][j + 3] = b4.w;
-                    }
-                }
-            } else {
-                data[i].zero();
+            for (int i = 0; i < NCH; ++i) {
+                const int row = k0 + r0 + RSTEP * i;
+                if (ok && row < kend) { s.valid |= 1u << i; s.data[i].load(base + row_base(row, op.ld, op.gw, op.gh, op.gc) + fixed[0]); }
+                else s.data[i].zero();
             }
         }
     }
-    __device__ __forceinline__ void commit(const OpDev& op, T* lds, int tid) {
+    template <bool PRO>
+    __device__ __forceinline__ void commit(Stager<T, TR, TC, LDT, XC>& s, const OpDev& op, const ProTab& tab, T* lds, int outer0) const {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int c = tid + NT * i;
-            const int r = c / CPR, cc = (c % CPR) * CH;
-            if (PRO && op.pro != BF_PRO_NONE && valid[i]) {
+            const int r = r0 + RSTEP * i;
+            if (PRO && op.pro != BF_PRO_NONE && ((s.valid >> i) & 1u)) {
+                const float* sp = nullptr;
+                const float* hp = nullptr;
+                if (op.pro != BF_PRO_GELU) {
+                    int f, ch;
+                    if constexpr (!XC) { f = fidx[i]; ch = (s.k0 + cc) % op.nch; }
+                    else { f = (s.k0 + r) / op.rpf; ch = (outer0 + cc) % op.nch; }
+                    const long o = tab.ok ? (long)(f - tab.f_lo) * tab.cw + (ch - tab.c_lo) : (long)f * op.nch + ch;
+                    sp = tab.sc + o; hp = tab.sh + o;
+                }
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
-                    float v = data[i].get(j);
-                    if (op.pro != BF_PRO_GELU) v = v * sc[PRO ? i : 0][j] + sh[PRO ? i : 0][j];
+                    float v = s.data[i].get(j);
+                    if (op.pro != BF_PRO_GELU) v = v * sp[j] + hp[j];
                     if (op.pro != BF_PRO_AFFINE) v = gelu_f(v);
-                    data[i].set(j, v);
+                    s.data[i].set(j, v);
                 }
             }
-            data[i].store(lds + r * LDT + cc);
+            s.data[i].store(lds + r * LDT + cc);
         }
     }
 };
@@ -136,134 +198,185 @@ __device__ __forceinline__ float frag_f32(const float* t, int outer, int k0, int
     else return t[(k0 + g) * LDT + outer + i];
 }
 
-template <typename T, bool AXC, bool BXC, bool APRO, bool BPRO>
-__global__ void __launch_bounds__(NT) gemm_kernel(int M, int N, int K, OpDev A, OpDev B, EpiDev E, int kper) {
+// Tile order.  The grid is 1-D; workgroups are dealt round-robin over the 8 XCDs (private L2 each), so each XCD is
+// given a CONTIGUOUS run of the tile sequence (split slowest, then m, n fastest): workgroups that share an activation
+// row panel (or, for split-K, a token slice) run back to back on one L2.  Bijective for any tile count; placement only
+// affects speed.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg / 8, r = nwg % 8, x = bid % 8;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+}
+
+template <typename T>
+__device__ __forceinline__ void store4(T* c, const float (&u)[4], bool full, int nleft) {
+    if (full) {
+        if constexpr (sizeof(T) == 2) {
+            const bf16x4 o = {(bf16)u[0], (bf16)u[1], (bf16)u[2], (bf16)u[3]};
+            *reinterpret_cast<bf16x4*>(c) = o;
+        } else {
+            *reinterpret_cast<float4*>(c) = make_float4(u[0], u[1], u[2], u[3]);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < nleft) c[r] = from_f<T>(u[r]);
+    }
+}
+
+template <typename T, bool AXC, bool BXC, bool APRO, bool BPRO, int NSTAGE, int TM>
+__global__ void __launch_bounds__(NT) gemm_kernel(int M, int N, int K, OpDev A, OpDev B, EpiDev E, int kper, int mt, int nt) {
     using Cfg = GemmCfg<T>;
     constexpr int BK = Cfg::BK;
+    constexpr int BM = 32 * TM;            // 2 x 2 waves, TM x 4 MFMA tiles of 16 x 16 per wave
     constexpr int LDA = AXC ? (BM + Cfg::PADX) : (BK + Cfg::PADK);
     constexpr int LDB = BXC ? (BN + Cfg::PADX) : (BK + Cfg::PADK);
     constexpr int A_ELEMS = AXC ? BK * LDA : BM * LDA;
     constexpr int B_ELEMS = BXC ? BK * LDB : BN * LDB;
+    constexpr bool ANYPRO = APRO || BPRO;
     __shared__ __attribute__((aligned(16))) T lds[A_ELEMS + B_ELEMS];
+    __shared__ __attribute__((aligned(16))) float ltab[ANYPRO ? 2 * TAB : 4];
     T* lA = lds;
     T* lB = lds + A_ELEMS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    // blockIdx.x walks M fastest so neighbouring blocks share the weight panel in L2
-    const long m0 = (long)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
-    const int kbeg = blockIdx.z * kper;
+    const int seq = xcd_remap(blockIdx.x, gridDim.x);
+    const int zt = seq / (mt * nt), rem = seq - zt * (mt * nt);
+    const int m0 = (rem / nt) * BM;
+    const int n0 = (rem % nt) * BN;
+    const int kbeg = zt * kper;
     const int kend = min(K, kbeg + kper);
 
-    using StA = Stager<T, AXC ? BK : BM, AXC ? BM : BK, LDA, APRO>;
-    using StB = Stager<T, BXC ? BK : BN, BXC ? BN : BK, LDB, BPRO>;
-    StA sa;
-    StB sb;
+    using StA = Stager<T, AXC ? BK : BM, AXC ? BM : BK, LDA, AXC>;
+    using StB = Stager<T, BXC ? BK : BN, BXC ? BN : BK, LDB, BXC>;
+    StagerFixed<T, AXC ? BK : BM, AXC ? BM : BK, LDA, AXC> fa_;
+    StagerFixed<T, BXC ? BK : BN, BXC ? BN : BK, LDB, BXC> fb_;
+    fa_.setup(A, m0, M, tid);
+    fb_.setup(B, n0, N, tid);
+    StA sa[NSTAGE];
+    StB sb[NSTAGE];
 
-    f32x4 acc[4][4];
+    f32x4 acc[TM][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto issue = [&](int k0) {
-        if constexpr (AXC) sa.issue(A, k0, kend, (int)m0, M, tid);
-        else sa.issue(A, m0, M, k0, kend, tid);
-        if constexpr (BXC) sb.issue(B, k0, kend, n0, N, tid);
-        else sb.issue(B, n0, N, k0, kend, tid);
-    };
+    // NSTAGE K-tiles of loads in flight before the first one is needed
+#pragma unroll
+    for (int s = 0; s < NSTAGE; ++s)
+        if (kbeg + s * BK < kend) { fa_.issue(sa[s], A, kbeg + s * BK, kend); fb_.issue(sb[s], B, kbeg + s * BK, kend); }
 
-    if (kbeg < kend) issue(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        __syncthreads();
-        sa.commit(A, lA, tid);
-        sb.commit(B, lB, tid);
-        __syncthreads();
-        if (k0 + BK < kend) issue(k0 + BK);
+    ProTab ta{}, tb{};
+    if constexpr (APRO) {
+        if constexpr (AXC) ta = stage_table(A, kbeg, kend - 1, m0, BM, ltab, ltab + TAB, tid);
+        else ta = stage_table(A, m0, min(M, m0 + BM) - 1, 0, A.nch, ltab, ltab + TAB, tid);
+    }
+    if constexpr (BPRO) {
+        if constexpr (BXC) tb = stage_table(B, kbeg, kend - 1, n0, BN, ltab, ltab + TAB, tid);
+        else tb = stage_table(B, n0, min(N, n0 + BN) - 1, 0, B.nch, ltab, ltab + TAB, tid);
+    }
+
+    int k0 = kbeg;
+    while (k0 < kend) {
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += Cfg::KSTEP) {
-            if constexpr (sizeof(T) == 2) {
-                bf16x8 fa[4], fb[4];
+        for (int s = 0; s < NSTAGE; ++s) {
+            if (k0 < kend) {
+                __syncthreads();
+                fa_.template commit<APRO>(sa[s], A, ta, lA, m0);
+                fb_.template commit<BPRO>(sb[s], B, tb, lB, n0);
+                __syncthreads();
+                if (k0 + NSTAGE * BK < kend) { fa_.issue(sa[s], A, k0 + NSTAGE * BK, kend); fb_.issue(sb[s], B, k0 + NSTAGE * BK, kend); }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i] = frag_bf16<AXC, LDA>((const bf16*)lA, wm * 64 + i * 16, kk, lane);
+                for (int kk = 0; kk < BK; kk += Cfg::KSTEP) {
+                    if constexpr (sizeof(T) == 2) {
+                        bf16x8 fa[TM], fb[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fb[j] = frag_bf16<BXC, LDB>((const bf16*)lB, wn * 64 + j * 16, kk, lane);
+                        for (int i = 0; i < TM; ++i) fa[i] = frag_bf16<AXC, LDA>((const bf16*)lA, wm * (16 * TM) + i * 16, kk, lane);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                        for (int j = 0; j < 4; ++j) fb[j] = frag_bf16<BXC, LDB>((const bf16*)lB, wn * 64 + j * 16, kk, lane);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-            } else {
-                float fa[4], fb[4];
+                        for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i] = frag_f32<AXC, LDA>((const float*)lA, wm * 64 + i * 16, kk, lane);
+                            for (int j = 0; j < 4; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    } else {
+                        float fa[TM], fb[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fb[j] = frag_f32<BXC, LDB>((const float*)lB, wn * 64 + j * 16, kk, lane);
+                        for (int i = 0; i < TM; ++i) fa[i] = frag_f32<AXC, LDA>((const float*)lA, wm * (16 * TM) + i * 16, kk, lane);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                        for (int j = 0; j < 4; ++j) fb[j] = frag_f32<BXC, LDB>((const float*)lB, wn * 64 + j * 16, kk, lane);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    }
+                }
+                k0 += BK;
             }
         }
     }
 
     // ------------------------------------------------------------------ epilogue
-    // lane holds rows m = .. + (lane & 15), columns n = .. + 4*(lane >> 4) + {0..3}
+    // lane holds rows m = .. + (lane & 15), columns n = .. + 4*(lane >> 4) + {0..3}.  Column vectors are fetched once per
+    // column group; full 4-column groups take the vector path, the ragged right edge a scalar one.
+    constexpr bool ATOMIC = AXC;            // the token-reduction (dW) form accumulates split-K partials
     const int li = lane & 15, lg = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const long m = m0 + wm * 64 + i * 16 + li;
-        if (m >= M) continue;
-        const long cbase = row_base(m, E.ldc, E.gw, E.gh, E.gc);
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + 4 * lg;
+        if (n >= N) continue;
+        const bool full = (n + 3 < N);
+        float cb[4] = {0.f, 0.f, 0.f, 0.f}, cs[4] = {1.f, 1.f, 1.f, 1.f}, ch[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + 4 * lg;
-            if (n >= N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            const bool full = (n + 3 < N);
+        for (int r = 0; r < 4; ++r) {
+            const int nn = min(n + r, N - 1);
+            if (E.bias) cb[r] = E.bias[nn];
+            if (E.colscale) { cs[r] = E.colscale[nn]; ch[r] = E.colshift[nn]; }
+        }
+        const long coff = col_off(n, E.seglen, E.segstride);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (n + r < N) {
-                    if (E.bias) v[r] += E.bias[n + r];
-                    if (E.colscale) v[r] = v[r] * E.colscale[n + r] + E.colshift[n + r];
-                }
-            }
-            if (E.aux_mode != BF_AUX_NONE) {
-                const T* aux = reinterpret_cast<const T*>(E.aux) + m * E.ld_aux + n;
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * (16 * TM) + i * 16 + li;
+            if (m >= M) continue;
+            float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (n + r < N) {
-                        const float a = to_f(aux[r]);
-                        v[r] = (E.aux_mode == BF_AUX_ADD) ? (v[r] + a) : (v[r] * dgelu_f(a));
-                    }
-                }
-            }
-            const long off = cbase + col_off(n, E.seglen, E.segstride);
-            if (E.out_mode == BF_OUT_ATOMIC_F32) {
+            for (int r = 0; r < 4; ++r) v[r] = (acc[i][j][r] + cb[r]) * cs[r] + ch[r];
+            const long off = row_base(m, E.ldc, E.gw, E.gh, E.gc) + coff;
+            if constexpr (ATOMIC) {
                 float* c = reinterpret_cast<float*>(E.c) + off;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (n + r < N) atomicAdd(c + r, v[r]);
-            } else if (E.out_mode == BF_OUT_STORE_F32) {
-                float* c = reinterpret_cast<float*>(E.c) + off;
-                if (full) *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-                else
-                    for (int r = 0; r < 4; ++r)
-                        if (n + r < N) c[r] = v[r];
             } else {
-                T* c = reinterpret_cast<T*>(E.c) + off;
-                if (full) {
-                    if constexpr (sizeof(T) == 2) {
-                        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                        *reinterpret_cast<bf16x4*>(c) = o;
+                if (E.aux_mode != BF_AUX_NONE) {
+                    const T* aux = reinterpret_cast<const T*>(E.aux) + (long)m * E.ld_aux + n;
+                    float a[4];
+                    if (full) {
+                        if constexpr (sizeof(T) == 2) { const bf16x4 t4 = *reinterpret_cast<const bf16x4*>(aux); a[0] = (float)t4[0]; a[1] = (float)t4[1]; a[2] = (float)t4[2]; a[3] = (float)t4[3]; }
+                        else { const float4 t4 = *reinterpret_cast<const float4*>(aux); a[0] = t4.x; a[1] = t4.y; a[2] = t4.z; a[3] = t4.w; }
                     } else {
-                        *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) a[r] = (n + r < N) ? to_f(aux[r]) : 0.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (E.aux_mode == BF_AUX_ADD) ? (v[r] + a[r]) : (v[r] * dgelu_f(a[r]));
+                }
+                if (E.out_mode == BF_OUT_STORE_F32) {
+                    float* c = reinterpret_cast<float*>(E.c) + off;
+                    if (full) *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n + r < N) c[r] = v[r];
                     }
                 } else {
-                    for (int r = 0; r < 4; ++r)
-                        if (n + r < N) c[r] = from_f<T>(v[r]);
+                    store4<T>(reinterpret_cast<T*>(E.c) + off, v, full, N - n);
+                    if (E.gelu_out) {     // second output: gelu(v) (the MLP hidden activation next to its pre-activation)
+                        const float u[4] = {gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
+                        store4<T>(reinterpret_cast<T*>(E.gelu_out) + off, u, full, N - n);
+                    }
                 }
             }
         }
@@ -285,13 +398,18 @@ int launch(int M, int N, int K, const bf_operand* A, const bf_operand* B, const 
     EpiDev e;
     e.bias = E->bias; e.colscale = E->colscale; e.colshift = E->colshift; e.aux_mode = E->aux_mode; e.aux = E->aux;
     e.ld_aux = E->ld_aux; e.out_mode = E->out_mode; e.c = E->c; e.ldc = E->ldc; e.seglen = E->seglen;
-    e.segstride = E->segstride; e.gw = E->gw; e.gh = E->gh; e.gc = E->gc;
+    e.segstride = E->segstride; e.gw = E->gw; e.gh = E->gh; e.gc = E->gc; e.gelu_out = E->gelu_out;
     if (splitk < 1) splitk = 1;
     int ktiles = bf_cdiv(K, BK);
     if (splitk > ktiles) splitk = ktiles;
     const int kper = bf_cdiv(ktiles, splitk) * BK;
     splitk = bf_cdiv(K, kper);
-    dim3 grid(bf_cdiv(M, BM), bf_cdiv(N, BN), splitk);
+    // 128 x 128 tiles unless that leaves the chip with fewer than two workgroups per CU: then 64 x 128
+    const int nt = bf_cdiv(N, BN);
+    const bool small = (long)bf_cdiv(M, 128) * nt * splitk < 512 && M > 64;
+    const int bm = small ? 64 : 128;
+    const int mt = bf_cdiv(M, bm);
+    dim3 grid((unsigned)((long)mt * nt * splitk));
     const bool ax = A->layout == BF_LAY_XC, bx = B->layout == BF_LAY_XC;
     const double es = sizeof(T);
     const char* pname = sizeof(T) == 2 ? (ax ? "gemm_bf16_dW(xc,xc)" : bx ? "gemm_bf16_dA(kc,xc)" : "gemm_bf16_fwd(kc,kc)")
@@ -300,8 +418,11 @@ int launch(int M, int N, int K, const bf_operand* A, const bf_operand* B, const 
                      (double)M * K * es + (double)N * K * es + (double)M * N * (E->out_mode == BF_OUT_STORE ? es : 4.0) +
                          (E->aux_mode != BF_AUX_NONE ? (double)M * N * es : 0.0));
     const bool ap = A->pro != BF_PRO_NONE, bp = B->pro != BF_PRO_NONE;
-#define BF_GEMM_GO(AX, BX, AP, BP) \
-    hipLaunchKernelGGL((gemm_kernel<T, AX, BX, AP, BP>), grid, dim3(NT), 0, st, M, N, K, a, b, e, kper)
+#define BF_GEMM_GO(AX, BX, AP, BP)                                                                                            \
+    do {                                                                                                                      \
+        if (small) hipLaunchKernelGGL((gemm_kernel<T, AX, BX, AP, BP, 3, 2>), grid, dim3(NT), 0, st, M, N, K, a, b, e, kper, mt, nt); \
+        else hipLaunchKernelGGL((gemm_kernel<T, AX, BX, AP, BP, 3, 4>), grid, dim3(NT), 0, st, M, N, K, a, b, e, kper, mt, nt);  \
+    } while (0)
     if (!ax && !bx && !bp) { if (ap) BF_GEMM_GO(false, false, true, false); else BF_GEMM_GO(false, false, false, false); }
     else if (!ax && bx && !bp) { if (ap) BF_GEMM_GO(false, true, true, false); else BF_GEMM_GO(false, true, false, false); }
     else if (ax && bx && !ap) { if (bp) BF_GEMM_GO(true, true, false, true); else BF_GEMM_GO(true, true, false, false); }
@@ -332,7 +453,9 @@ extern "C" int bf_gemm(int dtype, int M, int N, int K, const bf_operand* A, cons
                        "bf_gemm: affine prologue needs sc/sh, rows_per_frame and nch (multiple of the chunk)");
         }
     }
-    BF_REQUIRE(splitk <= 1 || E->out_mode == BF_OUT_ATOMIC_F32, "bf_gemm: split-K needs the atomic fp32 output mode");
+    BF_REQUIRE((A->layout == BF_LAY_XC) == (E->out_mode == BF_OUT_ATOMIC_F32),
+               "bf_gemm: the token-reduction form (A outer-contiguous) accumulates with fp32 atomics, the other forms store");
+    BF_REQUIRE((long)M < (1L << 31) && (long)N < (1L << 31) && (long)K < (1L << 31), "bf_gemm: extents must fit 31 bits");
     if (E->aux_mode != BF_AUX_NONE) BF_REQUIRE(E->aux != nullptr, "bf_gemm: aux pointer missing");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == BF_DTYPE_BF16) return launch<bf16>(M, N, K, A, B, E, splitk, st);

@@ -167,7 +167,7 @@ struct TemporalSaved {
 };
 struct SpatialSaved {
     float *mean1, *rstd1, *sc1, *sh1, *mean2, *rstd2, *sc2, *sh2, *mean3, *rstd3, *sc3, *sh3, *alpha, *beta, *mc;
-    void *qkv, *o, *x1, *pre, *z, *win_c, *wout_c, *w1_c, *w2_c;
+    void *qkv, *o, *x1, *pre, *hid, *z, *win_c, *wout_c, *w1_c, *w2_c;
     size_t bytes;
     SpatialSaved(const D& d, void* base) {
         Arena a(base);
@@ -180,6 +180,7 @@ struct SpatialSaved {
         o = a.take((size_t)d.N * d.E * d.es);
         x1 = a.take((size_t)d.N * d.E * d.es);
         pre = a.take((size_t)d.N * 4 * d.E * d.es);
+        hid = a.take((size_t)d.N * 4 * d.E * d.es);
         z = a.take((size_t)d.N * d.E * d.es);
         win_c = a.take((size_t)3 * d.E * d.E * d.es);
         wout_c = a.take((size_t)d.E * d.E * d.es);
@@ -376,16 +377,16 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
                        d.feat_scale ? p->low_freq_scalar : nullptr, d.feat_scale ? p->high_freq_scalar : nullptr, sv.alpha, sv.beta, sv.mc, d.E);
     BF_CHECK_LAUNCH();
     TRY(outproj_gemm(d, sv.o, sv.sc2, sv.sh2, wout_c, sv.alpha, sv.beta, x, sv.x1, st));
-    {   // pre = x1 @ W1^T + b1
+    {   // pre = x1 @ W1^T + b1 ; hid = gelu(pre) (both kept: pre for gelu', hid as the fc2 operand -- no erf in any prologue)
         bf_operand A = op_plain(sv.x1, d.E, BF_LAY_KC);
         bf_operand Bo = op_plain(w1_c, d.E, BF_LAY_KC);
         bf_epilogue e = epi_store(sv.pre, 4L * d.E);
         e.bias = p->fc1_b;
+        e.gelu_out = sv.hid;
         TRY(bf_gemm(d.dtype, (int)d.N, 4 * d.E, d.E, &A, &Bo, &e, 1, st));
     }
-    {   // z = gelu(pre) @ W2^T + b2
-        bf_operand A = op_plain(sv.pre, 4L * d.E, BF_LAY_KC);
-        A.pro = BF_PRO_GELU;
+    {   // z = hid @ W2^T + b2
+        bf_operand A = op_plain(sv.hid, 4L * d.E, BF_LAY_KC);
         bf_operand Bo = op_plain(w2_c, 4L * d.E, BF_LAY_KC);
         bf_epilogue e = epi_store(sv.z, d.E);
         e.bias = p->fc2_b;
@@ -420,7 +421,7 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     {
         bf_epilogue e; memset(&e, 0, sizeof(e));
         e.aux_mode = BF_AUX_DGELU; e.aux = sv.pre; e.ld_aux = 4L * d.E; e.out_mode = BF_OUT_STORE;
-        TRY(linear_bwd(d, sc, dz, d.E, sv.pre, 4 * d.E, BF_PRO_GELU, nullptr, nullptr, w2_c, g->fc2_w, g->fc2_b, dpre, &e, st));
+        TRY(linear_bwd(d, sc, dz, d.E, sv.hid, 4 * d.E, BF_PRO_NONE, nullptr, nullptr, w2_c, g->fc2_w, g->fc2_b, dpre, &e, st));
     }
     // fc1: pre = x1 @ W1^T + b1 ; dx1 = dout + dpre @ W1
     void* dx1 = sc.t1b;

@@ -209,28 +209,27 @@ __global__ void film_net_fwd_kernel(const float* __restrict__ cond, const float*
 __global__ void film_net_bwd_kernel(const float* __restrict__ dgb_, const float* __restrict__ chat, const float* __restrict__ lnw,
                                     const float* __restrict__ lnb, const float* __restrict__ W, float* __restrict__ dW,
                                     float* __restrict__ dbias, float* __restrict__ dlnw, float* __restrict__ dlnb, int B, int P, int E2) {
+    // one thread per output row o of the Linear: dW[o][:], dbias[o], and its share of dc[b][i] (atomics into dlnw/dlnb)
     const int E = E2 / 2;
-    auto DGB = [&](int b, int o) { return dgb_[(long)(o / E) * B * E + (long)b * E + (o % E)]; };   // [2][B][E]
-    for (int o = threadIdx.x; o < E2; o += blockDim.x) {
-        float sb = 0.f;
-        for (int b = 0; b < B; ++b) sb += DGB(b, o);
-        dbias[o] += sb;
-        for (int i = 0; i < P; ++i) {
-            float acc = 0.f;
-            for (int b = 0; b < B; ++b) acc += DGB(b, o) * (chat[b * P + i] * lnw[i] + lnb[i]);
-            dW[(long)o * P + i] += acc;
-        }
-    }
-    for (int i = threadIdx.x; i < P; i += blockDim.x) {
-        float sw = 0.f, sbias = 0.f;
+    const int o0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = o0 < E2;                 // no early return: the wave reductions below need every lane
+    const int o = valid ? o0 : 0;
+    float sb = 0.f;
+    for (int b = 0; b < B; ++b) sb += dgb_[(long)(o / E) * B * E + (long)b * E + (o % E)];
+    if (valid) dbias[o] += sb;
+    for (int i = 0; i < P; ++i) {
+        float acc = 0.f, sw = 0.f, sbias = 0.f;
+        const float w = W[(long)o * P + i];
         for (int b = 0; b < B; ++b) {
-            float dc = 0.f;
-            for (int o = 0; o < E2; ++o) dc += DGB(b, o) * W[(long)o * P + i];
-            sw += dc * chat[b * P + i];
-            sbias += dc;
+            const float dg = valid ? dgb_[(long)(o / E) * B * E + (long)b * E + (o % E)] : 0.f;
+            acc += dg * (chat[b * P + i] * lnw[i] + lnb[i]);
+            sw += dg * w * chat[b * P + i];
+            sbias += dg * w;
         }
-        dlnw[i] += sw;
-        dlnb[i] += sbias;
+        if (valid) dW[(long)o * P + i] += acc;
+        sw = wave_sum(sw);
+        sbias = wave_sum(sbias);
+        if ((threadIdx.x & 63) == 0) { atomicAdd(dlnw + i, sw); atomicAdd(dlnb + i, sbias); }
     }
 }
 
@@ -347,7 +346,7 @@ extern "C" int bf_film_net_fwd(const float* cond, const float* lnw, const float*
 extern "C" int bf_film_net_bwd(const float* dgb, const float* chat, const float* lnw, const float* lnb, const float* W, float* dW,
                                float* dbias, float* dlnw, float* dlnb, int B, int P, int E2, bf_stream_t stream) {
     BF_REQUIRE(dgb && chat && lnw && lnb && W && dW && dbias && dlnw && dlnb, "bf_film_net_bwd: bad arguments");
-    hipLaunchKernelGGL(film_net_bwd_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, dgb, chat, lnw, lnb, W, dW, dbias, dlnw, dlnb, B, P, E2);
+    hipLaunchKernelGGL(film_net_bwd_kernel, dim3(bf_cdiv(E2, 64)), dim3(64), 0, (hipStream_t)stream, dgb, chat, lnw, lnb, W, dW, dbias, dlnw, dlnb, B, P, E2);
     BF_CHECK_LAUNCH();
     return 0;
 }

@@ -81,6 +81,7 @@ typedef struct bf_epilogue {
     int32_t seglen;         /* output scatter (same addressing as bf_operand) */
     int64_t segstride;
     int32_t gw, gh, gc;
+    void* gelu_out;         /* optional second output (activation dtype, same addressing as c): gelu(value stored to c) */
 } bf_epilogue;
 
 /* C[M,N] (+)= epi( sum_k pro(A)[m,k] * pro(B)[n,k] ).  splitk > 1 requires BF_OUT_ATOMIC_F32. */
