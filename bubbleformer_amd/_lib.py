@@ -30,7 +30,7 @@ class Operand(C.Structure):
 class Epilogue(C.Structure):
     _fields_ = [("bias", fp), ("colscale", fp), ("colshift", fp), ("aux_mode", i32), ("aux", vp), ("ld_aux", i64),
                 ("out_mode", i32), ("c", vp), ("ldc", i64), ("seglen", i32), ("segstride", i64), ("gw", i32), ("gh", i32),
-                ("gc", i32), ("gelu_out", vp)]
+                ("gc", i32), ("gelu_out", vp), ("colsum", fp)]
 
 
 class Dims(C.Structure):

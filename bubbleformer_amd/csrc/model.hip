@@ -67,8 +67,10 @@ bf_epilogue epi_atomic(float* c, long ldc) { bf_epilogue e = epi_store(c, ldc); 
 void epi_scatter(bf_epilogue& e, int gw, int gh, int C) { e.gw = gw; e.gh = gh; e.gc = C; e.seglen = 2 * C; e.segstride = 2L * gw * C; }
 
 int splitk_for(int M, int N, long K) {
+    // measured (tools/dw_sweep.py): the split-K partials are added with fp32 atomics, so splits cost traffic; the best
+    // point is about one 64-row tile per CU, i.e. tiles(128 x 128) * splitk ~ 256
     const long tiles = (long)bf_cdiv(M, 128) * bf_cdiv(N, 128);
-    long s = (512 + tiles - 1) / tiles;                 // ~2 blocks per CU
+    long s = (256 + tiles / 2) / tiles;
     const long kt = (K + 63) / 64;
     if (s > kt / 4) s = kt / 4;                         // at least 4 K-steps per slice
     if (s < 1) s = 1;
@@ -261,9 +263,9 @@ int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* o, 
         bf_operand Bo = op_plain(o, d.E, BF_LAY_XC);
         op_affine(Bo, BF_PRO_AFFINE, sc2, sh2, d.S, d.E);
         bf_epilogue e = epi_atomic(sc.G, d.E);
+        e.colsum = sc.csum;                  // dbeta = colsum(dout), fused into the same pass over dout
         TRY(bf_gemm(d.dtype, d.E, d.E, (int)d.N, &A, &Bo, &e, splitk_for(d.E, d.E, d.N), st));
     }
-    TRY(bf_colsum(d.dtype, dout, d.N, d.E, nullptr, sc.csum, st));
     hipLaunchKernelGGL(outproj_finalize_kernel, dim3(d.E), dim3(256), 0, st, sc.G, sc.csum, W, bias, nb, gamma, lo, hi, mc, dW, dbias, dnb,
                        dgamma, dlo, dhi, d.E);
     BF_CHECK_LAUNCH();
@@ -284,9 +286,9 @@ int linear_bwd(const D& d, const Scratch& sc, const void* dy, int Nout, const vo
         bf_operand Bo = op_plain(x, Kin, BF_LAY_XC);
         if (xpro != BF_PRO_NONE) op_affine(Bo, xpro, xsc, xsh, d.S, Kin);
         bf_epilogue e = epi_atomic(dW, Kin);
+        e.colsum = db;                       // bias gradient = colsum(dy), fused into the same pass over dy
         TRY(bf_gemm(d.dtype, Nout, Kin, (int)d.N, &A, &Bo, &e, splitk_for(Nout, Kin, d.N), st));
     }
-    if (db) TRY(bf_colsum(d.dtype, dy, d.N, Nout, nullptr, db, st));
     {
         bf_operand A = op_plain(dy, Nout, BF_LAY_KC);
         bf_operand Bo = op_plain(w_c, Kin, BF_LAY_XC);

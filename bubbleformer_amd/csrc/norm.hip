@@ -41,7 +41,9 @@ __device__ __forceinline__ void reduce_rows(float (&v)[NV][Chunk<T>::N], float* 
 
 // ------------------------------------------------------------------------------------ stats
 // grid: (frames, ceil(C / 64)).  Two-pass (mean, then centred second moment) -- no E[x^2]-E[x]^2.
-template <typename T>
+constexpr int MAXR = 6;   // rows a thread may keep in registers (frames of up to RG * MAXR tokens are read from memory once)
+
+template <typename T, bool CACHED>
 __global__ void __launch_bounds__(NT) in_stats_kernel(const T* __restrict__ x, int S, int C, const float* __restrict__ w,
                                                      const float* __restrict__ b, const float* __restrict__ g, int gdiv,
                                                      const float* __restrict__ gb, float* __restrict__ mean,
@@ -56,24 +58,45 @@ __global__ void __launch_bounds__(NT) in_stats_kernel(const T* __restrict__ x, i
     float acc[1][CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) acc[0][j] = 0.f;
-    if (cv)
+    Chunk<T> keep[CACHED ? MAXR : 1];
+    if constexpr (CACHED) {
+#pragma unroll
+        for (int q = 0; q < MAXR; ++q) {
+            const int s = rg + RG * q;
+            if (cv && s < S) {
+                keep[q].load(xf + (long)s * C);
+#pragma unroll
+                for (int j = 0; j < CH; ++j) acc[0][j] += keep[q].get(j);
+            }
+        }
+    } else if (cv) {
         for (int s = rg; s < S; s += RG) {
             Chunk<T> v;
             v.load(xf + (long)s * C);
 #pragma unroll
             for (int j = 0; j < CH; ++j) acc[0][j] += v.get(j);
         }
+    }
     reduce_rows<T, 1>(acc, sm);
     float mu[CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) { mu[j] = acc[0][j] / (float)S; acc[0][j] = 0.f; }
-    if (cv)
+    if constexpr (CACHED) {
+#pragma unroll
+        for (int q = 0; q < MAXR; ++q) {
+            if (cv && rg + RG * q < S) {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) { const float d = keep[q].get(j) - mu[j]; acc[0][j] += d * d; }
+            }
+        }
+    } else if (cv) {
         for (int s = rg; s < S; s += RG) {
             Chunk<T> v;
             v.load(xf + (long)s * C);
 #pragma unroll
             for (int j = 0; j < CH; ++j) { const float d = v.get(j) - mu[j]; acc[0][j] += d * d; }
         }
+    }
     reduce_rows<T, 1>(acc, sm);
     if (cv && rg == 0) {
 #pragma unroll
@@ -129,7 +152,7 @@ __global__ void __launch_bounds__(NT) affine_apply_kernel(const T* __restrict__ 
 // Given dy: s1 = sum_s dyn, s2 = sum_s dyn * xhat  (dyn = dy * act'),  per (frame, channel)
 //   dx = rstd * w * g * (dyn - s1/S - xhat * s2/S) [+ add]
 //   dw += g * s2, db += g * s1, dg += w * s2 + b * s1, dgb += s1     (fp32 atomics over frames)
-template <typename T, bool GELU>
+template <typename T, bool GELU, bool CACHED>
 __global__ void __launch_bounds__(NT) in_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ add,
                                                    T* __restrict__ dx, int S, int C, const float* __restrict__ mean,
                                                    const float* __restrict__ rstd, const float* __restrict__ w,
@@ -155,38 +178,61 @@ __global__ void __launch_bounds__(NT) in_bwd_kernel(const T* __restrict__ dy, co
     float acc[2][CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) acc[0][j] = acc[1][j] = 0.f;
-    if (cv)
+    // a (frame, 64-channel) slab of up to RG * MAXR tokens is held in registers between the reduction and the apply pass
+    Chunk<T> kd[CACHED ? MAXR : 1], kx[CACHED ? MAXR : 1];
+    auto accumulate = [&](const Chunk<T>& d, const Chunk<T>& v) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const float xh = (v.get(j) - mu[j]) * rs[j];
+            float dd = d.get(j);
+            if (GELU) dd *= dgelu_f(xh * ww[j] + bb[j]);
+            acc[0][j] += dd;
+            acc[1][j] += dd * xh;
+        }
+    };
+    auto apply = [&](const Chunk<T>& d, const Chunk<T>& v, long off) {
+        Chunk<T> a, o;
+        if (add) a.load(add + off);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const float xh = (v.get(j) - mu[j]) * rs[j];
+            float dd = d.get(j);
+            if (GELU) dd *= dgelu_f(xh * ww[j] + bb[j]);
+            float t = rs[j] * ww[j] * gg[j] * (dd - (acc[0][j] + xh * acc[1][j]) / (float)S);
+            if (add) t += a.get(j);
+            o.set(j, t);
+        }
+        o.store(dx + off);
+    };
+    if constexpr (CACHED) {
+#pragma unroll
+        for (int q = 0; q < MAXR; ++q) {
+            const int s = rg + RG * q;
+            if (cv && s < S) { kd[q].load(dy + base + (long)s * C); kx[q].load(x + base + (long)s * C); accumulate(kd[q], kx[q]); }
+        }
+    } else if (cv) {
         for (int s = rg; s < S; s += RG) {
             Chunk<T> d, v;
             d.load(dy + base + (long)s * C);
             v.load(x + base + (long)s * C);
-#pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                const float xh = (v.get(j) - mu[j]) * rs[j];
-                float dd = d.get(j);
-                if (GELU) dd *= dgelu_f(xh * ww[j] + bb[j]);
-                acc[0][j] += dd;
-                acc[1][j] += dd * xh;
-            }
+            accumulate(d, v);
         }
+    }
     reduce_rows<T, 2>(acc, sm);
-    if (cv)
+    if constexpr (CACHED) {
+#pragma unroll
+        for (int q = 0; q < MAXR; ++q) {
+            const int s = rg + RG * q;
+            if (cv && s < S) apply(kd[q], kx[q], base + (long)s * C);
+        }
+    } else if (cv) {
         for (int s = rg; s < S; s += RG) {
-            Chunk<T> d, v, a, o;
+            Chunk<T> d, v;
             d.load(dy + base + (long)s * C);
             v.load(x + base + (long)s * C);
-            if (add) a.load(add + base + (long)s * C);
-#pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                const float xh = (v.get(j) - mu[j]) * rs[j];
-                float dd = d.get(j);
-                if (GELU) dd *= dgelu_f(xh * ww[j] + bb[j]);
-                float t = rs[j] * ww[j] * gg[j] * (dd - (acc[0][j] + xh * acc[1][j]) / (float)S);
-                if (add) t += a.get(j);
-                o.set(j, t);
-            }
-            o.store(dx + base + (long)s * C);
+            apply(d, v, base + (long)s * C);
         }
+    }
     if (cv && rg == 0) {
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
@@ -242,10 +288,12 @@ extern "C" int bf_in_stats(int dtype, const void* x, int frames, int S, int C, c
     BfProfScope prof((hipStream_t)stream, "in_stats", 0.0, (double)frames * S * C * bf_esize(dtype));
     if (dtype == BF_DTYPE_BF16) {
         BF_REQUIRE(chunk_ok<bf16>(C), "bf_in_stats: C must be a multiple of 8 (bf16)");
-        hipLaunchKernelGGL(in_stats_kernel<bf16>, grid, dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh);
+        if (S <= Geo<bf16>::RG * MAXR) hipLaunchKernelGGL((in_stats_kernel<bf16, true>), grid, dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh);
+        else hipLaunchKernelGGL((in_stats_kernel<bf16, false>), grid, dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh);
     } else {
         BF_REQUIRE(chunk_ok<float>(C), "bf_in_stats: C must be a multiple of 4 (f32)");
-        hipLaunchKernelGGL(in_stats_kernel<float>, grid, dim3(NT), 0, (hipStream_t)stream, (const float*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh);
+        if (S <= Geo<float>::RG * MAXR) hipLaunchKernelGGL((in_stats_kernel<float, true>), grid, dim3(NT), 0, (hipStream_t)stream, (const float*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh);
+        else hipLaunchKernelGGL((in_stats_kernel<float, false>), grid, dim3(NT), 0, (hipStream_t)stream, (const float*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh);
     }
     BF_CHECK_LAUNCH();
     return 0;
@@ -277,7 +325,11 @@ extern "C" int bf_in_bwd(int dtype, const void* dy, const void* x, const void* a
     if (gdiv < 1) gdiv = 1;
     hipStream_t st = (hipStream_t)stream;
     BfProfScope prof(st, "in_bwd", 0.0, (double)frames * S * C * bf_esize(dtype) * (add ? 4.0 : 3.0));
-#define GO(T, G) hipLaunchKernelGGL((in_bwd_kernel<T, G>), grid, dim3(NT), 0, st, (const T*)dy, (const T*)x, (const T*)add, (T*)dx, S, C, mean, rstd, w, b, g, gdiv, dw, db, dg, dgb)
+#define GO(T, G)                                                                                                                         \
+    do {                                                                                                                                  \
+        if (S <= Geo<T>::RG * MAXR) hipLaunchKernelGGL((in_bwd_kernel<T, G, true>), grid, dim3(NT), 0, st, (const T*)dy, (const T*)x, (const T*)add, (T*)dx, S, C, mean, rstd, w, b, g, gdiv, dw, db, dg, dgb); \
+        else hipLaunchKernelGGL((in_bwd_kernel<T, G, false>), grid, dim3(NT), 0, st, (const T*)dy, (const T*)x, (const T*)add, (T*)dx, S, C, mean, rstd, w, b, g, gdiv, dw, db, dg, dgb); \
+    } while (0)
     if (dtype == BF_DTYPE_BF16) { if (gelu) GO(bf16, true); else GO(bf16, false); }
     else { if (gelu) GO(float, true); else GO(float, false); }
 #undef GO

@@ -82,6 +82,7 @@ typedef struct bf_epilogue {
     int64_t segstride;
     int32_t gw, gh, gc;
     void* gelu_out;         /* optional second output (activation dtype, same addressing as c): gelu(value stored to c) */
+    float* colsum;          /* token-reduction form only (A outer-contiguous): colsum[m] += sum_k A[k][m] (bias gradient) */
 } bf_epilogue;
 
 /* C[M,N] (+)= epi( sum_k pro(A)[m,k] * pro(B)[n,k] ).  splitk > 1 requires BF_OUT_ATOMIC_F32. */
