@@ -194,7 +194,7 @@ struct SpatialSaved {
 
 // transient scratch (backward is the larger user)
 struct Scratch {
-    float *G, *csum, *zeros, *ones, *wg, *attn_ws;   // wg: prepared-layout weight gradient scratch
+    float *G, *csum, *zeros, *ones, *wg, *attn_ws, *in_ws;   // wg: prepared-layout weight gradient scratch
     static constexpr long ATTN_WS_FLOATS = 1024L * (4 * 128 + 32 * 16 + 16);
     void *t1, *t3, *t4, *t1b;
     size_t bytes;
@@ -210,6 +210,7 @@ struct Scratch {
         ones = a.f32((size_t)4 * d.E);
         wg = a.f32(wgn);
         attn_ws = a.f32(ATTN_WS_FLOATS);
+        in_ws = a.f32((size_t)2 * d.F * d.E);
         // activation-sized transients; embed/debed stages work at up to (patch/2)^2 * N pixels of E/4 (or cin/cout) channels
         size_t tok = (size_t)d.N * d.E;
         size_t big = tok * 4;
@@ -344,14 +345,14 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
     TRY(outproj_bwd(d, sc, dout, sv.o, sv.sc2, sv.sh2, wout_c, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr,
                     sv.alpha, sv.mc, g->output_head_w, g->output_head_b, nullptr, g->gamma, nullptr, nullptr, don, st));
     TRY(bf_in_bwd(d.dtype, don, sv.o, nullptr, dO, (int)d.F, (int)d.S, d.E, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, nullptr, 1, 0,
-                  g->norm2_w, g->norm2_b, nullptr, nullptr, st));
+                  g->norm2_w, g->norm2_b, nullptr, nullptr, sc.in_ws, st));
     TRY(bf_attn_bwd(d.dtype, sv.qkv, dO, dqkv, (long)d.B * d.S, d.T, d.S, (long)d.T * d.S, 1, d.S, d.heads, d.d, p->qnorm_w, p->qnorm_b,
                     p->knorm_w, p->knorm_b, p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor : nullptr, g->qnorm_w, g->qnorm_b,
                     g->knorm_w, g->knorm_b, g->rel_pos_emb, d.attn_scale ? g->attn_scale_factor : nullptr, 1.f, 0, sc.attn_ws, Scratch::ATTN_WS_FLOATS, st));
     void* dxn = sc.t1;      // don is dead
     TRY(linear_bwd(d, sc, dqkv, 3 * d.E, x, d.E, BF_PRO_AFFINE, sv.sc1, sv.sh1, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st));
     TRY(bf_in_bwd(d.dtype, dxn, x, dout, dx, (int)d.F, (int)d.S, d.E, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, nullptr, 1, 0,
-                  g->norm1_w, g->norm1_b, nullptr, nullptr, st));
+                  g->norm1_w, g->norm1_b, nullptr, nullptr, sc.in_ws, st));
     return 0;
 }
 
@@ -417,7 +418,7 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     // out = x1 + gamma_mlp * IN(z)
     void* dz = sc.t1;
     TRY(bf_in_bwd(d.dtype, dout, sv.z, nullptr, dz, (int)d.F, (int)d.S, d.E, sv.mean3, sv.rstd3, p->mlp_norm_w, p->mlp_norm_b, p->gamma_mlp,
-                  (int)d.F, 0, g->mlp_norm_w, g->mlp_norm_b, g->gamma_mlp, nullptr, st));
+                  (int)d.F, 0, g->mlp_norm_w, g->mlp_norm_b, g->gamma_mlp, nullptr, sc.in_ws, st));
     // fc2: z = gelu(pre) @ W2^T + b2 ; dpre = (dz @ W2) * gelu'(pre)
     void* dpre = sc.t4;
     {
@@ -440,7 +441,7 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
                     d.feat_scale ? g->high_freq_scalar : nullptr, don, st));
     void* dO = sc.t4;       // dpre is dead; [N][E]
     TRY(bf_in_bwd(d.dtype, don, sv.o, nullptr, dO, (int)d.F, (int)d.S, d.E, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, nullptr, 1, 0,
-                  g->norm2_w, g->norm2_b, nullptr, nullptr, st));
+                  g->norm2_w, g->norm2_b, nullptr, nullptr, sc.in_ws, st));
     void* dqkv = sc.t3;
     TRY(bf_attn_bwd(d.dtype, sv.qkv, dO, dqkv, d.F * d.h, d.w, 1, d.w, 0, 1, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
                     p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_x : nullptr, g->qnorm_w, g->qnorm_b, g->knorm_w, g->knorm_b,
@@ -451,7 +452,7 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     void* dxn = sc.t1;      // don is dead
     TRY(linear_bwd(d, sc, dqkv, 3 * d.E, x, d.E, BF_PRO_AFFINE, sv.sc1, sv.sh1, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st));
     TRY(bf_in_bwd(d.dtype, dxn, x, dx1, dx, (int)d.F, (int)d.S, d.E, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, nullptr, 1, 0,
-                  g->norm1_w, g->norm1_b, nullptr, nullptr, st));
+                  g->norm1_w, g->norm1_b, nullptr, nullptr, sc.in_ws, st));
     return 0;
 }
 
@@ -574,7 +575,7 @@ extern "C" int bf_embed_bwd(const bf_dims* dims, const bf_embed_params* p, const
     void* dy = buf(n - 1);
     TRY(bf_in_bwd(d.dtype, dout, sv.y[n - 1], nullptr, dy, (int)d.F, sv.gh[n - 1] * sv.gw[n - 1], sv.C[n - 1], sv.mean[n - 1], sv.rstd[n - 1],
                   p->in_w[n - 1], p->in_b[n - 1], film ? sv.gb : nullptr, d.T, 0, g->in_w[n - 1], g->in_b[n - 1], film ? sv.dgb : nullptr,
-                  film ? sv.dgb + (size_t)d.B * d.E : nullptr, st));
+                  film ? sv.dgb + (size_t)d.B * d.E : nullptr, sc.in_ws, st));
     if (film)
         TRY(bf_film_net_bwd(sv.dgb, sv.chat, p->film_ln_w, p->film_ln_b, p->film_w, g->film_w, g->film_b, g->film_ln_w, g->film_ln_b, d.B,
                             d.nfluid, 2 * d.E, st));
@@ -600,7 +601,7 @@ extern "C" int bf_embed_bwd(const bf_dims* dims, const bf_embed_params* p, const
             TRY(bf_gemm(d.dtype, (int)sv.P[i], K4, sv.C[i], &A, &Bo, &e, 1, st));
         }
         TRY(bf_in_bwd(d.dtype, dact, sv.y[i - 1], nullptr, dact, (int)d.F, sv.gh[i - 1] * sv.gw[i - 1], cp, sv.mean[i - 1], sv.rstd[i - 1],
-                      p->in_w[i - 1], p->in_b[i - 1], nullptr, 1, 1, g->in_w[i - 1], g->in_b[i - 1], nullptr, nullptr, st));
+                      p->in_w[i - 1], p->in_b[i - 1], nullptr, 1, 1, g->in_w[i - 1], g->in_b[i - 1], nullptr, nullptr, sc.in_ws, st));
         dy = dact;
     }
     {   // stage 0
@@ -718,7 +719,7 @@ extern "C" int bf_debed_bwd(const bf_dims* dims, const bf_debed_params* p, const
         }
         if (i > 0) {
             TRY(bf_in_bwd(d.dtype, dact, sv.y[i - 1], nullptr, dact, (int)d.F, (int)rpf, cin, sv.mean[i - 1], sv.rstd[i - 1], p->in_w[i - 1],
-                          p->in_b[i - 1], nullptr, 1, 1, g->in_w[i - 1], g->in_b[i - 1], nullptr, nullptr, st));
+                          p->in_b[i - 1], nullptr, 1, 1, g->in_w[i - 1], g->in_b[i - 1], nullptr, nullptr, sc.in_ws, st));
             dy = dact;
         }
     }

@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(NT) in_bwd_kernel(const T* __restrict__ dy, co
                                                    const float* __restrict__ rstd, const float* __restrict__ w,
                                                    const float* __restrict__ b, const float* __restrict__ g, int gdiv,
                                                    float* __restrict__ dw, float* __restrict__ db, float* __restrict__ dg,
-                                                   float* __restrict__ dgb) {
+                                                   float* __restrict__ dgb, float* __restrict__ ws) {
     constexpr int CH = Chunk<T>::N, LC = Geo<T>::LC, RG = Geo<T>::RG;
     __shared__ float sm[NT * CH];
     const int f = blockIdx.x, c0 = blockIdx.y * CPB;
@@ -233,7 +233,13 @@ __global__ void __launch_bounds__(NT) in_bwd_kernel(const T* __restrict__ dy, co
             apply(d, v, base + (long)s * C);
         }
     }
-    if (cv && rg == 0) {
+    if (cv && rg == 0 && ws) {          // per-frame partials; in_param_reduce_kernel sums them (no same-address atomics)
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            ws[((long)f * C + c + j) * 2] = acc[0][j];
+            ws[((long)f * C + c + j) * 2 + 1] = acc[1][j];
+        }
+    } else if (cv && rg == 0) {
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             if (dw) atomicAdd(dw + c + j, gg[j] * acc[1][j]);
@@ -241,6 +247,47 @@ __global__ void __launch_bounds__(NT) in_bwd_kernel(const T* __restrict__ dy, co
             if (dg) atomicAdd(dg + (long)(f / gdiv) * C + c + j, ww[j] * acc[1][j] + bb[j] * acc[0][j]);
             if (dgb) atomicAdd(dgb + (long)(f / gdiv) * C + c + j, acc[0][j]);
         }
+    }
+}
+
+// parameter gradients from the per-frame partials ws[f][c] = {s1, s2}:  grid (ceil(C/64)), block 256 = 64 channels x 4 frame lanes
+__global__ void __launch_bounds__(NT) in_param_reduce_kernel(const float* __restrict__ ws, int frames, int C, const float* __restrict__ w,
+                                                            const float* __restrict__ b, const float* __restrict__ g, int gdiv,
+                                                            float* __restrict__ dw, float* __restrict__ db, float* __restrict__ dg,
+                                                            float* __restrict__ dgb) {
+    __shared__ float red[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), fl = threadIdx.x >> 6;
+    const bool cv = c < C;
+    float aw = 0.f, ab = 0.f;
+    // dg / dgb are per frame GROUP: walk the groups, each of the 4 frame lanes takes a strided share of a group's frames
+    const int ngroups = (frames + gdiv - 1) / gdiv;
+    for (int fg = 0; fg < ngroups; ++fg) {
+        float s1 = 0.f, s2 = 0.f;
+        const int f1 = min(frames, (fg + 1) * gdiv);
+        if (cv)
+            for (int f = fg * gdiv + fl; f < f1; f += 4) { s1 += ws[((long)f * C + c) * 2]; s2 += ws[((long)f * C + c) * 2 + 1]; }
+        const float gg = (cv && g) ? g[(long)fg * C + c] : 1.f;
+        aw += gg * s2; ab += gg * s1;
+        if (dg || dgb) {
+            __syncthreads();
+            red[0][fl][threadIdx.x & 63] = s1; red[1][fl][threadIdx.x & 63] = s2;
+            __syncthreads();
+            if (fl == 0 && cv) {
+                const int l = threadIdx.x;
+                const float t1 = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
+                const float t2 = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+                if (dg) dg[(long)fg * C + c] += w[c] * t2 + b[c] * t1;
+                if (dgb) dgb[(long)fg * C + c] += t1;
+            }
+        }
+    }
+    __syncthreads();
+    red[0][fl][threadIdx.x & 63] = ab; red[1][fl][threadIdx.x & 63] = aw;
+    __syncthreads();
+    if (fl == 0 && cv) {
+        const int l = threadIdx.x;
+        if (db) db[c] += red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
+        if (dw) dw[c] += red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
     }
 }
 
@@ -317,7 +364,7 @@ extern "C" int bf_affine_apply(int dtype, const void* z, const void* resid, cons
 
 extern "C" int bf_in_bwd(int dtype, const void* dy, const void* x, const void* add, void* dx, int frames, int S, int C,
                          const float* mean, const float* rstd, const float* w, const float* b, const float* g, int gdiv,
-                         int gelu, float* dw, float* db, float* dg, float* dgb, bf_stream_t stream) {
+                         int gelu, float* dw, float* db, float* dg, float* dgb, float* ws, bf_stream_t stream) {
     BF_REQUIRE(dy && x && dx && mean && rstd && w && b, "bf_in_bwd: null pointer");
     const int ch = dtype == BF_DTYPE_BF16 ? 8 : 4;
     BF_REQUIRE(C % ch == 0, "bf_in_bwd: C must be a multiple of the 16-byte chunk");
@@ -327,13 +374,18 @@ extern "C" int bf_in_bwd(int dtype, const void* dy, const void* x, const void* a
     BfProfScope prof(st, "in_bwd", 0.0, (double)frames * S * C * bf_esize(dtype) * (add ? 4.0 : 3.0));
 #define GO(T, G)                                                                                                                         \
     do {                                                                                                                                  \
-        if (S <= Geo<T>::RG * MAXR) hipLaunchKernelGGL((in_bwd_kernel<T, G, true>), grid, dim3(NT), 0, st, (const T*)dy, (const T*)x, (const T*)add, (T*)dx, S, C, mean, rstd, w, b, g, gdiv, dw, db, dg, dgb); \
-        else hipLaunchKernelGGL((in_bwd_kernel<T, G, false>), grid, dim3(NT), 0, st, (const T*)dy, (const T*)x, (const T*)add, (T*)dx, S, C, mean, rstd, w, b, g, gdiv, dw, db, dg, dgb); \
+        if (S <= Geo<T>::RG * MAXR) hipLaunchKernelGGL((in_bwd_kernel<T, G, true>), grid, dim3(NT), 0, st, (const T*)dy, (const T*)x, (const T*)add, (T*)dx, S, C, mean, rstd, w, b, g, gdiv, dw, db, dg, dgb, ws); \
+        else hipLaunchKernelGGL((in_bwd_kernel<T, G, false>), grid, dim3(NT), 0, st, (const T*)dy, (const T*)x, (const T*)add, (T*)dx, S, C, mean, rstd, w, b, g, gdiv, dw, db, dg, dgb, ws); \
     } while (0)
     if (dtype == BF_DTYPE_BF16) { if (gelu) GO(bf16, true); else GO(bf16, false); }
     else { if (gelu) GO(float, true); else GO(float, false); }
 #undef GO
     BF_CHECK_LAUNCH();
+    if (ws) {
+        const int rdiv = (!g && !dg && !dgb) ? frames : gdiv;      // no per-group outputs: one group, all four frame lanes busy
+        hipLaunchKernelGGL(in_param_reduce_kernel, dim3(bf_cdiv(C, 64)), dim3(NT), 0, st, (const float*)ws, frames, C, w, b, g, rdiv, dw, db, dg, dgb);
+        BF_CHECK_LAUNCH();
+    }
     return 0;
 }
 

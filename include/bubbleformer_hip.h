@@ -102,7 +102,8 @@ int bf_affine_apply(int dtype, const void* z, const void* resid, const float* sc
 /* backward of y = act(xhat*w + b) [*g]; dx = ... [+ add]; dw/db/dg/dgb accumulate (fp32 atomics) */
 int bf_in_bwd(int dtype, const void* dy, const void* x, const void* add, void* dx, int frames, int S, int C, const float* mean,
               const float* rstd, const float* w, const float* b, const float* g, int gdiv, int gelu, float* dw, float* db,
-              float* dg, float* dgb, bf_stream_t stream);
+              float* dg, float* dgb, float* ws /* optional 2*frames*C floats: per-frame partials + reduce instead of atomics */,
+              bf_stream_t stream);
 /* out[c] += scale[c] * sum_rows x[row][c] */
 int bf_colsum(int dtype, const void* x, int64_t nrows, int C, const float* scale, float* out, bf_stream_t stream);
 
