@@ -144,28 +144,30 @@ def main():
     n = h.bf_prof_report(buf, len(buf))
     h.bf_prof_enable(0)
     prof = json.loads(buf.value.decode()) if n > 0 else {}
-    families = {}
-    for k, v in prof.items():
-        fam = k.split("(")[0]
-        a = families.setdefault(fam, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
-        for f in a:
-            a[f] += v[f]
     roofline = None
-    if families:
-        name, dom = max(families.items(), key=lambda kv: kv[1]["ms"])
+    if prof:
+        tot_ms = sum(v["ms"] for v in prof.values())
+        name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])          # dominant kernel = largest share of GPU time
         avg_ms = dom["ms"] / dom["calls"]
-        if name.startswith("gemm"):
-            ach = dom["flops"] / dom["calls"] / (avg_ms * 1e-3) / 1e12
-            peak = PEAK_MFMA_TFLOPS[args.dtype]
-            roofline = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                        "avg_launch_ms": avg_ms, "launches_per_step": dom["calls"] / nprof,
-                        "achieved_algorithmic_GBs": dom["bytes"] / dom["calls"] / (avg_ms * 1e-3) / 1e9}
+        flops, nbytes = dom["flops"] / dom["calls"], dom["bytes"] / dom["calls"]    # ALGORITHMIC work per launch
+        peak_tf = PEAK_MFMA_TFLOPS[args.dtype]
+        ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
+        tflops = flops / (avg_ms * 1e-3) / 1e12
+        gbs = nbytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "r01_kernels.json")          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
+        if os.path.exists(tpath):
+            for k in json.load(open(tpath))["kernels"]:
+                if k["kernel"] == name and "hbm_bytes_per_launch" in k:
+                    traffic = k["hbm_bytes_per_launch"]
+        if flops > 0 and flops / max(nbytes, 1.0) >= ridge:
+            roofline = {"kernel": name, "bound": "mfma", "achieved": tflops, "peak": peak_tf, "unit": "TFLOP/s", "frac": tflops / peak_tf}
         else:
-            ach = dom["bytes"] / dom["calls"] / (avg_ms * 1e-3) / 1e9
-            roofline = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
-                        "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": dom["calls"] / nprof}
-        roofline["kernel_time_share"] = {k: round(v["ms"] / sum(f["ms"] for f in families.values()), 4) for k, v in
-                                         sorted(families.items(), key=lambda kv: -kv[1]["ms"])}
+            roofline = {"kernel": name, "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS}
+        roofline.update({"traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": dom["calls"] / nprof,
+                         "algorithmic_bytes_per_launch": nbytes, "algorithmic_flops_per_launch": flops, "tflops": tflops,
+                         "mfma_frac": tflops / peak_tf, "share_of_gpu_time": dom["ms"] / tot_ms,
+                         "kernel_time_share": {k: round(v["ms"] / tot_ms, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:12]}})
 
     if rank != 0:
         if world > 1:

@@ -21,7 +21,7 @@ extern "C" int bf_abi_version(void) { return 1; }
 #include <string>
 #include <vector>
 namespace {
-struct Rec { hipEvent_t a, b; const char* name; double flops, bytes; };
+struct Rec { hipEvent_t a, b; std::string name; double flops, bytes; };
 bool g_prof_on = false;
 std::vector<Rec> g_recs;
 }
@@ -48,7 +48,7 @@ extern "C" int bf_prof_report(char* buf, int n) {
     struct Agg { long calls = 0; double ms = 0, flops = 0, bytes = 0; };
     std::map<std::string, Agg> agg;
     for (auto& r : g_recs) {
-        if (!r.name) continue;
+        if (r.name.empty()) continue;
         if (hipEventSynchronize(r.b) != hipSuccess) return -1;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return -1;

@@ -15,6 +15,7 @@
 // consecutive output COLUMNS of one row: 8-/16-byte epilogue stores and vector bias loads.
 // XC (outer-contiguous) bf16 tiles are read with the gfx950 transposing LDS read (ds_read_b64_tr_b16).
 #include "gemm_common.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace {
@@ -322,8 +323,10 @@ int launch(int M, int N, int K, const bf_operand* A, const bf_operand* B, const 
     dim3 grid((unsigned)((long)mt * nt * splitk));
     const bool ax = A->layout == BF_LAY_XC, bx = B->layout == BF_LAY_XC;
     const double es = sizeof(T);
-    const char* pname = sizeof(T) == 2 ? (ax ? "gemm_bf16_dW(xc,xc)" : bx ? "gemm_bf16_dA(kc,xc)" : "gemm_bf16_fwd(kc,kc)")
-                                       : (ax ? "gemm_f32_dW(xc,xc)" : bx ? "gemm_f32_dA(kc,xc)" : "gemm_f32_fwd(kc,kc)");
+    // one profiler name per kernel instantiation, so bench.py's per-kernel averages line up 1:1 with rocprofv3's rows
+    static thread_local char pname[96];
+    snprintf(pname, sizeof(pname), "gemm_kernel<%s,%s,%s,pro%s,tm%d>", sizeof(T) == 2 ? "bf16" : "f32", ax ? "xc" : "kc", bx ? "xc" : "kc",
+             A->pro != BF_PRO_NONE ? "A" : B->pro != BF_PRO_NONE ? "B" : "0", small ? 2 : 4);
     BfProfScope prof(st, pname, 2.0 * M * N * K,
                      (double)M * K * es + (double)N * K * es + (double)M * N * (E->out_mode == BF_OUT_STORE ? es : 4.0) +
                          (E->aux_mode != BF_AUX_NONE ? (double)M * N * es : 0.0));

@@ -11,6 +11,7 @@
 //   waves 2 (M) x 4 (N); wave tile (16 TM) x 96 = TM x 6 MFMA 16x16x32 tiles; BK = 64.
 // Same operand / prologue / epilogue contract as gemm.hip (plain rows only: no k2s2 gather or scatter here).
 #include "gemm_common.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace {
@@ -250,7 +251,8 @@ int bf_gemm_wide_try(int M, int N, int K, const bf_operand* A, const bf_operand*
     const int nt = bf_cdiv(N, BNW);
     const int tm = ((long)bf_cdiv(M, 128) * nt * splitk >= 224 || M <= 64) ? 4 : 2;   // keep ~one workgroup per CU
     const double es = 2.0;
-    const char* pname = ax ? "gemm_bf16_dW(xc,xc)" : bx ? "gemm_bf16_dA(kc,xc)" : "gemm_bf16_fwd(kc,kc)";
+    static thread_local char pname[96];
+    snprintf(pname, sizeof(pname), "gemm_wide_kernel<bf16,%s,%s,pro%s,tm%d>", ax ? "xc" : "kc", bx ? "xc" : "kc", ap ? "A" : bp ? "B" : "0", tm);
     BfProfScope prof(st, pname, 2.0 * M * N * K,
                      (double)M * K * es + (double)N * K * es + (double)M * N * (E->out_mode == BF_OUT_STORE ? es : 4.0) +
                          (E->aux_mode != BF_AUX_NONE ? (double)M * N * es : 0.0));
