@@ -20,7 +20,11 @@
 
 namespace {
 
-constexpr int BN = 128, NT = 256;
+constexpr int BN = 128;      // block tile columns; rows BM = 32 * TM; waves 2 x (NT / 128): NT = 256 -> 2 x 2 waves of TM x 4 MFMA tiles,
+                             // NT = 512 -> 2 x 4 waves of TM x 2 tiles (half the accumulators per wave, twice the waves per CU)
+#ifndef BF_GEMM_DEFAULT_WAVES
+#define BF_GEMM_DEFAULT_WAVES 4
+#endif
 #ifndef BF_GEMM_DEFAULT_STAGES
 #define BF_GEMM_DEFAULT_STAGES 1
 #endif
@@ -37,7 +41,7 @@ using namespace bfgemm;
 // XC: rows = k (advance per K-tile), cols = outer index (fixed for the block).
 // The fixed half of every chunk address is computed once (setup); issue() adds the moving half and puts the 16-byte
 // loads in flight; commit() (later) applies the prologue and writes LDS.  32-bit index math throughout.
-template <typename T, int TR, int TC, int LDT, bool XC>
+template <typename T, int TR, int TC, int LDT, bool XC, int NT>
 struct Stager {
     static constexpr int CH = Chunk<T>::N;
     static constexpr int CPR = TC / CH;
@@ -47,7 +51,7 @@ struct Stager {
     unsigned valid;
     int k0;
 };
-template <typename T, int TR, int TC, int LDT, bool XC>
+template <typename T, int TR, int TC, int LDT, bool XC, int NT>
 struct StagerFixed {
     static constexpr int CH = Chunk<T>::N;
     static constexpr int CPR = TC / CH;
@@ -88,7 +92,7 @@ struct StagerFixed {
             for (int i = 0; i < NCH; ++i) voff[i] = (long)(r0 + RSTEP * i) * op.ld + gfix[0];
         }
     }
-    __device__ __forceinline__ void issue(Stager<T, TR, TC, LDT, XC>& s, const OpDev& op, int k0, int kend) const {
+    __device__ __forceinline__ void issue(Stager<T, TR, TC, LDT, XC, NT>& s, const OpDev& op, int k0, int kend) const {
         s.k0 = k0; s.valid = 0u;
         if constexpr (!XC) {
             const bool cv = k0 + cc < kend;
@@ -129,7 +133,7 @@ struct StagerFixed {
         }
     }
     template <bool PRO>
-    __device__ __forceinline__ void commit(Stager<T, TR, TC, LDT, XC>& s, const OpDev& op, const ProTab& tab, T* lds, int outer0) const {
+    __device__ __forceinline__ void commit(Stager<T, TR, TC, LDT, XC, NT>& s, const OpDev& op, const ProTab& tab, T* lds, int outer0) const {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             if (PRO && op.pro != BF_PRO_NONE && ((s.valid >> i) & 1u)) {
@@ -161,11 +165,12 @@ struct StagerFixed {
     }
 };
 
-template <typename T, bool AXC, bool BXC, bool APRO, bool BPRO, int NSTAGE, int TM>
+template <typename T, bool AXC, bool BXC, bool APRO, bool BPRO, int NSTAGE, int TM, int NT>
 __global__ void __launch_bounds__(NT) gemm_kernel(int M, int N, int K, OpDev A, OpDev B, EpiDev E, int kper, int mt, int nt, int dbg) {
     using Cfg = GemmCfg<T>;
     constexpr int BK = Cfg::BK;
-    constexpr int BM = 32 * TM;            // 2 x 2 waves, TM x 4 MFMA tiles of 16 x 16 per wave
+    constexpr int BM = 32 * TM;            // 2 x WN waves, TM x TN MFMA tiles of 16 x 16 per wave
+    constexpr int WN = NT / 128, TN = 8 / WN;
     constexpr int LDA = AXC ? (BM + Cfg::PADX) : (BK + Cfg::PADK);
     constexpr int LDB = BXC ? (BN + Cfg::PADX) : (BK + Cfg::PADK);
     constexpr int A_ELEMS = AXC ? BK * LDA : BM * LDA;
@@ -179,7 +184,7 @@ __global__ void __launch_bounds__(NT) gemm_kernel(int M, int N, int K, OpDev A, 
     T* lB = lds + A_ELEMS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int seq = xcd_remap(blockIdx.x, gridDim.x);
     const int zt = seq / (mt * nt), rem = seq - zt * (mt * nt);
     const int m0 = (rem / nt) * BM;
@@ -187,20 +192,20 @@ __global__ void __launch_bounds__(NT) gemm_kernel(int M, int N, int K, OpDev A, 
     const int kbeg = zt * kper;
     const int kend = min(K, kbeg + kper);
 
-    using StA = Stager<T, AXC ? BK : BM, AXC ? BM : BK, LDA, AXC>;
-    using StB = Stager<T, BXC ? BK : BN, BXC ? BN : BK, LDB, BXC>;
-    StagerFixed<T, AXC ? BK : BM, AXC ? BM : BK, LDA, AXC> fa_;
-    StagerFixed<T, BXC ? BK : BN, BXC ? BN : BK, LDB, BXC> fb_;
+    using StA = Stager<T, AXC ? BK : BM, AXC ? BM : BK, LDA, AXC, NT>;
+    using StB = Stager<T, BXC ? BK : BN, BXC ? BN : BK, LDB, BXC, NT>;
+    StagerFixed<T, AXC ? BK : BM, AXC ? BM : BK, LDA, AXC, NT> fa_;
+    StagerFixed<T, BXC ? BK : BN, BXC ? BN : BK, LDB, BXC, NT> fb_;
     fa_.setup(A, m0, M, tid);
     fb_.setup(B, n0, N, tid);
     StA sa[NSTAGE];
     StB sb[NSTAGE];
 
-    f32x4 acc[TM][4];
+    f32x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // NSTAGE K-tiles of loads in flight before the first one is needed
 #pragma unroll
@@ -246,26 +251,26 @@ __global__ void __launch_bounds__(NT) gemm_kernel(int M, int N, int K, OpDev A, 
 #pragma unroll
                 for (int kk = 0; kk < BK; kk += Cfg::KSTEP) {
                     if constexpr (sizeof(T) == 2) {
-                        bf16x8 fa[TM], fb[4];
+                        bf16x8 fa[TM], fb[TN];
 #pragma unroll
                         for (int i = 0; i < TM; ++i) fa[i] = frag_bf16<AXC, LDA>((const bf16*)lA, wm * (16 * TM) + i * 16, kk, lane);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) fb[j] = frag_bf16<BXC, LDB>((const bf16*)lB, wn * 64 + j * 16, kk, lane);
+                        for (int j = 0; j < TN; ++j) fb[j] = frag_bf16<BXC, LDB>((const bf16*)lB, wn * (16 * TN) + j * 16, kk, lane);
 #pragma unroll
                         for (int i = 0; i < TM; ++i)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
+                            for (int j = 0; j < TN; ++j)
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
                     } else {
-                        float fa[TM], fb[4];
+                        float fa[TM], fb[TN];
 #pragma unroll
                         for (int i = 0; i < TM; ++i) fa[i] = frag_f32<AXC, LDA>((const float*)lA, wm * (16 * TM) + i * 16, kk, lane);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) fb[j] = frag_f32<BXC, LDB>((const float*)lB, wn * 64 + j * 16, kk, lane);
+                        for (int j = 0; j < TN; ++j) fb[j] = frag_f32<BXC, LDB>((const float*)lB, wn * (16 * TN) + j * 16, kk, lane);
 #pragma unroll
                         for (int i = 0; i < TM; ++i)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
+                            for (int j = 0; j < TN; ++j)
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j], fa[i], acc[i][j], 0, 0, 0);
                     }
                 }
@@ -291,7 +296,7 @@ __global__ void __launch_bounds__(NT) gemm_kernel(int M, int N, int K, OpDev A, 
     }
     // ------------------------------------------------------------------ epilogue (row-major through LDS)
     if ((dbg & 1) && acc[0][0][0] != 12345.678f) return;     // timing experiment: skip the epilogue
-    epilogue_rows<T, TM, 4, 2, 2, AXC>(acc, E, M, N, m0, n0, reinterpret_cast<float*>(lds), tid);
+    epilogue_rows<T, TM, TN, 2, WN, AXC>(acc, E, M, N, m0, n0, reinterpret_cast<float*>(lds), tid);
 }
 
 OpDev to_dev(const bf_operand* o) {
@@ -323,19 +328,28 @@ int launch(int M, int N, int K, const bf_operand* A, const bf_operand* B, const 
     dim3 grid((unsigned)((long)mt * nt * splitk));
     const bool ax = A->layout == BF_LAY_XC, bx = B->layout == BF_LAY_XC;
     const double es = sizeof(T);
+    static const int dbg = []() { const char* v = getenv("BF_GEMM_DEBUG"); return v ? atoi(v) : 0; }();
+    static const int w8env = []() { const char* v = getenv("BF_GEMM_WAVES"); return v ? atoi(v) : 0; }();
+    // measured (tools/gemm_bench.py, MI355X): 8 waves of TM x 2 tiles win for the dA form and for grids of < 2 workgroups
+    // per CU (more waves in flight per CU); 4 waves of TM x 4 tiles win for the large forward grids and the dW form
+    const bool w8 = sizeof(T) == 2 && (w8env == 8 || (w8env == 0 && !ax && (bx || small)));
     // one profiler name per kernel instantiation, so bench.py's per-kernel averages line up 1:1 with rocprofv3's rows
     static thread_local char pname[96];
-    snprintf(pname, sizeof(pname), "gemm_kernel<%s,%s,%s,pro%s,tm%d>", sizeof(T) == 2 ? "bf16" : "f32", ax ? "xc" : "kc", bx ? "xc" : "kc",
-             A->pro != BF_PRO_NONE ? "A" : B->pro != BF_PRO_NONE ? "B" : "0", small ? 2 : 4);
+    snprintf(pname, sizeof(pname), "gemm_kernel<%s,%s,%s,pro%s,tm%d,w%d>", sizeof(T) == 2 ? "bf16" : "f32", ax ? "xc" : "kc", bx ? "xc" : "kc",
+             A->pro != BF_PRO_NONE ? "A" : B->pro != BF_PRO_NONE ? "B" : "0", small ? 2 : 4, w8 ? 8 : 4);
     BfProfScope prof(st, pname, 2.0 * M * N * K,
                      (double)M * K * es + (double)N * K * es + (double)M * N * (E->out_mode == BF_OUT_STORE ? es : 4.0) +
                          (E->aux_mode != BF_AUX_NONE ? (double)M * N * es : 0.0));
     const bool ap = A->pro != BF_PRO_NONE, bp = B->pro != BF_PRO_NONE;
-    static const int dbg = []() { const char* v = getenv("BF_GEMM_DEBUG"); return v ? atoi(v) : 0; }();
 #define BF_GEMM_GO(AX, BX, AP, BP)                                                                                            \
     do {                                                                                                                      \
-        if (small) hipLaunchKernelGGL((gemm_kernel<T, AX, BX, AP, BP, 3, 2>), grid, dim3(NT), 0, st, M, N, K, a, b, e, kper, mt, nt, dbg); \
-        else hipLaunchKernelGGL((gemm_kernel<T, AX, BX, AP, BP, 3, 4>), grid, dim3(NT), 0, st, M, N, K, a, b, e, kper, mt, nt, dbg);  \
+        if (w8) {                                                                                                             \
+            if (small) hipLaunchKernelGGL((gemm_kernel<T, AX, BX, AP, BP, 3, 2, 512>), grid, dim3(512), 0, st, M, N, K, a, b, e, kper, mt, nt, dbg); \
+            else hipLaunchKernelGGL((gemm_kernel<T, AX, BX, AP, BP, 3, 4, 512>), grid, dim3(512), 0, st, M, N, K, a, b, e, kper, mt, nt, dbg);  \
+        } else {                                                                                                              \
+            if (small) hipLaunchKernelGGL((gemm_kernel<T, AX, BX, AP, BP, 3, 2, 256>), grid, dim3(256), 0, st, M, N, K, a, b, e, kper, mt, nt, dbg); \
+            else hipLaunchKernelGGL((gemm_kernel<T, AX, BX, AP, BP, 3, 4, 256>), grid, dim3(256), 0, st, M, N, K, a, b, e, kper, mt, nt, dbg);  \
+        }                                                                                                                     \
     } while (0)
     if (!ax && !bx && !bp) { if (ap) BF_GEMM_GO(false, false, true, false); else BF_GEMM_GO(false, false, false, false); }
     else if (!ax && bx && !bp) { if (ap) BF_GEMM_GO(false, true, true, false); else BF_GEMM_GO(false, true, false, false); }
