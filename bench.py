@@ -95,10 +95,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1"
+    # BENCH_DEVICE / BENCH_BACKEND exist only to rehearse the multi-rank control flow on a one-GPU box (gloo, every rank on
+    # one device); the driver's runs use one GPU per rank and RCCL ("nccl").
+    if os.environ.get("BENCH_DEVICE") is not None:
+        local = int(os.environ["BENCH_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from bubbleformer_amd import _lib
     from bubbleformer_amd.models import get_model

@@ -330,9 +330,9 @@ int launch(int M, int N, int K, const bf_operand* A, const bf_operand* B, const 
     const double es = sizeof(T);
     static const int dbg = []() { const char* v = getenv("BF_GEMM_DEBUG"); return v ? atoi(v) : 0; }();
     static const int w8env = []() { const char* v = getenv("BF_GEMM_WAVES"); return v ? atoi(v) : 0; }();
-    // measured (tools/gemm_bench.py, MI355X): 8 waves of TM x 2 tiles win for the dA form and for grids of < 2 workgroups
-    // per CU (more waves in flight per CU); 4 waves of TM x 4 tiles win for the large forward grids and the dW form
-    const bool w8 = sizeof(T) == 2 && (w8env == 8 || (w8env == 0 && !ax && (bx || small)));
+    // measured (tools/gemm_bench.py, MI355X): with one register stage, 8 waves of TM x 2 tiles (<= 128 VGPRs: two 8-wave
+    // workgroups per CU) win everywhere except the long-K, narrow-N forward GEMM on a small grid
+    const bool w8 = sizeof(T) == 2 && (w8env == 8 || (w8env == 0 && !(small && !ax && !bx && K >= 1024)));
     // one profiler name per kernel instantiation, so bench.py's per-kernel averages line up 1:1 with rocprofv3's rows
     static thread_local char pname[96];
     snprintf(pname, sizeof(pname), "gemm_kernel<%s,%s,%s,pro%s,tm%d,w%d>", sizeof(T) == 2 ? "bf16" : "f32", ax ? "xc" : "kc", bx ? "xc" : "kc",
@@ -341,21 +341,26 @@ int launch(int M, int N, int K, const bf_operand* A, const bf_operand* B, const 
                      (double)M * K * es + (double)N * K * es + (double)M * N * (E->out_mode == BF_OUT_STORE ? es : 4.0) +
                          (E->aux_mode != BF_AUX_NONE ? (double)M * N * es : 0.0));
     const bool ap = A->pro != BF_PRO_NONE, bp = B->pro != BF_PRO_NONE;
-#define BF_GEMM_GO(AX, BX, AP, BP)                                                                                            \
+    static const int st_env = []() { const char* v = getenv("BF_GEMM_STAGES"); return v ? atoi(v) : 0; }();
+    const bool s1 = st_env == 1;
+#define BF_GEMM_GO2(AX, BX, AP, BP, NS)                                                                                       \
     do {                                                                                                                      \
         if (w8) {                                                                                                             \
-            if (small) hipLaunchKernelGGL((gemm_kernel<T, AX, BX, AP, BP, 3, 2, 512>), grid, dim3(512), 0, st, M, N, K, a, b, e, kper, mt, nt, dbg); \
-            else hipLaunchKernelGGL((gemm_kernel<T, AX, BX, AP, BP, 3, 4, 512>), grid, dim3(512), 0, st, M, N, K, a, b, e, kper, mt, nt, dbg);  \
+            if (small) hipLaunchKernelGGL((gemm_kernel<T, AX, BX, AP, BP, NS, 2, 512>), grid, dim3(512), 0, st, M, N, K, a, b, e, kper, mt, nt, dbg); \
+            else hipLaunchKernelGGL((gemm_kernel<T, AX, BX, AP, BP, NS, 4, 512>), grid, dim3(512), 0, st, M, N, K, a, b, e, kper, mt, nt, dbg);  \
         } else {                                                                                                              \
-            if (small) hipLaunchKernelGGL((gemm_kernel<T, AX, BX, AP, BP, 3, 2, 256>), grid, dim3(256), 0, st, M, N, K, a, b, e, kper, mt, nt, dbg); \
-            else hipLaunchKernelGGL((gemm_kernel<T, AX, BX, AP, BP, 3, 4, 256>), grid, dim3(256), 0, st, M, N, K, a, b, e, kper, mt, nt, dbg);  \
+            if (small) hipLaunchKernelGGL((gemm_kernel<T, AX, BX, AP, BP, NS, 2, 256>), grid, dim3(256), 0, st, M, N, K, a, b, e, kper, mt, nt, dbg); \
+            else hipLaunchKernelGGL((gemm_kernel<T, AX, BX, AP, BP, NS, 4, 256>), grid, dim3(256), 0, st, M, N, K, a, b, e, kper, mt, nt, dbg);  \
         }                                                                                                                     \
     } while (0)
+    (void)s1;   // measured: one register stage (more workgroups per CU) beats three (deeper prefetch) on every shape of this model
+#define BF_GEMM_GO(AX, BX, AP, BP) BF_GEMM_GO2(AX, BX, AP, BP, 1)
     if (!ax && !bx && !bp) { if (ap) BF_GEMM_GO(false, false, true, false); else BF_GEMM_GO(false, false, false, false); }
     else if (!ax && bx && !bp) { if (ap) BF_GEMM_GO(false, true, true, false); else BF_GEMM_GO(false, true, false, false); }
     else if (ax && bx && !ap) { if (bp) BF_GEMM_GO(true, true, false, true); else BF_GEMM_GO(true, true, false, false); }
     else return bf_fail_msg("bf_gemm: unsupported layout/prologue combination", __FILE__, __LINE__);
 #undef BF_GEMM_GO
+#undef BF_GEMM_GO2
     BF_CHECK_LAUNCH();
     return 0;
 }
