@@ -67,7 +67,7 @@ struct StagerFixed {
     int r0, cc;
     bool gather;
 
-    __device__ __forceinline__ void setup(const OpDev& op, int outer0, int nouter, int tid) {
+    __device__ __forceinline__ void setup(const OpDev& op, int outer0, int nouter, int tid, bool need_frames) {
         r0 = tid / CPR; cc = (tid % CPR) * CH;
         gather = op.gw > 0 || op.seglen > 0;
         ok = 0u;
@@ -81,7 +81,7 @@ struct StagerFixed {
                 ok |= (v ? 1u : 0u) << i;
                 gfix[i] = v ? row_base(row, op.ld, op.gw, op.gh, op.gc) : 0;
                 voff[i] = gfix[i] + cc;
-                fidx[i] = row / op.rpf;
+                fidx[i] = need_frames ? row / op.rpf : 0;
             }
         } else {
             const int col = outer0 + cc;
@@ -196,8 +196,8 @@ __global__ void __launch_bounds__(NT) gemm_kernel(int M, int N, int K, OpDev A, 
     using StB = Stager<T, BXC ? BK : BN, BXC ? BN : BK, LDB, BXC, NT>;
     StagerFixed<T, AXC ? BK : BM, AXC ? BM : BK, LDA, AXC, NT> fa_;
     StagerFixed<T, BXC ? BK : BN, BXC ? BN : BK, LDB, BXC, NT> fb_;
-    fa_.setup(A, m0, M, tid);
-    fb_.setup(B, n0, N, tid);
+    fa_.setup(A, m0, M, tid, APRO);
+    fb_.setup(B, n0, N, tid, BPRO);
     StA sa[NSTAGE];
     StB sb[NSTAGE];
 

@@ -250,45 +250,31 @@ __global__ void __launch_bounds__(NT) in_bwd_kernel(const T* __restrict__ dy, co
     }
 }
 
-// parameter gradients from the per-frame partials ws[f][c] = {s1, s2}:  grid (ceil(C/64)), block 256 = 64 channels x 4 frame lanes
+// parameter gradients from the per-frame partials ws[f][c] = {s1, s2}.
+// grid (ceil(C/64), frame groups): one workgroup sums the frames of ONE frame group (gdiv frames; 256 threads = 64 channels x
+// 4 frame lanes) and adds its share to dw/db (a few atomics per address) and, if asked, stores dg/dgb of that group.
 __global__ void __launch_bounds__(NT) in_param_reduce_kernel(const float* __restrict__ ws, int frames, int C, const float* __restrict__ w,
                                                             const float* __restrict__ b, const float* __restrict__ g, int gdiv,
                                                             float* __restrict__ dw, float* __restrict__ db, float* __restrict__ dg,
                                                             float* __restrict__ dgb) {
     __shared__ float red[2][4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), fl = threadIdx.x >> 6;
+    const int l = threadIdx.x & 63, fl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + l, fg = blockIdx.y;
     const bool cv = c < C;
-    float aw = 0.f, ab = 0.f;
-    // dg / dgb are per frame GROUP: walk the groups, each of the 4 frame lanes takes a strided share of a group's frames
-    const int ngroups = (frames + gdiv - 1) / gdiv;
-    for (int fg = 0; fg < ngroups; ++fg) {
-        float s1 = 0.f, s2 = 0.f;
-        const int f1 = min(frames, (fg + 1) * gdiv);
-        if (cv)
-            for (int f = fg * gdiv + fl; f < f1; f += 4) { s1 += ws[((long)f * C + c) * 2]; s2 += ws[((long)f * C + c) * 2 + 1]; }
-        const float gg = (cv && g) ? g[(long)fg * C + c] : 1.f;
-        aw += gg * s2; ab += gg * s1;
-        if (dg || dgb) {
-            __syncthreads();
-            red[0][fl][threadIdx.x & 63] = s1; red[1][fl][threadIdx.x & 63] = s2;
-            __syncthreads();
-            if (fl == 0 && cv) {
-                const int l = threadIdx.x;
-                const float t1 = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
-                const float t2 = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
-                if (dg) dg[(long)fg * C + c] += w[c] * t2 + b[c] * t1;
-                if (dgb) dgb[(long)fg * C + c] += t1;
-            }
-        }
-    }
+    const int f1 = min(frames, (fg + 1) * gdiv);
+    float s1 = 0.f, s2 = 0.f;
+    if (cv)
+        for (int f = fg * gdiv + fl; f < f1; f += 4) { s1 += ws[((long)f * C + c) * 2]; s2 += ws[((long)f * C + c) * 2 + 1]; }
+    red[0][fl][l] = s1; red[1][fl][l] = s2;
     __syncthreads();
-    red[0][fl][threadIdx.x & 63] = ab; red[1][fl][threadIdx.x & 63] = aw;
-    __syncthreads();
-    if (fl == 0 && cv) {
-        const int l = threadIdx.x;
-        if (db) db[c] += red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
-        if (dw) dw[c] += red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
-    }
+    if (fl != 0 || !cv) return;
+    const float t1 = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
+    const float t2 = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+    const float gg = g ? g[(long)fg * C + c] : 1.f;
+    if (dw) atomicAdd(dw + c, gg * t2);
+    if (db) atomicAdd(db + c, gg * t1);
+    if (dg) dg[(long)fg * C + c] += w[c] * t2 + b[c] * t1;
+    if (dgb) dgb[(long)fg * C + c] += t1;
 }
 
 // ------------------------------------------------------------------------------------ column sums
@@ -382,8 +368,9 @@ extern "C" int bf_in_bwd(int dtype, const void* dy, const void* x, const void* a
 #undef GO
     BF_CHECK_LAUNCH();
     if (ws) {
-        const int rdiv = (!g && !dg && !dgb) ? frames : gdiv;      // no per-group outputs: one group, all four frame lanes busy
-        hipLaunchKernelGGL(in_param_reduce_kernel, dim3(bf_cdiv(C, 64)), dim3(NT), 0, st, (const float*)ws, frames, C, w, b, g, rdiv, dw, db, dg, dgb);
+        // no per-group scale / outputs: any grouping is valid -> 16 frames per workgroup keeps the grid wide
+        const int rdiv = (!g && !dg && !dgb) ? 16 : gdiv;
+        hipLaunchKernelGGL(in_param_reduce_kernel, dim3(bf_cdiv(C, 64), bf_cdiv(frames, rdiv)), dim3(NT), 0, st, (const float*)ws, frames, C, w, b, g, rdiv, dw, db, dg, dgb);
         BF_CHECK_LAUNCH();
     }
     return 0;
