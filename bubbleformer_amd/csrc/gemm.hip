@@ -322,7 +322,8 @@ int launch(int M, int N, int K, const bf_operand* A, const bf_operand* B, const 
     splitk = bf_cdiv(K, kper);
     // 128 x 128 tiles unless that leaves the chip with fewer than two workgroups per CU: then 64 x 128
     const int nt = bf_cdiv(N, BN);
-    const bool small = (long)bf_cdiv(M, 128) * nt * splitk < 512 && M > 64;
+    static const int small_env = []() { const char* v = getenv("BF_GEMM_SMALL"); return v ? atoi(v) : -1; }();
+    const bool small = small_env >= 0 ? (small_env != 0 && M > 64) : ((long)bf_cdiv(M, 128) * nt * splitk < 512 && M > 64);
     const int bm = small ? 64 : 128;
     const int mt = bf_cdiv(M, bm);
     dim3 grid((unsigned)((long)mt * nt * splitk));

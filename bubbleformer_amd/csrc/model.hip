@@ -256,13 +256,14 @@ int outproj_gemm(const D& d, const void* o, const float* sc, const float* sh, co
 int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* o, const float* sc2, const float* sh2, const void* w_c,
                 const float* W, const float* bias, const float* nb, const float* gamma, const float* lo, const float* hi,
                 const float* alpha, const float* mc, float* dW, float* dbias, float* dnb, float* dgamma, float* dlo, float* dhi,
-                void* don, hipStream_t st) {
+                void* don, void* tmp, hipStream_t st) {
     ZERO(sc.G, (size_t)d.E * d.E * 4);
     ZERO(sc.csum, (size_t)d.E * 4);
-    {   // G[n][k] = sum_m dout[m][n] * on[m][k]
+    {   // G[n][k] = sum_m dout[m][n] * on[m][k].  The normalised operand is materialised first (one 2U element-wise pass,
+        // ~7 us) because applying the affine inside the token-reduction GEMM's staging costs ~20 us (tools/gemm_bench.py)
+        TRY(bf_affine_apply(d.dtype, o, nullptr, sc2, sh2, tmp, d.N, (int)d.S, d.E, st));
         bf_operand A = op_plain(dout, d.E, BF_LAY_XC);
-        bf_operand Bo = op_plain(o, d.E, BF_LAY_XC);
-        op_affine(Bo, BF_PRO_AFFINE, sc2, sh2, d.S, d.E);
+        bf_operand Bo = op_plain(tmp, d.E, BF_LAY_XC);
         bf_epilogue e = epi_atomic(sc.G, d.E);
         e.colsum = sc.csum;                  // dbeta = colsum(dout), fused into the same pass over dout
         TRY(bf_gemm(d.dtype, d.E, d.E, (int)d.N, &A, &Bo, &e, splitk_for(d.E, d.E, d.N), st));
@@ -281,9 +282,14 @@ int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* o, 
 }
 // backward of y = affine(x) @ W^T + b:  dW += dy^T affine(x), db += colsum(dy), dxn = dy @ W
 int linear_bwd(const D& d, const Scratch& sc, const void* dy, int Nout, const void* x, int Kin, int xpro, const float* xsc, const float* xsh,
-               const void* w_c, float* dW, float* db, void* dxn, const bf_epilogue* dx_epi, hipStream_t st) {
+               const void* w_c, float* dW, float* db, void* dxn, const bf_epilogue* dx_epi, void* tmp, hipStream_t st) {
     {
         bf_operand A = op_plain(dy, Nout, BF_LAY_XC);
+        if (xpro == BF_PRO_AFFINE && tmp) {      // see outproj_bwd: materialise the normalised operand once
+            TRY(bf_affine_apply(d.dtype, x, nullptr, xsc, xsh, tmp, d.N, (int)d.S, Kin, st));
+            x = tmp;
+            xpro = BF_PRO_NONE;
+        }
         bf_operand Bo = op_plain(x, Kin, BF_LAY_XC);
         if (xpro != BF_PRO_NONE) op_affine(Bo, xpro, xsc, xsh, d.S, Kin);
         bf_epilogue e = epi_atomic(dW, Kin);
@@ -343,14 +349,14 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
     void* dO = sc.t1b;      // [N][E]
     void* dqkv = sc.t3;     // [N][3E]
     TRY(outproj_bwd(d, sc, dout, sv.o, sv.sc2, sv.sh2, wout_c, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr,
-                    sv.alpha, sv.mc, g->output_head_w, g->output_head_b, nullptr, g->gamma, nullptr, nullptr, don, st));
+                    sv.alpha, sv.mc, g->output_head_w, g->output_head_b, nullptr, g->gamma, nullptr, nullptr, don, /*tmp*/ sc.t1b, st));
     TRY(bf_in_bwd(d.dtype, don, sv.o, nullptr, dO, (int)d.F, (int)d.S, d.E, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, nullptr, 1, 0,
                   g->norm2_w, g->norm2_b, nullptr, nullptr, sc.in_ws, st));
     TRY(bf_attn_bwd(d.dtype, sv.qkv, dO, dqkv, (long)d.B * d.S, d.T, d.S, (long)d.T * d.S, 1, d.S, d.heads, d.d, p->qnorm_w, p->qnorm_b,
                     p->knorm_w, p->knorm_b, p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor : nullptr, g->qnorm_w, g->qnorm_b,
                     g->knorm_w, g->knorm_b, g->rel_pos_emb, d.attn_scale ? g->attn_scale_factor : nullptr, 1.f, 0, sc.attn_ws, Scratch::ATTN_WS_FLOATS, st));
     void* dxn = sc.t1;      // don is dead
-    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, x, d.E, BF_PRO_AFFINE, sv.sc1, sv.sh1, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st));
+    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, x, d.E, BF_PRO_AFFINE, sv.sc1, sv.sh1, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, /*tmp*/ sc.t1b, st));
     TRY(bf_in_bwd(d.dtype, dxn, x, dout, dx, (int)d.F, (int)d.S, d.E, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, nullptr, 1, 0,
                   g->norm1_w, g->norm1_b, nullptr, nullptr, sc.in_ws, st));
     return 0;
@@ -424,21 +430,21 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     {
         bf_epilogue e; memset(&e, 0, sizeof(e));
         e.aux_mode = BF_AUX_DGELU; e.aux = sv.pre; e.ld_aux = 4L * d.E; e.out_mode = BF_OUT_STORE;
-        TRY(linear_bwd(d, sc, dz, d.E, sv.hid, 4 * d.E, BF_PRO_NONE, nullptr, nullptr, w2_c, g->fc2_w, g->fc2_b, dpre, &e, st));
+        TRY(linear_bwd(d, sc, dz, d.E, sv.hid, 4 * d.E, BF_PRO_NONE, nullptr, nullptr, w2_c, g->fc2_w, g->fc2_b, dpre, &e, nullptr, st));
     }
     // fc1: pre = x1 @ W1^T + b1 ; dx1 = dout + dpre @ W1
     void* dx1 = sc.t1b;
     {
         bf_epilogue e; memset(&e, 0, sizeof(e));
         e.aux_mode = BF_AUX_ADD; e.aux = dout; e.ld_aux = d.E; e.out_mode = BF_OUT_STORE;
-        TRY(linear_bwd(d, sc, dpre, 4 * d.E, sv.x1, d.E, BF_PRO_NONE, nullptr, nullptr, w1_c, g->fc1_w, g->fc1_b, dx1, &e, st));
+        TRY(linear_bwd(d, sc, dpre, 4 * d.E, sv.x1, d.E, BF_PRO_NONE, nullptr, nullptr, w1_c, g->fc1_w, g->fc1_b, dx1, &e, nullptr, st));
     }
     // folded out-projection
     void* don = sc.t1;      // dz is dead
     TRY(outproj_bwd(d, sc, dx1, sv.o, sv.sc2, sv.sh2, wout_c, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att,
                     d.feat_scale ? p->low_freq_scalar : nullptr, d.feat_scale ? p->high_freq_scalar : nullptr, sv.alpha, sv.mc,
                     g->output_head_w, g->output_head_b, g->norm2_b, g->gamma_att, d.feat_scale ? g->low_freq_scalar : nullptr,
-                    d.feat_scale ? g->high_freq_scalar : nullptr, don, st));
+                    d.feat_scale ? g->high_freq_scalar : nullptr, don, /*tmp: dpre is dead*/ sc.t4, st));
     void* dO = sc.t4;       // dpre is dead; [N][E]
     TRY(bf_in_bwd(d.dtype, don, sv.o, nullptr, dO, (int)d.F, (int)d.S, d.E, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, nullptr, 1, 0,
                   g->norm2_w, g->norm2_b, nullptr, nullptr, sc.in_ws, st));
@@ -450,7 +456,7 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
                     p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_y : nullptr, g->qnorm_w, g->qnorm_b, g->knorm_w, g->knorm_b,
                     g->rel_pos_emb, d.attn_scale ? g->attn_scale_factor_y : nullptr, 0.5f, 1, sc.attn_ws, Scratch::ATTN_WS_FLOATS, st));
     void* dxn = sc.t1;      // don is dead
-    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, x, d.E, BF_PRO_AFFINE, sv.sc1, sv.sh1, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st));
+    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, x, d.E, BF_PRO_AFFINE, sv.sc1, sv.sh1, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, /*tmp: dO is dead*/ sc.t4, st));
     TRY(bf_in_bwd(d.dtype, dxn, x, dx1, dx, (int)d.F, (int)d.S, d.E, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, nullptr, 1, 0,
                   g->norm1_w, g->norm1_b, nullptr, nullptr, sc.in_ws, st));
     return 0;
