@@ -25,6 +25,7 @@ sys.path.insert(0, REPO)
 CFG = dict(input_fields=4, output_fields=4, patch_size=16, embed_dim=384, num_heads=6, processor_blocks=12,
            attn_scale=True, feat_scale=True, num_fluid_params=9)          # config/model_cfg/film_avit_small.yaml
 BATCH, T, H, W = 8, 16, 192, 192
+DROP_PATH = 0.2                     # film_avit_small.yaml: stochastic depth, rates np.linspace(0, 0.2, 12) over the blocks
 FIELD_STATS = ((-2.37, 1.98), (0.0145, 0.081), (-0.07, 0.49), (0.055, 0.77))
 # algorithmic work per sample at this shape (fwd+bwd)
 FLOPS_PER_SAMPLE = 423.20e9
@@ -113,7 +114,7 @@ def main():
     from bubbleformer_amd.trainer import TrainStep
     torch.manual_seed(42)
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    model = get_model("filmavit", time_window=T, drop_path=0.0, compute_dtype=cdt, **CFG).to(dev)
+    model = get_model("filmavit", time_window=T, drop_path=DROP_PATH, compute_dtype=cdt, **CFG).to(dev).train()
     step = TrainStep(model, lr=2.5e-4, weight_decay=1e-2)            # config/optim_cfg/adamw.yaml
     x, cond, y = synthetic_batch(42 + 1000 * rank, dev)
 
@@ -190,7 +191,7 @@ def main():
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "FiLMAViT-small (E=384, 6 heads, 12 blocks, P=16, 9 fluid params) fwd + relative-L2 loss + bwd + AdamW, "
                                "4-field 16x192x192 clips, batch 8 per GPU (BASELINE.json configs[1])",
-                   "global_batch": BATCH * world, "parallelism": f"dp{world}", "drop_path": 0.0},
+                   "global_batch": BATCH * world, "parallelism": f"dp{world}", "drop_path": DROP_PATH},
         "loss": final_loss,
         "roofline": roofline,
         "step_roofline": {"hbm_frac": per_gpu * (BYTES_PER_SAMPLE + BYTES_PER_STEP_PARAMS / BATCH) / (PEAK_HBM_GBS * 1e9),

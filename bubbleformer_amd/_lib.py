@@ -30,7 +30,7 @@ class Operand(C.Structure):
 class Epilogue(C.Structure):
     _fields_ = [("bias", fp), ("colscale", fp), ("colshift", fp), ("aux_mode", i32), ("aux", vp), ("ld_aux", i64),
                 ("out_mode", i32), ("c", vp), ("ldc", i64), ("seglen", i32), ("segstride", i64), ("gw", i32), ("gh", i32),
-                ("gc", i32), ("gelu_out", vp), ("colsum", fp)]
+                ("gc", i32), ("gelu_out", vp), ("colsum", fp), ("rowscale", fp), ("rows_per_group", i32)]
 
 
 class Dims(C.Structure):
@@ -96,10 +96,10 @@ SIGNATURES = {
     "bf_embed_saved_bytes": (i64, [P(Dims)]),
     "bf_debed_saved_bytes": (i64, [P(Dims)]),
     "bf_scratch_bytes": (i64, [P(Dims)]),
-    "bf_temporal_fwd": (C.c_int, [P(Dims), P(TemporalParams), vp, vp, vp, vp, vp]),
-    "bf_temporal_bwd": (C.c_int, [P(Dims), P(TemporalParams), P(TemporalParams), vp, vp, vp, vp, vp, vp]),
-    "bf_spatial_fwd": (C.c_int, [P(Dims), P(SpatialParams), vp, vp, vp, vp, vp]),
-    "bf_spatial_bwd": (C.c_int, [P(Dims), P(SpatialParams), P(SpatialParams), vp, vp, vp, vp, vp, vp]),
+    "bf_temporal_fwd": (C.c_int, [P(Dims), P(TemporalParams), vp, vp, vp, vp, fp, vp]),
+    "bf_temporal_bwd": (C.c_int, [P(Dims), P(TemporalParams), P(TemporalParams), vp, vp, vp, vp, vp, fp, vp]),
+    "bf_spatial_fwd": (C.c_int, [P(Dims), P(SpatialParams), vp, vp, vp, vp, fp, fp, vp]),
+    "bf_spatial_bwd": (C.c_int, [P(Dims), P(SpatialParams), P(SpatialParams), vp, vp, vp, vp, vp, fp, fp, vp]),
     "bf_embed_fwd": (C.c_int, [P(Dims), P(EmbedParams), fp, fp, vp, vp, vp, vp]),
     "bf_embed_bwd": (C.c_int, [P(Dims), P(EmbedParams), P(EmbedParams), vp, fp, vp, vp, vp]),
     "bf_debed_fwd": (C.c_int, [P(Dims), P(DebedParams), vp, fp, fp, fp, vp, vp, vp]),

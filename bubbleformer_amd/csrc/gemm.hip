@@ -314,7 +314,7 @@ int launch(int M, int N, int K, const bf_operand* A, const bf_operand* B, const 
     EpiDev e;
     e.bias = E->bias; e.colscale = E->colscale; e.colshift = E->colshift; e.aux_mode = E->aux_mode; e.aux = E->aux;
     e.ld_aux = E->ld_aux; e.out_mode = E->out_mode; e.c = E->c; e.ldc = E->ldc; e.seglen = E->seglen;
-    e.segstride = E->segstride; e.gw = E->gw; e.gh = E->gh; e.gc = E->gc; e.gelu_out = E->gelu_out; e.colsum = E->colsum;
+    e.segstride = E->segstride; e.gw = E->gw; e.gh = E->gh; e.gc = E->gc; e.gelu_out = E->gelu_out; e.colsum = E->colsum; e.rowscale = E->rowscale; e.rpg = E->rows_per_group > 0 ? E->rows_per_group : 1;
     if (splitk < 1) splitk = 1;
     int ktiles = bf_cdiv(K, BK);
     if (splitk > ktiles) splitk = ktiles;

@@ -12,7 +12,7 @@ struct OpDev {
 };
 struct EpiDev {
     const float* bias; const float* colscale; const float* colshift; int aux_mode; const void* aux; long ld_aux;
-    int out_mode; void* c; long ldc; int seglen; long segstride; int gw, gh, gc; void* gelu_out; float* colsum;
+    int out_mode; void* c; long ldc; int seglen; long segstride; int gw, gh, gc; void* gelu_out; float* colsum; const float* rowscale; int rpg;
 };
 
 __device__ __forceinline__ long row_base(int row, long ld, int gw, int gh, int gc) {
@@ -174,6 +174,11 @@ __device__ __forceinline__ void epilogue_rows(const f32x4 (&acc)[TM][TN], const 
                 const float4 hi = *reinterpret_cast<const float4*>(stg + srow * LDS_ + c + 4);
                 float v[G] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                 const bool full = n + G <= N;
+                if (E.rowscale) {                           // stochastic depth: the whole branch value is scaled per sample
+                    const float rs = E.rowscale[m / E.rpg];
+#pragma unroll
+                    for (int q = 0; q < G; ++q) v[q] *= rs;
+                }
                 if (E.aux_mode != BF_AUX_NONE) {
                     const T* aux = reinterpret_cast<const T*>(E.aux) + (long)m * E.ld_aux + n;
                     float a[G];

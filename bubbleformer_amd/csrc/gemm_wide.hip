@@ -242,7 +242,7 @@ int bf_gemm_wide_try(int M, int N, int K, const bf_operand* A, const bf_operand*
     cv(A, a); cv(B, b);
     EpiDev e;
     e.bias = E->bias; e.colscale = E->colscale; e.colshift = E->colshift; e.aux_mode = E->aux_mode; e.aux = E->aux; e.ld_aux = E->ld_aux;
-    e.out_mode = E->out_mode; e.c = E->c; e.ldc = E->ldc; e.seglen = 0; e.segstride = 0; e.gw = e.gh = e.gc = 0; e.gelu_out = E->gelu_out; e.colsum = nullptr;
+    e.out_mode = E->out_mode; e.c = E->c; e.ldc = E->ldc; e.seglen = 0; e.segstride = 0; e.gw = e.gh = e.gc = 0; e.gelu_out = E->gelu_out; e.colsum = nullptr; e.rowscale = E->rowscale; e.rpg = E->rows_per_group > 0 ? E->rows_per_group : 1;
     if (splitk < 1) splitk = 1;
     const int ktiles = bf_cdiv(K, BKW);
     if (splitk > ktiles) splitk = ktiles;

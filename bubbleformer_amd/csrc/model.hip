@@ -140,6 +140,20 @@ __global__ void outproj_finalize_kernel(const float* __restrict__ G, const float
         dW[(long)n * E + k] += v;
     }
 }
+// stochastic-depth helpers: out[f][c] = m[f / fdiv] * (v ? v[c] : 1);   dv[c] += sum_f m[f / fdiv] * t[f][c]
+__global__ void frame_table_kernel(const float* __restrict__ m, int fdiv, const float* __restrict__ v, float* __restrict__ out, int F, int C) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)F * C) return;
+    const int f = (int)(i / C), c = (int)(i % C);
+    out[i] = m[f / fdiv] * (v ? v[c] : 1.f);
+}
+__global__ void frame_wcolsum_kernel(const float* __restrict__ t, const float* __restrict__ m, int fdiv, float* __restrict__ dv, int F, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float acc = 0.f;
+    for (int f = 0; f < F; ++f) acc += m[f / fdiv] * t[(long)f * C + c];
+    dv[c] += acc;
+}
 __global__ void fill_kernel(float* p, float v, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
 
 // compute-dtype view of an fp32 weight: cast in bf16 mode, alias in f32 mode
@@ -151,7 +165,7 @@ int wview(const D& d, int mode, const float* src, void* dst, int R, int K, int K
 
 // ------------------------------------------------------------------------------------------------ saved-record layouts
 struct TemporalSaved {
-    float *mean1, *rstd1, *sc1, *sh1, *mean2, *rstd2, *sc2, *sh2, *alpha, *beta, *mc;
+    float *mean1, *rstd1, *sc1, *sh1, *mean2, *rstd2, *sc2, *sh2, *alpha, *beta, *mc, *mtab;
     void *qkv, *o, *win_c, *wout_c;
     size_t bytes;
     TemporalSaved(const D& d, void* base) {
@@ -159,7 +173,7 @@ struct TemporalSaved {
         const size_t fe = (size_t)d.F * d.E;
         mean1 = a.f32(fe); rstd1 = a.f32(fe); sc1 = a.f32(fe); sh1 = a.f32(fe);
         mean2 = a.f32(fe); rstd2 = a.f32(fe); sc2 = a.f32(fe); sh2 = a.f32(fe);
-        alpha = a.f32(d.E); beta = a.f32(d.E); mc = a.f32(d.E);
+        alpha = a.f32(d.E); beta = a.f32(d.E); mc = a.f32(d.E); mtab = a.f32(fe);
         qkv = a.take((size_t)d.N * 3 * d.E * d.es);
         o = a.take((size_t)d.N * d.E * d.es);
         win_c = a.take((size_t)3 * d.E * d.E * d.es);
@@ -168,7 +182,7 @@ struct TemporalSaved {
     }
 };
 struct SpatialSaved {
-    float *mean1, *rstd1, *sc1, *sh1, *mean2, *rstd2, *sc2, *sh2, *mean3, *rstd3, *sc3, *sh3, *alpha, *beta, *mc;
+    float *mean1, *rstd1, *sc1, *sh1, *mean2, *rstd2, *sc2, *sh2, *mean3, *rstd3, *sc3, *sh3, *alpha, *beta, *mc, *mtab, *gtab;
     void *qkv, *o, *x1, *pre, *hid, *z, *win_c, *wout_c, *w1_c, *w2_c;
     size_t bytes;
     SpatialSaved(const D& d, void* base) {
@@ -177,7 +191,7 @@ struct SpatialSaved {
         mean1 = a.f32(fe); rstd1 = a.f32(fe); sc1 = a.f32(fe); sh1 = a.f32(fe);
         mean2 = a.f32(fe); rstd2 = a.f32(fe); sc2 = a.f32(fe); sh2 = a.f32(fe);
         mean3 = a.f32(fe); rstd3 = a.f32(fe); sc3 = a.f32(fe); sh3 = a.f32(fe);
-        alpha = a.f32(d.E); beta = a.f32(d.E); mc = a.f32(d.E);
+        alpha = a.f32(d.E); beta = a.f32(d.E); mc = a.f32(d.E); mtab = a.f32(fe); gtab = a.f32(fe);
         qkv = a.take((size_t)d.N * 3 * d.E * d.es);
         o = a.take((size_t)d.N * d.E * d.es);
         x1 = a.take((size_t)d.N * d.E * d.es);
@@ -194,7 +208,7 @@ struct SpatialSaved {
 
 // transient scratch (backward is the larger user)
 struct Scratch {
-    float *G, *csum, *zeros, *ones, *wg, *attn_ws, *in_ws;   // wg: prepared-layout weight gradient scratch
+    float *G, *csum, *zeros, *ones, *wg, *attn_ws, *in_ws, *dgtab;   // wg: prepared-layout weight gradient scratch
     static constexpr long ATTN_WS_FLOATS = 1024L * (4 * 128 + 32 * 16 + 16);
     void *t1, *t3, *t4, *t1b;
     size_t bytes;
@@ -211,6 +225,7 @@ struct Scratch {
         wg = a.f32(wgn);
         attn_ws = a.f32(ATTN_WS_FLOATS);
         in_ws = a.f32((size_t)2 * d.F * d.E);
+        dgtab = a.f32((size_t)d.F * d.E);
         // activation-sized transients; embed/debed stages work at up to (patch/2)^2 * N pixels of E/4 (or cin/cout) channels
         size_t tok = (size_t)d.N * d.E;
         size_t big = tok * 4;
@@ -244,12 +259,13 @@ int qkv_gemm(const D& d, const void* x, const float* sc, const float* sh, const 
 }
 // out = x + alpha * (affine(o) @ W^T) + beta
 int outproj_gemm(const D& d, const void* o, const float* sc, const float* sh, const void* w_c, const float* alpha, const float* beta,
-                 const void* resid, void* out, hipStream_t st) {
+                 const void* resid, void* out, const float* drop, long rows_per_group, hipStream_t st) {
     bf_operand A = op_plain(o, d.E, BF_LAY_KC);
     op_affine(A, BF_PRO_AFFINE, sc, sh, d.S, d.E);
     bf_operand Bo = op_plain(w_c, d.E, BF_LAY_KC);
     bf_epilogue e = epi_store(out, d.E);
     e.colscale = alpha; e.colshift = beta; e.aux_mode = BF_AUX_ADD; e.aux = resid; e.ld_aux = d.E;
+    e.rowscale = drop; e.rows_per_group = (int)rows_per_group;
     return bf_gemm(d.dtype, (int)d.N, d.E, d.E, &A, &Bo, &e, 1, st);
 }
 // backward of the folded out-projection: param grads + don = (dout * alpha) @ W
@@ -314,7 +330,8 @@ extern "C" int64_t bf_spatial_saved_bytes(const bf_dims* s) { D d; if (get_dims(
 extern "C" int64_t bf_scratch_bytes(const bf_dims* s) { D d; if (get_dims(s, &d)) return -1; return (int64_t)Scratch(d, nullptr).bytes; }
 
 // ================================================================================================= temporal block
-extern "C" int bf_temporal_fwd(const bf_dims* dims, const bf_temporal_params* p, const void* x, void* out, void* saved, void* scratch, bf_stream_t s) {
+extern "C" int bf_temporal_fwd(const bf_dims* dims, const bf_temporal_params* p, const void* x, void* out, void* saved, void* scratch,
+                               const float* drop, bf_stream_t s) {
     D d; TRY(get_dims(dims, &d));
     BF_REQUIRE(p && x && out && saved && scratch, "bf_temporal_fwd: null pointer");
     hipStream_t st = (hipStream_t)s;
@@ -331,12 +348,12 @@ extern "C" int bf_temporal_fwd(const bf_dims* dims, const bf_temporal_params* p,
     hipLaunchKernelGGL(outproj_prep_kernel, dim3(d.E), dim3(256), 0, st, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma,
                        (const float*)nullptr, (const float*)nullptr, sv.alpha, sv.beta, sv.mc, d.E);
     BF_CHECK_LAUNCH();
-    TRY(outproj_gemm(d, sv.o, sv.sc2, sv.sh2, wout_c, sv.alpha, sv.beta, x, out, st));
+    TRY(outproj_gemm(d, sv.o, sv.sc2, sv.sh2, wout_c, sv.alpha, sv.beta, x, out, drop, (long)d.T * d.S, st));   // mask per batch element
     return 0;
 }
 
 extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p, const bf_temporal_params* g, const void* x, const void* dout,
-                               void* dx, void* saved, void* scratch, bf_stream_t s) {
+                               void* dx, void* saved, void* scratch, const float* drop, bf_stream_t s) {
     D d; TRY(get_dims(dims, &d));
     BF_REQUIRE(p && g && x && dout && dx && saved && scratch, "bf_temporal_bwd: null pointer");
     hipStream_t st = (hipStream_t)s;
@@ -348,7 +365,14 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
     void* don = sc.t1;      // [N][E]
     void* dO = sc.t1b;      // [N][E]
     void* dqkv = sc.t3;     // [N][3E]
-    TRY(outproj_bwd(d, sc, dout, sv.o, sv.sc2, sv.sh2, wout_c, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr,
+    const void* dbr = dout; // gradient entering the attention branch
+    if (drop) {             // branch = drop[b] * (...): scale the incoming gradient once (2U pass), the rest is unchanged
+        hipLaunchKernelGGL(frame_table_kernel, dim3(bf_cdiv(d.F * d.E, 256)), dim3(256), 0, st, drop, d.T, (const float*)nullptr, sv.mtab, (int)d.F, d.E);
+        BF_CHECK_LAUNCH();
+        TRY(bf_affine_apply(d.dtype, dout, nullptr, sv.mtab, sc.zeros, sc.t4, d.N, (int)d.S, d.E, st));
+        dbr = sc.t4;
+    }
+    TRY(outproj_bwd(d, sc, dbr, sv.o, sv.sc2, sv.sh2, wout_c, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr,
                     sv.alpha, sv.mc, g->output_head_w, g->output_head_b, nullptr, g->gamma, nullptr, nullptr, don, /*tmp*/ sc.t1b, st));
     TRY(bf_in_bwd(d.dtype, don, sv.o, nullptr, dO, (int)d.F, (int)d.S, d.E, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, nullptr, 1, 0,
                   g->norm2_w, g->norm2_b, nullptr, nullptr, sc.in_ws, st));
@@ -363,7 +387,8 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
 }
 
 // ================================================================================================= axial (spatial) block
-extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, const void* x, void* out, void* saved, void* scratch, bf_stream_t s) {
+extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, const void* x, void* out, void* saved, void* scratch,
+                              const float* drop_att, const float* drop_mlp, bf_stream_t s) {
     D d; TRY(get_dims(dims, &d));
     BF_REQUIRE(p && x && out && saved && scratch, "bf_spatial_fwd: null pointer");
     hipStream_t st = (hipStream_t)s;
@@ -385,7 +410,7 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
     hipLaunchKernelGGL(outproj_prep_kernel, dim3(d.E), dim3(256), 0, st, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att,
                        d.feat_scale ? p->low_freq_scalar : nullptr, d.feat_scale ? p->high_freq_scalar : nullptr, sv.alpha, sv.beta, sv.mc, d.E);
     BF_CHECK_LAUNCH();
-    TRY(outproj_gemm(d, sv.o, sv.sc2, sv.sh2, wout_c, sv.alpha, sv.beta, x, sv.x1, st));
+    TRY(outproj_gemm(d, sv.o, sv.sc2, sv.sh2, wout_c, sv.alpha, sv.beta, x, sv.x1, drop_att, d.S, st));     // mask per frame
     {   // pre = x1 @ W1^T + b1 ; hid = gelu(pre) (both kept: pre for gelu', hid as the fc2 operand -- no erf in any prologue)
         bf_operand A = op_plain(sv.x1, d.E, BF_LAY_KC);
         bf_operand Bo = op_plain(w1_c, d.E, BF_LAY_KC);
@@ -401,15 +426,22 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
         e.bias = p->fc2_b;
         TRY(bf_gemm(d.dtype, (int)d.N, d.E, 4 * d.E, &A, &Bo, &e, 1, st));
     }
-    // out = x1 + gamma_mlp * InstanceNorm(z)
-    TRY(bf_in_stats(d.dtype, sv.z, (int)d.F, (int)d.S, d.E, p->mlp_norm_w, p->mlp_norm_b, p->gamma_mlp, (int)d.F, nullptr, sv.mean3, sv.rstd3,
+    // out = x1 + drop_mlp[f] * gamma_mlp * InstanceNorm(z): the per-(frame, channel) factor rides in the InstanceNorm affine
+    const float* g3 = p->gamma_mlp;
+    int g3div = (int)d.F;
+    if (drop_mlp) {
+        hipLaunchKernelGGL(frame_table_kernel, dim3(bf_cdiv(d.F * d.E, 256)), dim3(256), 0, st, drop_mlp, 1, (const float*)p->gamma_mlp, sv.gtab, (int)d.F, d.E);
+        BF_CHECK_LAUNCH();
+        g3 = sv.gtab; g3div = 1;
+    }
+    TRY(bf_in_stats(d.dtype, sv.z, (int)d.F, (int)d.S, d.E, p->mlp_norm_w, p->mlp_norm_b, g3, g3div, nullptr, sv.mean3, sv.rstd3,
                     sv.sc3, sv.sh3, st));
     TRY(bf_affine_apply(d.dtype, sv.z, sv.x1, sv.sc3, sv.sh3, out, d.N, (int)d.S, d.E, st));
     return 0;
 }
 
 extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, const bf_spatial_params* g, const void* x, const void* dout,
-                              void* dx, void* saved, void* scratch, bf_stream_t s) {
+                              void* dx, void* saved, void* scratch, const float* drop_att, const float* drop_mlp, bf_stream_t s) {
     D d; TRY(get_dims(dims, &d));
     BF_REQUIRE(p && g && x && dout && dx && saved && scratch, "bf_spatial_bwd: null pointer");
     hipStream_t st = (hipStream_t)s;
@@ -423,6 +455,13 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     ZERO(sc.zeros, (size_t)4 * d.E * 4);
     // out = x1 + gamma_mlp * IN(z)
     void* dz = sc.t1;
+    if (drop_mlp) {   // gtab[f][c] = drop_mlp[f] * gamma_mlp[c] was the scale: its gradient comes back per frame, then d gamma = sum_f drop * dgtab
+        ZERO(sc.dgtab, (size_t)d.F * d.E * 4);
+        TRY(bf_in_bwd(d.dtype, dout, sv.z, nullptr, dz, (int)d.F, (int)d.S, d.E, sv.mean3, sv.rstd3, p->mlp_norm_w, p->mlp_norm_b, sv.gtab, 1, 0,
+                      g->mlp_norm_w, g->mlp_norm_b, sc.dgtab, nullptr, sc.in_ws, st));
+        hipLaunchKernelGGL(frame_wcolsum_kernel, dim3(bf_cdiv(d.E, 64)), dim3(64), 0, st, (const float*)sc.dgtab, drop_mlp, 1, g->gamma_mlp, (int)d.F, d.E);
+        BF_CHECK_LAUNCH();
+    } else
     TRY(bf_in_bwd(d.dtype, dout, sv.z, nullptr, dz, (int)d.F, (int)d.S, d.E, sv.mean3, sv.rstd3, p->mlp_norm_w, p->mlp_norm_b, p->gamma_mlp,
                   (int)d.F, 0, g->mlp_norm_w, g->mlp_norm_b, g->gamma_mlp, nullptr, sc.in_ws, st));
     // fc2: z = gelu(pre) @ W2^T + b2 ; dpre = (dz @ W2) * gelu'(pre)
@@ -441,7 +480,14 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     }
     // folded out-projection
     void* don = sc.t1;      // dz is dead
-    TRY(outproj_bwd(d, sc, dx1, sv.o, sv.sc2, sv.sh2, wout_c, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att,
+    const void* dbr = dx1;  // gradient entering the attention branch (dx1 itself continues down the residual)
+    if (drop_att) {
+        hipLaunchKernelGGL(frame_table_kernel, dim3(bf_cdiv(d.F * d.E, 256)), dim3(256), 0, st, drop_att, 1, (const float*)nullptr, sv.mtab, (int)d.F, d.E);
+        BF_CHECK_LAUNCH();
+        TRY(bf_affine_apply(d.dtype, dx1, nullptr, sv.mtab, sc.zeros, sc.t3, d.N, (int)d.S, d.E, st));    // t3 (dqkv) is not live yet
+        dbr = sc.t3;
+    }
+    TRY(outproj_bwd(d, sc, dbr, sv.o, sv.sc2, sv.sh2, wout_c, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att,
                     d.feat_scale ? p->low_freq_scalar : nullptr, d.feat_scale ? p->high_freq_scalar : nullptr, sv.alpha, sv.mc,
                     g->output_head_w, g->output_head_b, g->norm2_b, g->gamma_att, d.feat_scale ? g->low_freq_scalar : nullptr,
                     d.feat_scale ? g->high_freq_scalar : nullptr, don, /*tmp: dpre is dead*/ sc.t4, st));

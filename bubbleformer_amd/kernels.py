@@ -14,8 +14,8 @@ def operand(t=None, ld=0, layout=L.BF_LAY_KC, seglen=0, segstride=0, gw=0, gh=0,
 
 
 def epilogue(c, ldc, bias=None, colscale=None, colshift=None, aux_mode=L.BF_AUX_NONE, aux=None, ld_aux=0, out_mode=L.BF_OUT_STORE,
-             seglen=0, segstride=0, gw=0, gh=0, gc=0, gelu_out=None, colsum=None) -> L.Epilogue:
-    return L.Epilogue(_p(bias), _p(colscale), _p(colshift), aux_mode, _p(aux), ld_aux, out_mode, _p(c), ldc, seglen, segstride, gw, gh, gc, _p(gelu_out), _p(colsum))
+             seglen=0, segstride=0, gw=0, gh=0, gc=0, gelu_out=None, colsum=None, rowscale=None, rows_per_group=0) -> L.Epilogue:
+    return L.Epilogue(_p(bias), _p(colscale), _p(colshift), aux_mode, _p(aux), ld_aux, out_mode, _p(c), ldc, seglen, segstride, gw, gh, gc, _p(gelu_out), _p(colsum), _p(rowscale), rows_per_group)
 
 
 def gemm(dtype, M, N, K, A: L.Operand, B: L.Operand, E: L.Epilogue, splitk=1):

@@ -12,25 +12,32 @@ from .linear_layers import GeluMLP
 from .positional_encoding import RelativePositionBias
 
 
-class _StochasticDepthUnsupported(nn.Module):
-    """Placeholder for timm.layers.DropPath (layers/attention.py:64,194): stochastic depth is not wired into the fused
-    epilogues yet, so a training-mode forward with drop_path > 0 raises instead of silently skipping it."""
+class DropPath(nn.Module):
+    """Stochastic depth holder (timm.layers.DropPath at layers/attention.py:64,194).  The mask multiply itself runs inside
+    the fused stage (per-sample factor in the out-projection epilogue / the MLP branch's InstanceNorm affine); this module
+    only carries the rate and draws the per-sample factors in training mode."""
 
-    def __init__(self, p: float):
+    def __init__(self, drop_prob: float = 0.0, scale_by_keep: bool = True):
         super().__init__()
-        self.drop_prob = p
+        self.drop_prob = float(drop_prob)
+        self.scale_by_keep = scale_by_keep
+
+    def factors(self, n: int, device):
+        if not self.training or self.drop_prob <= 0.0:
+            return None
+        return ops.drop_path_factors(n, self.drop_prob, device)
+
+    def extra_repr(self):
+        return f"drop_prob={self.drop_prob:0.3f}"
 
 
 def _make_drop_path(p: float):
-    return _StochasticDepthUnsupported(p) if p > 0.0 else nn.Identity()
+    return DropPath(p) if p > 0.0 else nn.Identity()
 
 
-def _check_drop_path(mod: nn.Module):
+def _factors(mod: nn.Module, n: int, device):
     dp = mod.drop_path
-    if isinstance(dp, _StochasticDepthUnsupported) and mod.training:
-        raise NotImplementedError(
-            f"drop_path={dp.drop_prob} in training mode: stochastic depth is not implemented in the HIP blocks yet; "
-            "build the model with drop_path=0.0 or call .eval()")
+    return dp.factors(n, device) if isinstance(dp, DropPath) else None
 
 
 class AttentionBlock(nn.Module):
@@ -62,9 +69,11 @@ class AttentionBlock(nn.Module):
                 self.output_head.bias, self.qnorm.weight, self.qnorm.bias, self.knorm.weight, self.knorm.bias,
                 self.rel_pos_bias.relative_attention_bias.weight]
 
-    def forward_tokens(self, tok: torch.Tensor) -> torch.Tensor:
-        _check_drop_path(self)
-        return ops.temporal_block(tok, self.num_heads, self.attn_scale, self.stage_params())
+    def forward_tokens(self, tok: torch.Tensor, drop=None) -> torch.Tensor:
+        """drop: explicit [B] stochastic-depth factors (tests); drawn here in training mode when the block has a rate."""
+        if drop is None:
+            drop = _factors(self, tok.shape[0], tok.device)            # dim 0 of the reference's (B, n, emb, h, w) input
+        return ops.temporal_block(tok, self.num_heads, self.attn_scale, self.stage_params(), drop)
 
     def forward(self, x):
         """x: (B, N, emb, H, W) -> same."""
@@ -111,10 +120,15 @@ class AxialAttentionBlock(nn.Module):
                 self.rel_pos_bias.relative_attention_bias.weight, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight,
                 self.mlp.fc2.bias, self.mlp_norm.weight, self.mlp_norm.bias]
 
-    def forward_tokens(self, tok: torch.Tensor) -> torch.Tensor:
-        """tok: (B, T, h, w, E); frames are independent, so any leading (B, T) split of B*T frames is equivalent."""
-        _check_drop_path(self)
-        return ops.spatial_block(tok, self.num_heads, self.attn_scale, self.feat_scale, self.stage_params())
+    def forward_tokens(self, tok: torch.Tensor, drop_att=None, drop_mlp=None) -> torch.Tensor:
+        """tok: (B, T, h, w, E); frames are independent, so any leading (B, T) split of B*T frames is equivalent.
+        Two independent masks over dim 0 = B*T of the reference's (B*T, emb, h, w) input (attention.py:309,317)."""
+        nf = tok.shape[0] * tok.shape[1]
+        if drop_att is None:
+            drop_att = _factors(self, nf, tok.device)
+        if drop_mlp is None:
+            drop_mlp = _factors(self, nf, tok.device)
+        return ops.spatial_block(tok, self.num_heads, self.attn_scale, self.feat_scale, self.stage_params(), drop_att, drop_mlp)
 
     def forward(self, x):
         """x: (B, emb, H, W) -> same."""

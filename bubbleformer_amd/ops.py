@@ -138,7 +138,8 @@ class _BlockFn(torch.autograd.Function):
     """Shared driver for the temporal and the axial block."""
 
     @staticmethod
-    def forward(ctx, x, kind, heads, attn_scale, feat_scale, *params):
+    def forward(ctx, x, kind, heads, attn_scale, feat_scale, drop_a, drop_b, *params):
+        # drop_a / drop_b: per-sample stochastic-depth factors (0 or 1/keep) or None
         _require_gpu(x)
         x = x.contiguous()
         B, T, h, w, E = x.shape
@@ -154,7 +155,14 @@ class _BlockFn(torch.autograd.Function):
             saved = _saved(lib.bf_spatial_saved_bytes(C.byref(d)), x.device, "bf_spatial_saved_bytes")
             fwd = lib.bf_spatial_fwd
         out = torch.empty_like(x)
-        L.check(fwd(C.byref(d), C.byref(st), _p(x), _p(out), _p(saved), _p(scratch_for(d, x.device)), _stream()), f"bf_{kind}_fwd")
+        drop_a = None if drop_a is None else drop_a.contiguous().float()
+        drop_b = None if drop_b is None else drop_b.contiguous().float()
+        if kind == "temporal":
+            rc = fwd(C.byref(d), C.byref(st), _p(x), _p(out), _p(saved), _p(scratch_for(d, x.device)), _p(drop_a), _stream())
+        else:
+            rc = fwd(C.byref(d), C.byref(st), _p(x), _p(out), _p(saved), _p(scratch_for(d, x.device)), _p(drop_a), _p(drop_b), _stream())
+        L.check(rc, f"bf_{kind}_fwd")
+        ctx.drops = (drop_a, drop_b)
         ctx.kind, ctx.cfg = kind, (heads, attn_scale, feat_scale)
         ctx.save_for_backward(x, saved, *[p for p in params if p is not None])
         ctx.mask = [p is not None for p in params]
@@ -176,20 +184,34 @@ class _BlockFn(torch.autograd.Function):
         else:
             st, gs, bwd = L.SpatialParams(*[_p(p) for p in params]), L.SpatialParams(*[_p(g) for g in gviews]), lib.bf_spatial_bwd
         dx = torch.empty_like(x)
-        L.check(bwd(C.byref(d), C.byref(st), C.byref(gs), _p(x), _p(dout), _p(dx), _p(saved), _p(scratch_for(d, x.device)), _stream()),
-                f"bf_{ctx.kind}_bwd")
+        drop_a, drop_b = ctx.drops
+        if ctx.kind == "temporal":
+            rc = bwd(C.byref(d), C.byref(st), C.byref(gs), _p(x), _p(dout), _p(dx), _p(saved), _p(scratch_for(d, x.device)), _p(drop_a), _stream())
+        else:
+            rc = bwd(C.byref(d), C.byref(st), C.byref(gs), _p(x), _p(dout), _p(dx), _p(saved), _p(scratch_for(d, x.device)), _p(drop_a),
+                     _p(drop_b), _stream())
+        L.check(rc, f"bf_{ctx.kind}_bwd")
         _stage_done(params, direct)
-        return (dx, None, None, None, None, *ret)
+        return (dx, None, None, None, None, None, None, *ret)
 
 
-def temporal_block(x: torch.Tensor, heads: int, attn_scale: bool, params: List[Optional[torch.Tensor]]) -> torch.Tensor:
-    """x: (B, T, h, w, E) tokens.  params in ``_lib.TEMPORAL_FIELDS`` order (None where the reference has no parameter)."""
-    return _BlockFn.apply(x, "temporal", heads, attn_scale, True, *params)
+def temporal_block(x: torch.Tensor, heads: int, attn_scale: bool, params: List[Optional[torch.Tensor]], drop=None) -> torch.Tensor:
+    """x: (B, T, h, w, E) tokens.  params in ``_lib.TEMPORAL_FIELDS`` order (None where the reference has no parameter).
+    drop: optional [B] stochastic-depth factors (0 or 1/keep) for the attention branch."""
+    return _BlockFn.apply(x, "temporal", heads, attn_scale, True, drop, None, *params)
 
 
-def spatial_block(x: torch.Tensor, heads: int, attn_scale: bool, feat_scale: bool, params: List[Optional[torch.Tensor]]) -> torch.Tensor:
-    """x: (B, T, h, w, E) tokens (frames = B*T).  params in ``_lib.SPATIAL_FIELDS`` order."""
-    return _BlockFn.apply(x, "spatial", heads, attn_scale, feat_scale, *params)
+def spatial_block(x: torch.Tensor, heads: int, attn_scale: bool, feat_scale: bool, params: List[Optional[torch.Tensor]], drop_att=None,
+                  drop_mlp=None) -> torch.Tensor:
+    """x: (B, T, h, w, E) tokens (frames = B*T).  params in ``_lib.SPATIAL_FIELDS`` order.
+    drop_att / drop_mlp: optional [B*T] stochastic-depth factors for the attention and the MLP branch."""
+    return _BlockFn.apply(x, "spatial", heads, attn_scale, feat_scale, drop_att, drop_mlp, *params)
+
+
+def drop_path_factors(n: int, drop_prob: float, device) -> torch.Tensor:
+    """timm.layers.DropPath semantics (scale_by_keep=True): one Bernoulli(keep) / keep factor per sample of dim 0."""
+    keep = 1.0 - drop_prob
+    return torch.empty(n, dtype=torch.float32, device=device).bernoulli_(keep).div_(keep)
 
 
 # ------------------------------------------------------------------------------------------------ embed / debed

@@ -83,6 +83,8 @@ typedef struct bf_epilogue {
     int32_t gw, gh, gc;
     void* gelu_out;         /* optional second output (activation dtype, same addressing as c): gelu(value stored to c) */
     float* colsum;          /* token-reduction form only (A outer-contiguous): colsum[m] += sum_k A[k][m] (bias gradient) */
+    const float* rowscale;  /* optional per-row-group factor applied to the value before aux / store (stochastic depth) */
+    int32_t rows_per_group; /* group = row / rows_per_group */
 } bf_epilogue;
 
 /* C[M,N] (+)= epi( sum_k pro(A)[m,k] * pro(B)[n,k] ).  splitk > 1 requires BF_OUT_ATOMIC_F32. */
@@ -187,12 +189,16 @@ int64_t bf_debed_saved_bytes(const bf_dims* d);
 int64_t bf_scratch_bytes(const bf_dims* d);
 
 /* x, out, dout, dx: [N][E] activations.  Gradients ACCUMULATE into `g` (zero it first). */
-int bf_temporal_fwd(const bf_dims* d, const bf_temporal_params* p, const void* x, void* out, void* saved, void* scratch, bf_stream_t s);
+/* Stochastic depth (timm DropPath at layers/attention.py:123,309,317): `drop*` are the per-sample factors (0 or 1/keep) the
+ * caller drew -- [B] for the temporal block (dim 0 = batch), [B*T] each for the two branches of the axial block -- or NULL. */
+int bf_temporal_fwd(const bf_dims* d, const bf_temporal_params* p, const void* x, void* out, void* saved, void* scratch,
+                    const float* drop, bf_stream_t s);
 int bf_temporal_bwd(const bf_dims* d, const bf_temporal_params* p, const bf_temporal_params* g, const void* x, const void* dout,
-                    void* dx, void* saved, void* scratch, bf_stream_t s);
-int bf_spatial_fwd(const bf_dims* d, const bf_spatial_params* p, const void* x, void* out, void* saved, void* scratch, bf_stream_t s);
+                    void* dx, void* saved, void* scratch, const float* drop, bf_stream_t s);
+int bf_spatial_fwd(const bf_dims* d, const bf_spatial_params* p, const void* x, void* out, void* saved, void* scratch,
+                   const float* drop_att, const float* drop_mlp, bf_stream_t s);
 int bf_spatial_bwd(const bf_dims* d, const bf_spatial_params* p, const bf_spatial_params* g, const void* x, const void* dout,
-                   void* dx, void* saved, void* scratch, bf_stream_t s);
+                   void* dx, void* saved, void* scratch, const float* drop_att, const float* drop_mlp, bf_stream_t s);
 /* x: (B*T, cin, H, W) fp32 clip; fluid: [B][nfluid] fp32 or NULL; out: [N][E].  dx_in (optional): d(loss)/d(clip). */
 int bf_embed_fwd(const bf_dims* d, const bf_embed_params* p, const float* x, const float* fluid, void* out, void* saved, void* scratch, bf_stream_t s);
 int bf_embed_bwd(const bf_dims* d, const bf_embed_params* p, const bf_embed_params* g, const void* dout, float* dx_in, void* saved,

@@ -179,8 +179,11 @@ def _split_heads(qkv: Tensor, heads: int):
     return u[..., :d], u[..., d:2 * d], u[..., 2 * d:]
 
 
-def temporal_block(sd: SD, pre: str, t: Tensor, heads: int, attn_scale: bool = True) -> Tensor:
-    """t: [B, T, h, w, E] -> same.  Attention along T for every (b, y, x, head)."""
+def temporal_block(sd: SD, pre: str, t: Tensor, heads: int, attn_scale: bool = True, drop: Optional[Tensor] = None) -> Tensor:
+    """t: [B, T, h, w, E] -> same.  Attention along T for every (b, y, x, head).
+    drop: optional [B] stochastic-depth factors (0 or 1/keep) -- timm.layers.DropPath's published behaviour (per-sample
+    Bernoulli(keep) mask on dim 0, scaled by 1/keep; the package is absent from the reference tree, so this leg is
+    parity-UNPINNED and only cross-checks the HIP path against the same explicit masks)."""
     B, T, h, w, E = t.shape
     xn = instance_norm_tokens(t.reshape(B * T, h * w, E), sd[f"{pre}norm1.weight"], sd[f"{pre}norm1.bias"])
     qkv = xn @ sd[f"{pre}input_head.weight"].reshape(3 * E, E).t() + sd[f"{pre}input_head.bias"]
@@ -194,10 +197,14 @@ def temporal_block(sd: SD, pre: str, t: Tensor, heads: int, attn_scale: bool = T
     o = o.permute(0, 4, 1, 2, 3, 5).reshape(B * T, h * w, E)
     on = instance_norm_tokens(o, sd[f"{pre}norm2.weight"], sd[f"{pre}norm2.bias"])
     y = on @ sd[f"{pre}output_head.weight"].reshape(E, E).t() + sd[f"{pre}output_head.bias"]
-    return t + (y * sd[f"{pre}gamma"]).reshape(B, T, h, w, E)
+    br = (y * sd[f"{pre}gamma"]).reshape(B, T, h, w, E)
+    if drop is not None:
+        br = br * drop.reshape(B, 1, 1, 1, 1)
+    return t + br
 
 
-def spatial_block(sd: SD, pre: str, t: Tensor, heads: int, attn_scale: bool = True, feat_scale: bool = True) -> Tensor:
+def spatial_block(sd: SD, pre: str, t: Tensor, heads: int, attn_scale: bool = True, feat_scale: bool = True,
+                  drop_att: Optional[Tensor] = None, drop_mlp: Optional[Tensor] = None) -> Tensor:
     """t: [F, h, w, E] -> same.  Axial attention along w and along h (shared
     q/k/v and shared bias table), averaged; feature scaling; MLP + InstanceNorm."""
     Fr, h, w, E = t.shape
@@ -221,11 +228,17 @@ def spatial_block(sd: SD, pre: str, t: Tensor, heads: int, attn_scale: bool = Tr
     if feat_scale:
         m = y.mean(dim=1, keepdim=True)
         y = y + m * sd[f"{pre}low_freq_scalar"] + (y - m) * sd[f"{pre}high_freq_scalar"]
-    x1 = t.reshape(Fr, h * w, E) + y * sd[f"{pre}gamma_att"]
+    br = y * sd[f"{pre}gamma_att"]
+    if drop_att is not None:
+        br = br * drop_att.reshape(Fr, 1, 1)
+    x1 = t.reshape(Fr, h * w, E) + br
     hid = gelu(x1 @ sd[f"{pre}mlp.fc1.weight"].t() + sd[f"{pre}mlp.fc1.bias"])
     z = hid @ sd[f"{pre}mlp.fc2.weight"].t() + sd[f"{pre}mlp.fc2.bias"]
     zn = instance_norm_tokens(z, sd[f"{pre}mlp_norm.weight"], sd[f"{pre}mlp_norm.bias"])
-    return (x1 + zn * sd[f"{pre}gamma_mlp"]).reshape(Fr, h, w, E)
+    br2 = zn * sd[f"{pre}gamma_mlp"]
+    if drop_mlp is not None:
+        br2 = br2 * drop_mlp.reshape(Fr, 1, 1)
+    return (x1 + br2).reshape(Fr, h, w, E)
 
 
 # --------------------------------------------------------------------------- #

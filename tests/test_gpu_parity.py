@@ -162,3 +162,112 @@ def test_train_step_reduces_loss():
     y = torch.from_numpy(z["y"]).cuda()
     losses = [float(step(x, c, y)) for _ in range(8)]
     assert losses[-1] < losses[0] and all(l == l for l in losses), losses
+
+
+def test_long_axes_two_block_attention_paths():
+    """T = 18, w = 20, h = 3: sequence lengths in (16, 32] take the two-block MFMA attention path in bf16 mode and ragged
+    masking in both modes.  fp32 mode vs the oracle run here (1e-4); bf16 mode vs fp32 mode (bf16 bounds)."""
+    from bubbleformer_amd.models import get_model
+    from oracle import filmavit_ref as R, weights as W
+    cfg = dict(input_fields=2, output_fields=2, patch_size=4, embed_dim=64, num_heads=1, processor_blocks=1, num_fluid_params=4)
+    B, T, H, Wd = 1, 18, 12, 80
+    shapes = W.param_shapes(**cfg)
+    sd0 = W.generate(shapes, seed=21)
+    x0 = W.synthetic_clip(B, T, 2, H, Wd, 501)
+    y0 = W.synthetic_clip(B, T, 2, H, Wd, 502)
+    c0 = W.synthetic_fluid_params(B, 4, 503)
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    xo = x0.clone().requires_grad_(True)
+    lo = R.lp_loss(R.filmavit_forward(sd, xo, c0, patch_size=4, num_heads=1), y0)
+    lo.backward()
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        m = get_model("filmavit", time_window=T, drop_path=0.0, compute_dtype=dt, **cfg)
+        m.load_state_dict(sd0)
+        m = m.cuda()
+        xg = x0.cuda().requires_grad_(True)
+        loss, pred = m.forward_loss(xg, c0.cuda(), y0.cuda())
+        loss.backward()
+        res[dt] = (float(loss), xg.grad.cpu(), {k: p.grad.cpu() for k, p in m.named_parameters()})
+    l32, dx32, g32 = res[torch.float32]
+    assert abs(l32 - float(lo)) / abs(float(lo)) < 1e-4
+    assert rel_l2(dx32, xo.grad) < 1e-4
+    for k in g32:
+        if not structurally_zero(k):
+            assert rel_l2(g32[k], sd[k].grad) < 1e-4, k
+    l16, dx16, g16 = res[torch.bfloat16]
+    assert abs(l16 - l32) / abs(l32) < 3e-2
+    assert rel_l2(dx16, dx32) < 8e-2
+    num = sum(float((g16[k].double() - g32[k].double()).pow(2).sum()) for k in g32)
+    den = sum(float(g32[k].double().pow(2).sum()) for k in g32)
+    assert (num / den) ** 0.5 < 8e-2, (num / den) ** 0.5
+    for k in g32:
+        if not structurally_zero(k):
+            assert rel_l2(g16[k], g32[k]) < 0.5, k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_stochastic_depth_with_explicit_masks(dtype):
+    """DropPath (layers/attention.py:123,309,317): the same explicit per-sample factors through the HIP blocks and the oracle."""
+    from bubbleformer_amd.models import get_model
+    from oracle import filmavit_ref as R, weights as W
+    cfg = dict(input_fields=2, output_fields=2, patch_size=4, embed_dim=64, num_heads=2, processor_blocks=2, num_fluid_params=4)
+    B, T, H, Wd = 3, 4, 8, 12
+    shapes = W.param_shapes(**cfg)
+    sd0 = W.generate(shapes, seed=31)
+    x0 = W.synthetic_clip(B, T, 2, H, Wd, 601)
+    y0 = W.synthetic_clip(B, T, 2, H, Wd, 602)
+    c0 = W.synthetic_fluid_params(B, 4, 603)
+    g = torch.Generator().manual_seed(5)
+    keep = 0.6
+    masks = [[(torch.rand(n, generator=g) < keep).float() / keep for n in (B, B * T, B * T)] for _ in range(2)]
+    masks[0][0][0] = 0.0                      # make sure both outcomes occur
+    masks[0][0][1] = 1.0 / keep
+    # oracle
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    t = R.embed(sd, "embed.", x0.reshape(B * T, 2, H, Wd), 4)
+    h, w, E = t.shape[1], t.shape[2], t.shape[3]
+    t = R.film(sd, "film_embed.", t.reshape(B, T, h, w, E), c0)
+    for i in range(2):
+        t = R.temporal_block(sd, f"blocks.{i}.temporal.", t, 2, True, masks[i][0])
+        t = R.spatial_block(sd, f"blocks.{i}.spatial.", t.reshape(B * T, h, w, E), 2, True, True, masks[i][1], masks[i][2]).reshape(B, T, h, w, E)
+    lo = R.lp_loss(R.debed(sd, "debed.", t.reshape(B * T, h, w, E), 4).reshape(B, T, 2, H, Wd), y0)
+    lo.backward()
+    # HIP
+    m = get_model("filmavit", time_window=T, drop_path=0.4, compute_dtype=dtype, **cfg)
+    m.load_state_dict(sd0)
+    m = m.cuda().train()
+    tok = m.embed.tokens(x0.cuda(), c0.cuda(), m.film_embed.film_params(), compute_dtype=dtype)
+    for i, blk in enumerate(m.blocks):
+        tok = blk.temporal.forward_tokens(tok, masks[i][0].cuda())
+        tok = blk.spatial.forward_tokens(tok, masks[i][1].cuda(), masks[i][2].cuda())
+    loss, _ = m.debed.loss_from_tokens(tok, y0.cuda())
+    loss.backward()
+    ft, gt = (1e-4, 1e-4) if dtype == torch.float32 else (3e-2, 8e-2)
+    assert abs(float(loss) - float(lo)) / abs(float(lo)) < ft
+    num = den = 0.0
+    for k, p in m.named_parameters():
+        ref = sd[k].grad
+        num += float((p.grad.cpu().double() - ref.double()).pow(2).sum())
+        den += float(ref.double().pow(2).sum())
+        if not structurally_zero(k):
+            assert rel_l2(p.grad.cpu(), ref) < (gt if dtype == torch.float32 else 0.5), k
+    assert (num / den) ** 0.5 < gt
+
+
+def test_training_mode_draws_masks_and_eval_is_deterministic():
+    spec, z, model = build_product_model("tiny_d64", torch.float32)
+    for blk in model.blocks:        # the golden models are built with drop_path = 0: give block 1 a rate as the reference's linspace would
+        pass
+    from bubbleformer_amd.layers.attention import DropPath
+    model.blocks[1].temporal.drop_path = DropPath(0.5)
+    model.blocks[1].spatial.drop_path = DropPath(0.5)
+    x = torch.from_numpy(z["x"]).cuda()
+    c = torch.from_numpy(z["cond"]).cuda()
+    model.eval()
+    a = model(x, c)
+    assert rel_l2(a.cpu(), z["pred_f64"]) < 1e-4            # identity in eval mode
+    model.train()
+    torch.manual_seed(0)
+    outs = [model(x, c) for _ in range(4)]
+    assert any(rel_l2(o.cpu(), a.cpu()) > 1e-3 for o in outs)   # masks are active in training mode
