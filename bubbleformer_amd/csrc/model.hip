@@ -156,6 +156,29 @@ __global__ void frame_wcolsum_kernel(const float* __restrict__ t, const float* _
 }
 __global__ void fill_kernel(float* p, float v, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
 
+// up to four plain fp32 -> bf16 weight casts in ONE launch (a stage's projection weights)
+struct Cast4 { const float* src[4]; bf16* dst[4]; long n[4]; };
+__global__ void __launch_bounds__(256) cast4_kernel(Cast4 j) {
+    const int w = blockIdx.y;
+    const long n4 = j.n[w] / 4;
+    const float4* s4 = reinterpret_cast<const float4*>(j.src[w]);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = s4[i];
+        const bf16x4 o = {(bf16)v.x, (bf16)v.y, (bf16)v.z, (bf16)v.w};
+        *reinterpret_cast<bf16x4*>(j.dst[w] + 4 * i) = o;
+    }
+}
+// weights[i] (fp32, count n[i], multiples of 4) -> compute-dtype operands: one cast launch in bf16 mode, aliases in f32 mode
+int wviews(const D& d, int cnt, const float* const* src, void* const* dst, const long* n, const void** out, hipStream_t st) {
+    if (d.dtype == BF_DTYPE_F32) { for (int i = 0; i < cnt; ++i) out[i] = src[i]; return 0; }
+    Cast4 j;
+    for (int i = 0; i < 4; ++i) { j.src[i] = src[i < cnt ? i : 0]; j.dst[i] = (bf16*)dst[i < cnt ? i : 0]; j.n[i] = i < cnt ? n[i] : 0; out[i < cnt ? i : 0] = dst[i < cnt ? i : 0]; }
+    for (int i = 0; i < cnt; ++i) out[i] = dst[i];
+    hipLaunchKernelGGL(cast4_kernel, dim3(64, cnt), dim3(256), 0, st, j);
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
 // compute-dtype view of an fp32 weight: cast in bf16 mode, alias in f32 mode
 int wview(const D& d, int mode, const float* src, void* dst, int R, int K, int Kp, const void** out, hipStream_t st) {
     if (d.dtype == BF_DTYPE_F32 && mode == 0 && Kp == K) { *out = src; return 0; }
@@ -273,8 +296,7 @@ int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* o, 
                 const float* W, const float* bias, const float* nb, const float* gamma, const float* lo, const float* hi,
                 const float* alpha, const float* mc, float* dW, float* dbias, float* dnb, float* dgamma, float* dlo, float* dhi,
                 void* don, void* tmp, hipStream_t st) {
-    ZERO(sc.G, (size_t)d.E * d.E * 4);
-    ZERO(sc.csum, (size_t)d.E * 4);
+    ZERO(sc.G, (size_t)((char*)sc.csum - (char*)sc.G) + (size_t)d.E * 4);     // G and csum are adjacent in the arena: one memset
     {   // G[n][k] = sum_m dout[m][n] * on[m][k].  The normalised operand is materialised first (one 2U element-wise pass,
         // ~7 us) because applying the affine inside the token-reduction GEMM's staging costs ~20 us (tools/gemm_bench.py)
         TRY(bf_affine_apply(d.dtype, o, nullptr, sc2, sh2, tmp, d.N, (int)d.S, d.E, st));
@@ -337,8 +359,14 @@ extern "C" int bf_temporal_fwd(const bf_dims* dims, const bf_temporal_params* p,
     hipStream_t st = (hipStream_t)s;
     TemporalSaved sv(d, saved);
     const void *win_c, *wout_c;
-    TRY(wview(d, 0, p->input_head_w, sv.win_c, 3 * d.E, d.E, d.E, &win_c, st));
-    TRY(wview(d, 0, p->output_head_w, sv.wout_c, d.E, d.E, d.E, &wout_c, st));
+    {
+        const float* src[2] = {p->input_head_w, p->output_head_w};
+        void* dst[2] = {sv.win_c, sv.wout_c};
+        const long n[2] = {3L * d.E * d.E, (long)d.E * d.E};
+        const void* out[4];
+        TRY(wviews(d, 2, src, dst, n, out, st));
+        win_c = out[0]; wout_c = out[1];
+    }
     TRY(bf_in_stats(d.dtype, x, (int)d.F, (int)d.S, d.E, p->norm1_w, p->norm1_b, nullptr, 1, nullptr, sv.mean1, sv.rstd1, sv.sc1, sv.sh1, st));
     TRY(qkv_gemm(d, x, sv.sc1, sv.sh1, win_c, p->input_head_b, sv.qkv, st));
     // sequences along T for every (b, y, x): token = b*T*S + pos + t*S
@@ -394,10 +422,14 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
     hipStream_t st = (hipStream_t)s;
     SpatialSaved sv(d, saved);
     const void *win_c, *wout_c, *w1_c, *w2_c;
-    TRY(wview(d, 0, p->input_head_w, sv.win_c, 3 * d.E, d.E, d.E, &win_c, st));
-    TRY(wview(d, 0, p->output_head_w, sv.wout_c, d.E, d.E, d.E, &wout_c, st));
-    TRY(wview(d, 0, p->fc1_w, sv.w1_c, 4 * d.E, d.E, d.E, &w1_c, st));
-    TRY(wview(d, 0, p->fc2_w, sv.w2_c, d.E, 4 * d.E, 4 * d.E, &w2_c, st));
+    {
+        const float* src[4] = {p->input_head_w, p->output_head_w, p->fc1_w, p->fc2_w};
+        void* dst[4] = {sv.win_c, sv.wout_c, sv.w1_c, sv.w2_c};
+        const long n[4] = {3L * d.E * d.E, (long)d.E * d.E, 4L * d.E * d.E, 4L * d.E * d.E};
+        const void* out[4];
+        TRY(wviews(d, 4, src, dst, n, out, st));
+        win_c = out[0]; wout_c = out[1]; w1_c = out[2]; w2_c = out[3];
+    }
     TRY(bf_in_stats(d.dtype, x, (int)d.F, (int)d.S, d.E, p->norm1_w, p->norm1_b, nullptr, 1, nullptr, sv.mean1, sv.rstd1, sv.sc1, sv.sh1, st));
     TRY(qkv_gemm(d, x, sv.sc1, sv.sh1, win_c, p->input_head_b, sv.qkv, st));
     // along w: one sequence per (frame, row): contiguous tokens
