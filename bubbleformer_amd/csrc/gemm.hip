@@ -320,10 +320,10 @@ int launch(int M, int N, int K, const bf_operand* A, const bf_operand* B, const 
     if (splitk > ktiles) splitk = ktiles;
     const int kper = bf_cdiv(ktiles, splitk) * BK;
     splitk = bf_cdiv(K, kper);
-    // 128 x 128 tiles unless that leaves the chip with fewer than two workgroups per CU: then 64 x 128
     const int nt = bf_cdiv(N, BN);
     static const int small_env = []() { const char* v = getenv("BF_GEMM_SMALL"); return v ? atoi(v) : -1; }();
-    const bool small = small_env >= 0 ? (small_env != 0 && M > 64) : ((long)bf_cdiv(M, 128) * nt * splitk < 512 && M > 64);
+    // measured: with 8-wave workgroups the 128 x 128 tile beats 64 x 128 even on grids of < 2 workgroups per CU
+    const bool small = small_env >= 0 ? (small_env != 0 && M > 64) : (M <= 64);
     const int bm = small ? 64 : 128;
     const int mt = bf_cdiv(M, bm);
     dim3 grid((unsigned)((long)mt * nt * splitk));
@@ -332,8 +332,8 @@ int launch(int M, int N, int K, const bf_operand* A, const bf_operand* B, const 
     static const int dbg = []() { const char* v = getenv("BF_GEMM_DEBUG"); return v ? atoi(v) : 0; }();
     static const int w8env = []() { const char* v = getenv("BF_GEMM_WAVES"); return v ? atoi(v) : 0; }();
     // measured (tools/gemm_bench.py, MI355X): with one register stage, 8 waves of TM x 2 tiles (<= 128 VGPRs: two 8-wave
-    // workgroups per CU) win everywhere except the long-K, narrow-N forward GEMM on a small grid
-    const bool w8 = sizeof(T) == 2 && (w8env == 8 || (w8env == 0 && !(small && !ax && !bx && K >= 1024)));
+    // workgroups per CU) win on every shape of this model
+    const bool w8 = sizeof(T) == 2 && (w8env == 8 || w8env == 0);
     // one profiler name per kernel instantiation, so bench.py's per-kernel averages line up 1:1 with rocprofv3's rows
     static thread_local char pname[96];
     snprintf(pname, sizeof(pname), "gemm_kernel<%s,%s,%s,pro%s,tm%d,w%d>", sizeof(T) == 2 ? "bf16" : "f32", ax ? "xc" : "kc", bx ? "xc" : "kc",

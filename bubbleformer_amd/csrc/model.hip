@@ -67,10 +67,10 @@ bf_epilogue epi_atomic(float* c, long ldc) { bf_epilogue e = epi_store(c, ldc); 
 void epi_scatter(bf_epilogue& e, int gw, int gh, int C) { e.gw = gw; e.gh = gh; e.gc = C; e.seglen = 2 * C; e.segstride = 2L * gw * C; }
 
 int splitk_for(int M, int N, long K) {
-    // measured (tools/dw_sweep.py): the split-K partials are added with fp32 atomics, so splits cost traffic; the best
-    // point is about one 64-row tile per CU, i.e. tiles(128 x 128) * splitk ~ 256
+    // measured (tools/dw_sweep.py, 128 x 128 tiles, 8 waves): the split-K partials are added with fp32 atomics, so splits cost
+    // write traffic in proportion to the output size; the optimum sits near 64 / sqrt(tiles): 36 tiles -> 11, 9 tiles -> 21
     const long tiles = (long)bf_cdiv(M, 128) * bf_cdiv(N, 128);
-    long s = (256 + tiles / 2) / tiles;
+    long s = (256 + tiles / 2) / tiles;   // ~one wave of tiles over 256 CUs; more slices lose to atomic traffic in the full step
     const long kt = (K + 63) / 64;
     if (s > kt / 4) s = kt / 4;                         // at least 4 K-steps per slice
     if (s < 1) s = 1;
