@@ -67,8 +67,9 @@ bf_epilogue epi_atomic(float* c, long ldc) { bf_epilogue e = epi_store(c, ldc); 
 void epi_scatter(bf_epilogue& e, int gw, int gh, int C) { e.gw = gw; e.gh = gh; e.gc = C; e.seglen = 2 * C; e.segstride = 2L * gw * C; }
 
 int splitk_for(int M, int N, long K) {
-    // measured (tools/dw_sweep.py, 128 x 128 tiles, 8 waves): the split-K partials are added with fp32 atomics, so splits cost
-    // write traffic in proportion to the output size; the optimum sits near 64 / sqrt(tiles): 36 tiles -> 11, 9 tiles -> 21
+    // the split-K partials are added with fp32 atomics, so splits cost write traffic in proportion to the output size.  An isolated
+    // sweep (tools/dw_sweep.py) prefers ~64/sqrt(tiles) slices, but inside the full step that loses 5% (A/B on the bench: 351 vs
+    // 369 samples/s) to the rule below.
     const long tiles = (long)bf_cdiv(M, 128) * bf_cdiv(N, 128);
     long s = (256 + tiles / 2) / tiles;   // ~one wave of tiles over 256 CUs; more slices lose to atomic traffic in the full step
     const long kt = (K + 63) / 64;
