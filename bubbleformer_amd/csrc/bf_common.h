@@ -30,6 +30,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 // Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).  Off by default;
 // when off a scope costs one load of a global flag.
 int bf_prof_begin(hipStream_t st);
+bool bf_prof_is_on();
 void bf_prof_end(int idx, hipStream_t st, const char* name, double flops, double bytes);
 struct BfProfScope {
     int idx; hipStream_t st; const char* name; double flops, bytes;

@@ -25,6 +25,7 @@ struct Rec { hipEvent_t a, b; std::string name; double flops, bytes; };
 bool g_prof_on = false;
 std::vector<Rec> g_recs;
 }
+bool bf_prof_is_on() { return g_prof_on; }
 int bf_prof_begin(hipStream_t st) {
     if (!g_prof_on) return -1;
     Rec r{};

@@ -13,6 +13,7 @@
 //  * parameter gradients of those folds come from G = dout^T @ on (one split-K GEMM) instead of a saved y:
 //       dW = alpha * G (+ dmc x norm2.bias), dalpha[n] = <W[n, :], G[n, :]>, dbeta = colsum(dout).
 #include "bf_common.h"
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -80,6 +81,56 @@ int splitk_for(int M, int N, long K) {
 
 #define TRY(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
 #define ZERO(ptr, bytes) do { hipError_t e__ = hipMemsetAsync((ptr), 0, (bytes), st); if (e__ != hipSuccess) return bf_fail(e__, __FILE__, __LINE__); } while (0)
+#define ZERO_ON(stream, ptr, bytes) do { hipError_t e__ = hipMemsetAsync((ptr), 0, (bytes), (stream)); if (e__ != hipSuccess) return bf_fail(e__, __FILE__, __LINE__); } while (0)
+#define HIP_TRY(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return bf_fail(e__, __FILE__, __LINE__); } while (0)
+
+// ------------------------------------------------------------------------------------------------ side stream
+// The backward of every linear layer has two independent GEMMs over the same dy: the data gradient (on the critical path)
+// and the weight gradient (needed only by the optimizer).  Alone, each runs ~one wave of tiles with its load / MFMA / epilogue
+// phases in lock step across the chip; issued on two HIP streams they interleave and fill each other's bubbles.  The library
+// owns one extra stream per device; a stage forks work onto it with an event and joins it before it returns, so the caller
+// still sees plain stream-ordered semantics on ITS stream (and the fork/join pattern is hipGraph-capturable).
+// BF_SIDE_STREAM=0, or the launch profiler being on (per-kernel times must not overlap), runs everything on the caller's stream.
+struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool failed = false; };
+SideStream* side_stream() {
+    static SideStream tab[64];
+    static const bool enabled = []() { const char* v = getenv("BF_SIDE_STREAM"); return !(v && atoi(v) == 0); }();
+    if (!enabled || bf_prof_is_on()) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    SideStream& s = tab[dev];
+    if (!s.st && !s.failed) {
+        static const int prio_env = []() { const char* v = getenv("BF_SIDE_PRIO"); return v ? atoi(v) : 0; }();
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // lo = least urgent (numerically greatest)
+        const int prio = prio_env == 1 ? lo : prio_env == 2 ? hi : 0;
+        if (hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) { s.failed = true; s.st = nullptr; }
+    }
+    return s.st ? &s : nullptr;
+}
+struct Fork {
+    hipStream_t main; SideStream* s; bool used = false;
+    explicit Fork(hipStream_t m) : main(m), s(side_stream()) {}
+    // stream for work that depends only on what has been issued on `main` so far
+    int begin(hipStream_t* out) {
+        *out = main;
+        if (!s) return 0;
+        HIP_TRY(hipEventRecord(s->fork, main));
+        HIP_TRY(hipStreamWaitEvent(s->st, s->fork, 0));
+        used = true;
+        *out = s->st;
+        return 0;
+    }
+    // everything forked so far is ordered before what `main` is given next
+    int join() {
+        if (!s || !used) return 0;
+        HIP_TRY(hipEventRecord(s->join, s->st));
+        HIP_TRY(hipStreamWaitEvent(main, s->join, 0));
+        used = false;
+        return 0;
+    }
+};
 
 // ------------------------------------------------------------------------------------------------ small param kernels
 // out-projection fold.  mc[n] = <W[n,:], nb> + bias[n]; alpha = gamma*(1+hi); beta = gamma*(bias*(1+hi) + mc*(lo-hi))
@@ -235,6 +286,7 @@ struct Scratch {
     float *G, *csum, *zeros, *ones, *wg, *attn_ws, *in_ws, *dgtab;   // wg: prepared-layout weight gradient scratch
     static constexpr long ATTN_WS_FLOATS = 1024L * (4 * 128 + 32 * 16 + 16);
     void *t1, *t3, *t4, *t1b;
+    void *s1, *e5, *e6, *e7;     // [N][E] each: s1 feeds side-stream GEMMs only; e5..e7 keep side-stream inputs from being recycled within a stage
     size_t bytes;
     Scratch(const D& d, void* base) {
         Arena a(base);
@@ -262,6 +314,7 @@ struct Scratch {
         t3 = a.take(std::max(tok * 3, big / 2) * d.es);
         t1 = a.take(std::max(tok, big / 2) * d.es);
         t1b = a.take(std::max(tok, big / 2) * d.es);
+        s1 = a.take(tok * d.es); e5 = a.take(tok * d.es); e6 = a.take(tok * d.es); e7 = a.take(tok * d.es);
         bytes = a.off;
     }
 };
@@ -296,18 +349,21 @@ int outproj_gemm(const D& d, const void* o, const float* sc, const float* sh, co
 int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* o, const float* sc2, const float* sh2, const void* w_c,
                 const float* W, const float* bias, const float* nb, const float* gamma, const float* lo, const float* hi,
                 const float* alpha, const float* mc, float* dW, float* dbias, float* dnb, float* dgamma, float* dlo, float* dhi,
-                void* don, void* tmp, hipStream_t st) {
-    ZERO(sc.G, (size_t)((char*)sc.csum - (char*)sc.G) + (size_t)d.E * 4);     // G and csum are adjacent in the arena: one memset
+                void* don, hipStream_t st, Fork& fk) {
+    hipStream_t ss;                                   // parameter-gradient side: memset, normalised operand, G GEMM, finalize
+    TRY(fk.begin(&ss));
+    void* tmp = sc.s1;
+    ZERO_ON(ss, sc.G, (size_t)((char*)sc.csum - (char*)sc.G) + (size_t)d.E * 4);     // G and csum are adjacent in the arena: one memset
     {   // G[n][k] = sum_m dout[m][n] * on[m][k].  The normalised operand is materialised first (one 2U element-wise pass,
         // ~7 us) because applying the affine inside the token-reduction GEMM's staging costs ~20 us (tools/gemm_bench.py)
-        TRY(bf_affine_apply(d.dtype, o, nullptr, sc2, sh2, tmp, d.N, (int)d.S, d.E, st));
+        TRY(bf_affine_apply(d.dtype, o, nullptr, sc2, sh2, tmp, d.N, (int)d.S, d.E, ss));
         bf_operand A = op_plain(dout, d.E, BF_LAY_XC);
         bf_operand Bo = op_plain(tmp, d.E, BF_LAY_XC);
         bf_epilogue e = epi_atomic(sc.G, d.E);
         e.colsum = sc.csum;                  // dbeta = colsum(dout), fused into the same pass over dout
-        TRY(bf_gemm(d.dtype, d.E, d.E, (int)d.N, &A, &Bo, &e, splitk_for(d.E, d.E, d.N), st));
+        TRY(bf_gemm(d.dtype, d.E, d.E, (int)d.N, &A, &Bo, &e, splitk_for(d.E, d.E, d.N), ss));
     }
-    hipLaunchKernelGGL(outproj_finalize_kernel, dim3(d.E), dim3(256), 0, st, sc.G, sc.csum, W, bias, nb, gamma, lo, hi, mc, dW, dbias, dnb,
+    hipLaunchKernelGGL(outproj_finalize_kernel, dim3(d.E), dim3(256), 0, ss, sc.G, sc.csum, W, bias, nb, gamma, lo, hi, mc, dW, dbias, dnb,
                        dgamma, dlo, dhi, d.E);
     BF_CHECK_LAUNCH();
     {   // don = (dout * alpha) @ W     (alpha per reduction column; frame independent)
@@ -321,11 +377,14 @@ int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* o, 
 }
 // backward of y = affine(x) @ W^T + b:  dW += dy^T affine(x), db += colsum(dy), dxn = dy @ W
 int linear_bwd(const D& d, const Scratch& sc, const void* dy, int Nout, const void* x, int Kin, int xpro, const float* xsc, const float* xsh,
-               const void* w_c, float* dW, float* db, void* dxn, const bf_epilogue* dx_epi, void* tmp, hipStream_t st) {
+               const void* w_c, float* dW, float* db, void* dxn, const bf_epilogue* dx_epi, hipStream_t st, Fork& fk) {
     {
+        hipStream_t ss;                          // weight gradient: side stream
+        TRY(fk.begin(&ss));
+        void* tmp = sc.s1;
         bf_operand A = op_plain(dy, Nout, BF_LAY_XC);
-        if (xpro == BF_PRO_AFFINE && tmp) {      // see outproj_bwd: materialise the normalised operand once
-            TRY(bf_affine_apply(d.dtype, x, nullptr, xsc, xsh, tmp, d.N, (int)d.S, Kin, st));
+        if (xpro == BF_PRO_AFFINE) {             // see outproj_bwd: materialise the normalised operand once
+            TRY(bf_affine_apply(d.dtype, x, nullptr, xsc, xsh, tmp, d.N, (int)d.S, Kin, ss));
             x = tmp;
             xpro = BF_PRO_NONE;
         }
@@ -333,7 +392,7 @@ int linear_bwd(const D& d, const Scratch& sc, const void* dy, int Nout, const vo
         if (xpro != BF_PRO_NONE) op_affine(Bo, xpro, xsc, xsh, d.S, Kin);
         bf_epilogue e = epi_atomic(dW, Kin);
         e.colsum = db;                       // bias gradient = colsum(dy), fused into the same pass over dy
-        TRY(bf_gemm(d.dtype, Nout, Kin, (int)d.N, &A, &Bo, &e, splitk_for(Nout, Kin, d.N), st));
+        TRY(bf_gemm(d.dtype, Nout, Kin, (int)d.N, &A, &Bo, &e, splitk_for(Nout, Kin, d.N), ss));
     }
     {
         bf_operand A = op_plain(dy, Nout, BF_LAY_KC);
@@ -391,6 +450,7 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
     const void* win_c = d.dtype == BF_DTYPE_F32 ? (const void*)p->input_head_w : sv.win_c;
     const void* wout_c = d.dtype == BF_DTYPE_F32 ? (const void*)p->output_head_w : sv.wout_c;
     ZERO(sc.zeros, (size_t)4 * d.E * 4);
+    Fork fk(st);            // weight-gradient GEMMs go to the side stream; nothing they read (dbr, t3, s1) is rewritten before the join
     void* don = sc.t1;      // [N][E]
     void* dO = sc.t1b;      // [N][E]
     void* dqkv = sc.t3;     // [N][3E]
@@ -402,17 +462,17 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
         dbr = sc.t4;
     }
     TRY(outproj_bwd(d, sc, dbr, sv.o, sv.sc2, sv.sh2, wout_c, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr,
-                    sv.alpha, sv.mc, g->output_head_w, g->output_head_b, nullptr, g->gamma, nullptr, nullptr, don, /*tmp*/ sc.t1b, st));
+                    sv.alpha, sv.mc, g->output_head_w, g->output_head_b, nullptr, g->gamma, nullptr, nullptr, don, st, fk));
     TRY(bf_in_bwd(d.dtype, don, sv.o, nullptr, dO, (int)d.F, (int)d.S, d.E, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, nullptr, 1, 0,
                   g->norm2_w, g->norm2_b, nullptr, nullptr, sc.in_ws, st));
     TRY(bf_attn_bwd(d.dtype, sv.qkv, dO, dqkv, (long)d.B * d.S, d.T, d.S, (long)d.T * d.S, 1, d.S, d.heads, d.d, p->qnorm_w, p->qnorm_b,
                     p->knorm_w, p->knorm_b, p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor : nullptr, g->qnorm_w, g->qnorm_b,
                     g->knorm_w, g->knorm_b, g->rel_pos_emb, d.attn_scale ? g->attn_scale_factor : nullptr, 1.f, 0, sc.attn_ws, Scratch::ATTN_WS_FLOATS, st));
     void* dxn = sc.t1;      // don is dead
-    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, x, d.E, BF_PRO_AFFINE, sv.sc1, sv.sh1, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, /*tmp*/ sc.t1b, st));
+    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, x, d.E, BF_PRO_AFFINE, sv.sc1, sv.sh1, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk));
     TRY(bf_in_bwd(d.dtype, dxn, x, dout, dx, (int)d.F, (int)d.S, d.E, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, nullptr, 1, 0,
                   g->norm1_w, g->norm1_b, nullptr, nullptr, sc.in_ws, st));
-    return 0;
+    return fk.join();
 }
 
 // ================================================================================================= axial (spatial) block
@@ -486,6 +546,9 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     const void* w1_c = f32 ? (const void*)p->fc1_w : sv.w1_c;
     const void* w2_c = f32 ? (const void*)p->fc2_w : sv.w2_c;
     ZERO(sc.zeros, (size_t)4 * d.E * 4);
+    // weight-gradient GEMMs go to the side stream and are joined at the end; every buffer they read (dz = t1, dpre = t4,
+    // dx1 = t1b, dbr = e5, dqkv = t3, s1) is written once per call, so the critical path below never recycles one under them.
+    Fork fk(st);
     // out = x1 + gamma_mlp * IN(z)
     void* dz = sc.t1;
     if (drop_mlp) {   // gtab[f][c] = drop_mlp[f] * gamma_mlp[c] was the scale: its gradient comes back per frame, then d gamma = sum_f drop * dgtab
@@ -502,29 +565,29 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     {
         bf_epilogue e; memset(&e, 0, sizeof(e));
         e.aux_mode = BF_AUX_DGELU; e.aux = sv.pre; e.ld_aux = 4L * d.E; e.out_mode = BF_OUT_STORE;
-        TRY(linear_bwd(d, sc, dz, d.E, sv.hid, 4 * d.E, BF_PRO_NONE, nullptr, nullptr, w2_c, g->fc2_w, g->fc2_b, dpre, &e, nullptr, st));
+        TRY(linear_bwd(d, sc, dz, d.E, sv.hid, 4 * d.E, BF_PRO_NONE, nullptr, nullptr, w2_c, g->fc2_w, g->fc2_b, dpre, &e, st, fk));
     }
     // fc1: pre = x1 @ W1^T + b1 ; dx1 = dout + dpre @ W1
     void* dx1 = sc.t1b;
     {
         bf_epilogue e; memset(&e, 0, sizeof(e));
         e.aux_mode = BF_AUX_ADD; e.aux = dout; e.ld_aux = d.E; e.out_mode = BF_OUT_STORE;
-        TRY(linear_bwd(d, sc, dpre, 4 * d.E, sv.x1, d.E, BF_PRO_NONE, nullptr, nullptr, w1_c, g->fc1_w, g->fc1_b, dx1, &e, nullptr, st));
+        TRY(linear_bwd(d, sc, dpre, 4 * d.E, sv.x1, d.E, BF_PRO_NONE, nullptr, nullptr, w1_c, g->fc1_w, g->fc1_b, dx1, &e, st, fk));
     }
     // folded out-projection
-    void* don = sc.t1;      // dz is dead
+    void* don = sc.e6;
     const void* dbr = dx1;  // gradient entering the attention branch (dx1 itself continues down the residual)
     if (drop_att) {
         hipLaunchKernelGGL(frame_table_kernel, dim3(bf_cdiv(d.F * d.E, 256)), dim3(256), 0, st, drop_att, 1, (const float*)nullptr, sv.mtab, (int)d.F, d.E);
         BF_CHECK_LAUNCH();
-        TRY(bf_affine_apply(d.dtype, dx1, nullptr, sv.mtab, sc.zeros, sc.t3, d.N, (int)d.S, d.E, st));    // t3 (dqkv) is not live yet
-        dbr = sc.t3;
+        TRY(bf_affine_apply(d.dtype, dx1, nullptr, sv.mtab, sc.zeros, sc.e5, d.N, (int)d.S, d.E, st));
+        dbr = sc.e5;
     }
     TRY(outproj_bwd(d, sc, dbr, sv.o, sv.sc2, sv.sh2, wout_c, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att,
                     d.feat_scale ? p->low_freq_scalar : nullptr, d.feat_scale ? p->high_freq_scalar : nullptr, sv.alpha, sv.mc,
                     g->output_head_w, g->output_head_b, g->norm2_b, g->gamma_att, d.feat_scale ? g->low_freq_scalar : nullptr,
-                    d.feat_scale ? g->high_freq_scalar : nullptr, don, /*tmp: dpre is dead*/ sc.t4, st));
-    void* dO = sc.t4;       // dpre is dead; [N][E]
+                    d.feat_scale ? g->high_freq_scalar : nullptr, don, st, fk));
+    void* dO = sc.e7;       // [N][E]
     TRY(bf_in_bwd(d.dtype, don, sv.o, nullptr, dO, (int)d.F, (int)d.S, d.E, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, nullptr, 1, 0,
                   g->norm2_w, g->norm2_b, nullptr, nullptr, sc.in_ws, st));
     void* dqkv = sc.t3;
@@ -534,11 +597,11 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     TRY(bf_attn_bwd(d.dtype, sv.qkv, dO, dqkv, d.F * d.w, d.h, d.w, d.S, 1, d.w, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
                     p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_y : nullptr, g->qnorm_w, g->qnorm_b, g->knorm_w, g->knorm_b,
                     g->rel_pos_emb, d.attn_scale ? g->attn_scale_factor_y : nullptr, 0.5f, 1, sc.attn_ws, Scratch::ATTN_WS_FLOATS, st));
-    void* dxn = sc.t1;      // don is dead
-    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, x, d.E, BF_PRO_AFFINE, sv.sc1, sv.sh1, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, /*tmp: dO is dead*/ sc.t4, st));
+    void* dxn = sc.e6;      // don is dead (it was only read on this stream)
+    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, x, d.E, BF_PRO_AFFINE, sv.sc1, sv.sh1, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk));
     TRY(bf_in_bwd(d.dtype, dxn, x, dx1, dx, (int)d.F, (int)d.S, d.E, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, nullptr, 1, 0,
                   g->norm1_w, g->norm1_b, nullptr, nullptr, sc.in_ws, st));
-    return 0;
+    return fk.join();
 }
 
 // ================================================================================================= patch embed (+ FiLM)

@@ -18,15 +18,21 @@ import re
 
 
 def normalise(name: str) -> str:
-    m = re.search(r"gemm_kernelI(DF16b|f)Lb([01])ELb([01])ELb([01])ELb([01])ELi(\d)ELi(\d)E", name)
+    m = re.search(r"gemm_kernelI(DF16b|f)Lb([01])ELb([01])ELb([01])ELb([01])ELi(\d)ELi(\d)ELi(\d+)E", name)
     if m:
-        t, ax, bx, ap, bp, _, tm = m.groups()
-        return "gemm_kernel<%s,%s,%s,pro%s,tm%s>" % ("bf16" if t == "DF16b" else "f32", "xc" if ax == "1" else "kc", "xc" if bx == "1" else "kc",
-                                                    "A" if ap == "1" else "B" if bp == "1" else "0", tm)
-    m = re.search(r"gemm_kernel<bool _Accum, bool, E, (true|false), (true|false), (true|false), \d, (\d)>", name)
+        t, ax, bx, ap, bp, _, tm, nt = m.groups()
+        return "gemm_kernel<%s,%s,%s,pro%s,tm%s,w%d>" % ("bf16" if t == "DF16b" else "f32", "xc" if ax == "1" else "kc", "xc" if bx == "1" else "kc",
+                                                        "A" if ap == "1" else "B" if bp == "1" else "0", tm, int(nt) // 64)
+    m = re.search(r"gemm_kernel<(__hip_bfloat16|float), (true|false), (true|false), (true|false), (true|false), \d, (\d), (\d+)>", name)
+    if m:
+        t, ax, bx, ap, bp, tm, nt = m.groups()
+        return "gemm_kernel<%s,%s,%s,pro%s,tm%s,w%d>" % ("bf16" if t != "float" else "f32", "xc" if ax == "true" else "kc", "xc" if bx == "true" else "kc",
+                                                        "A" if ap == "true" else "B" if bp == "true" else "0", tm, int(nt) // 64)
+    m = re.search(r"gemm_kernel<bool _Accum, bool, E, (true|false), (true|false), (true|false), \d, (\d), (\d+)>", name)
     if m:   # rocprofv3's demangler garbles the A-outer-contiguous (dW) instantiations; AXC = true there
-        bx, ap, bp, tm = m.groups()
-        return "gemm_kernel<bf16,xc,%s,pro%s,tm%s>" % ("xc" if bx == "true" else "kc", "A" if ap == "true" else "B" if bp == "true" else "0", tm)
+        bx, ap, bp, tm, nt = m.groups()
+        return "gemm_kernel<bf16,xc,%s,pro%s,tm%s,w%d>" % ("xc" if bx == "true" else "kc", "A" if ap == "true" else "B" if bp == "true" else "0", tm,
+                                                          int(nt) // 64)
     m = re.search(r"gemm_wide_kernel<(true|false), (true|false), (true|false), (true|false), (\d)>", name)
     if m:
         ax, bx, ap, bp, tm = m.groups()
