@@ -300,7 +300,12 @@ struct Scratch {
         ones = a.f32((size_t)4 * d.E);
         wg = a.f32(wgn);
         attn_ws = a.f32(ATTN_WS_FLOATS);
-        in_ws = a.f32((size_t)2 * d.F * d.E);
+        {   // InstanceNorm workspace: the trunk (S tokens x E) and every embed / debed resolution (S * 4^i tokens x E/4)
+            int64_t n = bf_in_ws_floats(d.dtype, (int)d.F, (int)d.S, d.E);
+            long Si = d.S;
+            for (int i = 1; i < d.nst; ++i) { Si *= 4; n = std::max(n, bf_in_ws_floats(d.dtype, (int)d.F, (int)Si, cm)); }
+            in_ws = a.f32((size_t)n);
+        }
         dgtab = a.f32((size_t)d.F * d.E);
         // activation-sized transients; embed/debed stages work at up to (patch/2)^2 * N pixels of E/4 (or cin/cout) channels
         size_t tok = (size_t)d.N * d.E;
@@ -418,6 +423,7 @@ extern "C" int bf_temporal_fwd(const bf_dims* dims, const bf_temporal_params* p,
     BF_REQUIRE(p && x && out && saved && scratch, "bf_temporal_fwd: null pointer");
     hipStream_t st = (hipStream_t)s;
     TemporalSaved sv(d, saved);
+    Scratch sc(d, scratch);
     const void *win_c, *wout_c;
     {
         const float* src[2] = {p->input_head_w, p->output_head_w};
@@ -427,12 +433,12 @@ extern "C" int bf_temporal_fwd(const bf_dims* dims, const bf_temporal_params* p,
         TRY(wviews(d, 2, src, dst, n, out, st));
         win_c = out[0]; wout_c = out[1];
     }
-    TRY(bf_in_stats(d.dtype, x, (int)d.F, (int)d.S, d.E, p->norm1_w, p->norm1_b, nullptr, 1, nullptr, sv.mean1, sv.rstd1, sv.sc1, sv.sh1, st));
+    TRY(bf_in_stats(d.dtype, x, (int)d.F, (int)d.S, d.E, p->norm1_w, p->norm1_b, nullptr, 1, nullptr, sv.mean1, sv.rstd1, sv.sc1, sv.sh1, sc.in_ws, st));
     TRY(qkv_gemm(d, x, sv.sc1, sv.sh1, win_c, p->input_head_b, sv.qkv, st));
     // sequences along T for every (b, y, x): token = b*T*S + pos + t*S
     TRY(bf_attn_fwd(d.dtype, sv.qkv, sv.o, (long)d.B * d.S, d.T, d.S, (long)d.T * d.S, 1, d.S, d.heads, d.d, p->qnorm_w, p->qnorm_b,
                     p->knorm_w, p->knorm_b, p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor : nullptr, 1.f, 0, st));
-    TRY(bf_in_stats(d.dtype, sv.o, (int)d.F, (int)d.S, d.E, p->norm2_w, p->norm2_b, nullptr, 1, nullptr, sv.mean2, sv.rstd2, sv.sc2, sv.sh2, st));
+    TRY(bf_in_stats(d.dtype, sv.o, (int)d.F, (int)d.S, d.E, p->norm2_w, p->norm2_b, nullptr, 1, nullptr, sv.mean2, sv.rstd2, sv.sc2, sv.sh2, sc.in_ws, st));
     hipLaunchKernelGGL(outproj_prep_kernel, dim3(d.E), dim3(256), 0, st, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma,
                        (const float*)nullptr, (const float*)nullptr, sv.alpha, sv.beta, sv.mc, d.E);
     BF_CHECK_LAUNCH();
@@ -482,6 +488,7 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
     BF_REQUIRE(p && x && out && saved && scratch, "bf_spatial_fwd: null pointer");
     hipStream_t st = (hipStream_t)s;
     SpatialSaved sv(d, saved);
+    Scratch sc(d, scratch);
     const void *win_c, *wout_c, *w1_c, *w2_c;
     {
         const float* src[4] = {p->input_head_w, p->output_head_w, p->fc1_w, p->fc2_w};
@@ -491,7 +498,7 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
         TRY(wviews(d, 4, src, dst, n, out, st));
         win_c = out[0]; wout_c = out[1]; w1_c = out[2]; w2_c = out[3];
     }
-    TRY(bf_in_stats(d.dtype, x, (int)d.F, (int)d.S, d.E, p->norm1_w, p->norm1_b, nullptr, 1, nullptr, sv.mean1, sv.rstd1, sv.sc1, sv.sh1, st));
+    TRY(bf_in_stats(d.dtype, x, (int)d.F, (int)d.S, d.E, p->norm1_w, p->norm1_b, nullptr, 1, nullptr, sv.mean1, sv.rstd1, sv.sc1, sv.sh1, sc.in_ws, st));
     TRY(qkv_gemm(d, x, sv.sc1, sv.sh1, win_c, p->input_head_b, sv.qkv, st));
     // along w: one sequence per (frame, row): contiguous tokens
     TRY(bf_attn_fwd(d.dtype, sv.qkv, sv.o, d.F * d.h, d.w, 1, d.w, 0, 1, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
@@ -499,7 +506,7 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
     // along h: one sequence per (frame, column): stride w
     TRY(bf_attn_fwd(d.dtype, sv.qkv, sv.o, d.F * d.w, d.h, d.w, d.S, 1, d.w, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
                     p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_y : nullptr, 0.5f, 1, st));
-    TRY(bf_in_stats(d.dtype, sv.o, (int)d.F, (int)d.S, d.E, p->norm2_w, p->norm2_b, nullptr, 1, nullptr, sv.mean2, sv.rstd2, sv.sc2, sv.sh2, st));
+    TRY(bf_in_stats(d.dtype, sv.o, (int)d.F, (int)d.S, d.E, p->norm2_w, p->norm2_b, nullptr, 1, nullptr, sv.mean2, sv.rstd2, sv.sc2, sv.sh2, sc.in_ws, st));
     hipLaunchKernelGGL(outproj_prep_kernel, dim3(d.E), dim3(256), 0, st, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att,
                        d.feat_scale ? p->low_freq_scalar : nullptr, d.feat_scale ? p->high_freq_scalar : nullptr, sv.alpha, sv.beta, sv.mc, d.E);
     BF_CHECK_LAUNCH();
@@ -528,7 +535,7 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
         g3 = sv.gtab; g3div = 1;
     }
     TRY(bf_in_stats(d.dtype, sv.z, (int)d.F, (int)d.S, d.E, p->mlp_norm_w, p->mlp_norm_b, g3, g3div, nullptr, sv.mean3, sv.rstd3,
-                    sv.sc3, sv.sh3, st));
+                    sv.sc3, sv.sh3, sc.in_ws, st));
     TRY(bf_affine_apply(d.dtype, sv.z, sv.x1, sv.sc3, sv.sh3, out, d.N, (int)d.S, d.E, st));
     return 0;
 }
@@ -676,6 +683,7 @@ extern "C" int bf_embed_fwd(const bf_dims* dims, const bf_embed_params* p, const
     BF_REQUIRE((d.nfluid > 0) == (fluid != nullptr), "bf_embed_fwd: fluid parameters must be given exactly when nfluid > 0");
     hipStream_t st = (hipStream_t)s;
     EmbedSaved sv(d, saved);
+    Scratch sc(d, scratch);
     const int n = d.nst, H = d.h * d.patch, W = d.w * d.patch;
     if (d.nfluid > 0)
         TRY(bf_film_net_fwd(fluid, p->film_ln_w, p->film_ln_b, p->film_w, p->film_b, sv.gb, sv.chat, sv.crstd, d.B, d.nfluid, 2 * d.E, st));
@@ -702,7 +710,7 @@ extern "C" int bf_embed_fwd(const bf_dims* dims, const bf_embed_params* p, const
         const bool last = i == n - 1;
         const bool film = last && d.nfluid > 0;
         TRY(bf_in_stats(d.dtype, sv.y[i], (int)d.F, sv.gh[i] * sv.gw[i], sv.C[i], p->in_w[i], p->in_b[i], film ? sv.gb : nullptr, d.T,
-                        film ? sv.gb + (size_t)d.B * d.E : nullptr, sv.mean[i], sv.rstd[i], sv.sc[i], sv.sh[i], st));
+                        film ? sv.gb + (size_t)d.B * d.E : nullptr, sv.mean[i], sv.rstd[i], sv.sc[i], sv.sh[i], sc.in_ws, st));
     }
     TRY(bf_affine_apply(d.dtype, sv.y[n - 1], nullptr, sv.sc[n - 1], sv.sh[n - 1], out, d.N, (int)d.S, d.E, st));
     return 0;
@@ -793,7 +801,7 @@ extern "C" int bf_debed_fwd(const bf_dims* dims, const bf_debed_params* p, const
             epi_scatter(e, sv.gw[i], sv.gh[i], co);
             TRY(bf_gemm(d.dtype, (int)sv.Pin[i], 4 * co, cin, &A, &Bo, &e, 1, st));
             TRY(bf_in_stats(d.dtype, sv.y[i], (int)d.F, 4 * sv.gh[i] * sv.gw[i], co, p->in_w[i], p->in_b[i], nullptr, 1, nullptr, sv.mean[i],
-                            sv.rstd[i], sv.sc[i], sv.sh[i], st));
+                            sv.rstd[i], sv.sc[i], sv.sh[i], sc.in_ws, st));
         } else {
             TRY(bf_wprep(d.dtype, 0, p->conv_w[i], sv.wc[i], cin, 4 * co, sv.Np, st));
             bf_operand Bo = op_plain(sv.wc[i], sv.Np, BF_LAY_XC);

@@ -119,6 +119,82 @@ __global__ void __launch_bounds__(NT) in_stats_kernel(const T* __restrict__ x, i
     }
 }
 
+// Long frames (S > RG * MAXR tokens: the embed / debed resolutions) are cut into slices of RG * MAXR tokens so that the grid
+// is frames x slices x channel blocks instead of frames x channel blocks (which left most CUs idle and every wave with one
+// load in flight).  A slice is read ONCE into registers; slices are merged exactly (Chan et al. pairwise update):
+//   part[(f * nsl + sl) * C + c] = {slice mean, slice centred second moment}
+template <typename T>
+__global__ void __launch_bounds__(NT) in_stats_slice_kernel(const T* __restrict__ x, int S, int C, int nsl, float* __restrict__ part) {
+    constexpr int CH = Chunk<T>::N, LC = Geo<T>::LC, RG = Geo<T>::RG;
+    __shared__ float sm[NT * CH];
+    const int f = blockIdx.x / nsl, sl = blockIdx.x % nsl, c0 = blockIdx.y * CPB;
+    const int tid = threadIdx.x, lc = tid % LC, rg = tid / LC;
+    const int c = c0 + lc * CH;
+    const bool cv = c < C;
+    const int s0 = sl * (RG * MAXR), n = min(S - s0, RG * MAXR);
+    const T* xf = x + ((long)f * S + s0) * C + c;
+    float acc[1][CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc[0][j] = 0.f;
+    Chunk<T> keep[MAXR];
+#pragma unroll
+    for (int q = 0; q < MAXR; ++q) {
+        const int r = rg + RG * q;
+        if (cv && r < n) keep[q].load(xf + (long)r * C); else keep[q].zero();
+    }
+#pragma unroll
+    for (int q = 0; q < MAXR; ++q)
+#pragma unroll
+        for (int j = 0; j < CH; ++j) acc[0][j] += keep[q].get(j);
+    reduce_rows<T, 1>(acc, sm);
+    float mu[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { mu[j] = acc[0][j] / (float)n; acc[0][j] = 0.f; }
+#pragma unroll
+    for (int q = 0; q < MAXR; ++q) {
+        if (rg + RG * q < n) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) { const float d = keep[q].get(j) - mu[j]; acc[0][j] += d * d; }
+        }
+    }
+    reduce_rows<T, 1>(acc, sm);
+    if (cv && rg == 0) {
+        float* o = part + (((long)f * nsl + sl) * C + c) * 2;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { o[2 * j] = mu[j]; o[2 * j + 1] = acc[0][j]; }
+    }
+}
+// one thread per (frame, channel): merge the slices, then the same outputs as in_stats_kernel
+__global__ void __launch_bounds__(NT) in_stats_merge_kernel(const float* __restrict__ part, int frames, int S, int C, int nsl, int rows,
+                                                           const float* __restrict__ w, const float* __restrict__ b,
+                                                           const float* __restrict__ g, int gdiv, const float* __restrict__ gb,
+                                                           float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ sc,
+                                                           float* __restrict__ sh) {
+    const long i = (long)blockIdx.x * NT + threadIdx.x;
+    if (i >= (long)frames * C) return;
+    const int f = (int)(i / C), c = (int)(i % C);
+    const float2* pp = reinterpret_cast<const float2*>(part) + (long)f * nsl * C + c;
+    float tot = 0.f;
+    for (int sl = 0; sl < nsl; ++sl) tot += pp[(long)sl * C].x * (float)min(rows, S - sl * rows);
+    const float mu = tot / (float)S;
+    float m2 = 0.f;
+    for (int sl = 0; sl < nsl; ++sl) {
+        const float2 v = pp[(long)sl * C];
+        const float dm = v.x - mu;
+        m2 += v.y + dm * dm * (float)min(rows, S - sl * rows);
+    }
+    const float r = rsqrtf(m2 / (float)S + BF_IN_EPS);
+    float a = r * w[c];
+    float s0 = b[c] - mu * a;
+    if (g) {
+        const long gi = (long)(f / gdiv) * C + c;
+        const float gg = g[gi];
+        a *= gg;
+        s0 = s0 * gg + (gb ? gb[gi] : 0.f);
+    }
+    mean[i] = mu; rstd[i] = r; sc[i] = a; sh[i] = s0;
+}
+
 // ------------------------------------------------------------------------------------ apply
 // out = [resid +] z * sc[f, c] + sh[f, c]      (grid-stride over 16-byte chunks)
 template <typename T>
@@ -250,6 +326,100 @@ __global__ void __launch_bounds__(NT) in_bwd_kernel(const T* __restrict__ dy, co
     }
 }
 
+// Long frames, as for the statistics: phase 0 reduces {s1, s2} per slice into part[(f * nsl + sl) * C + c], in_slice_sum_kernel
+// adds the slices into ws[f][c], phase 1 applies over the same slices (grid = frames * slices x channel blocks).
+template <typename T, bool GELU, int PHASE>
+__global__ void __launch_bounds__(NT) in_bwd_slice_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ add,
+                                                         T* __restrict__ dx, int S, int C, int nsl, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, const float* __restrict__ w,
+                                                         const float* __restrict__ b, const float* __restrict__ g, int gdiv,
+                                                         float* __restrict__ part, const float* __restrict__ tot) {
+    constexpr int CH = Chunk<T>::N, LC = Geo<T>::LC, RG = Geo<T>::RG;
+    __shared__ float sm[NT * CH];
+    const int f = blockIdx.x / nsl, sl = blockIdx.x % nsl, c0 = blockIdx.y * CPB;
+    const int tid = threadIdx.x, lc = tid % LC, rg = tid / LC;
+    const int c = c0 + lc * CH;
+    const bool cv = c < C;
+    const int s0 = sl * (RG * MAXR), n = min(S - s0, RG * MAXR);
+    const long base = ((long)f * S + s0) * C + c;
+    float mu[CH], rs[CH], ww[CH], bb[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        mu[j] = cv ? mean[(long)f * C + c + j] : 0.f;
+        rs[j] = cv ? rstd[(long)f * C + c + j] : 0.f;
+        ww[j] = cv ? w[c + j] : 0.f;
+        bb[j] = cv ? b[c + j] : 0.f;
+    }
+    Chunk<T> kd[MAXR], kx[MAXR], ka[MAXR];
+#pragma unroll
+    for (int q = 0; q < MAXR; ++q) {            // all loads of the slice in flight before the first use
+        const int r = rg + RG * q;
+        if (cv && r < n) {
+            kd[q].load(dy + base + (long)r * C);
+            kx[q].load(x + base + (long)r * C);
+            if (PHASE == 1 && add) ka[q].load(add + base + (long)r * C);
+        } else { kd[q].zero(); kx[q].zero(); }
+    }
+    if constexpr (PHASE == 0) {
+        float acc[2][CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) acc[0][j] = acc[1][j] = 0.f;
+#pragma unroll
+        for (int q = 0; q < MAXR; ++q) {
+            if (rg + RG * q < n) {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const float xh = (kx[q].get(j) - mu[j]) * rs[j];
+                    float dd = kd[q].get(j);
+                    if (GELU) dd *= dgelu_f(xh * ww[j] + bb[j]);
+                    acc[0][j] += dd;
+                    acc[1][j] += dd * xh;
+                }
+            }
+        }
+        reduce_rows<T, 2>(acc, sm);
+        if (cv && rg == 0) {
+            float* o = part + (((long)f * nsl + sl) * C + c) * 2;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) { o[2 * j] = acc[0][j]; o[2 * j + 1] = acc[1][j]; }
+        }
+    } else {
+        float t1[CH], t2[CH], gg[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            t1[j] = cv ? tot[((long)f * C + c + j) * 2] / (float)S : 0.f;
+            t2[j] = cv ? tot[((long)f * C + c + j) * 2 + 1] / (float)S : 0.f;
+            gg[j] = (cv && g) ? g[(long)(f / gdiv) * C + c + j] : 1.f;
+        }
+#pragma unroll
+        for (int q = 0; q < MAXR; ++q) {
+            const int r = rg + RG * q;
+            if (cv && r < n) {
+                Chunk<T> o;
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const float xh = (kx[q].get(j) - mu[j]) * rs[j];
+                    float dd = kd[q].get(j);
+                    if (GELU) dd *= dgelu_f(xh * ww[j] + bb[j]);
+                    float t = rs[j] * ww[j] * gg[j] * (dd - t1[j] - xh * t2[j]);
+                    if (add) t += ka[q].get(j);
+                    o.set(j, t);
+                }
+                o.store(dx + base + (long)r * C);
+            }
+        }
+    }
+}
+__global__ void __launch_bounds__(NT) in_slice_sum_kernel(const float* __restrict__ part, long FC, int C, int nsl, float* __restrict__ tot) {
+    const long i = (long)blockIdx.x * NT + threadIdx.x;
+    if (i >= FC) return;
+    const long f = i / C; const int c = (int)(i % C);
+    const float2* pp = reinterpret_cast<const float2*>(part) + f * nsl * C + c;
+    float a = 0.f, b = 0.f;
+    for (int sl = 0; sl < nsl; ++sl) { const float2 v = pp[(long)sl * C]; a += v.x; b += v.y; }
+    reinterpret_cast<float2*>(tot)[i] = make_float2(a, b);
+}
+
 // parameter gradients from the per-frame partials ws[f][c] = {s1, s2}.
 // grid (ceil(C/64), frame groups): one workgroup sums the frames of ONE frame group (gdiv frames; 256 threads = 64 channels x
 // 4 frame lanes) and adds its share to dw/db (a few atomics per address) and, if asked, stores dg/dgb of that group.
@@ -311,14 +481,39 @@ int chunk_ok(int C) { return C % Chunk<T>::N == 0; }
 
 }  // namespace
 
+template <typename T> int slice_rows() { return Geo<T>::RG * MAXR; }
+
+extern "C" int64_t bf_in_ws_floats(int dtype, int frames, int S, int C) {
+    const int rows = dtype == BF_DTYPE_BF16 ? slice_rows<bf16>() : slice_rows<float>();
+    const int64_t fc2 = (int64_t)2 * frames * C;
+    return S > rows ? fc2 * (1 + bf_cdiv(S, rows)) : fc2;
+}
+
 extern "C" int bf_in_stats(int dtype, const void* x, int frames, int S, int C, const float* w, const float* b,
                            const float* g, int gdiv, const float* gb, float* mean, float* rstd, float* sc, float* sh,
-                           bf_stream_t stream) {
+                           float* ws, bf_stream_t stream) {
     BF_REQUIRE(x && w && b && mean && rstd && sc && sh, "bf_in_stats: null pointer");
     BF_REQUIRE(frames > 0 && S > 0 && C > 0, "bf_in_stats: empty");
     dim3 grid(frames, bf_cdiv(C, CPB));
     if (gdiv < 1) gdiv = 1;
     BfProfScope prof((hipStream_t)stream, "in_stats", 0.0, (double)frames * S * C * bf_esize(dtype));
+    {
+        const int rows = dtype == BF_DTYPE_BF16 ? slice_rows<bf16>() : slice_rows<float>();
+        if (ws && S > rows) {                     // long frames: slices + exact merge
+            BF_REQUIRE(C % (dtype == BF_DTYPE_BF16 ? 8 : 4) == 0, "bf_in_stats: C must be a multiple of the 16-byte chunk");
+            const int nsl = bf_cdiv(S, rows);
+            BF_REQUIRE((long)frames * nsl < 2147483647L, "bf_in_stats: grid too large");
+            float* part = ws + (size_t)2 * frames * C;
+            dim3 sg(frames * nsl, bf_cdiv(C, CPB));
+            if (dtype == BF_DTYPE_BF16) hipLaunchKernelGGL(in_stats_slice_kernel<bf16>, sg, dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, S, C, nsl, part);
+            else hipLaunchKernelGGL(in_stats_slice_kernel<float>, sg, dim3(NT), 0, (hipStream_t)stream, (const float*)x, S, C, nsl, part);
+            BF_CHECK_LAUNCH();
+            hipLaunchKernelGGL(in_stats_merge_kernel, dim3(bf_cdiv((long)frames * C, NT)), dim3(NT), 0, (hipStream_t)stream, (const float*)part, frames, S, C,
+                               nsl, rows, w, b, g, gdiv, gb, mean, rstd, sc, sh);
+            BF_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if (dtype == BF_DTYPE_BF16) {
         BF_REQUIRE(chunk_ok<bf16>(C), "bf_in_stats: C must be a multiple of 8 (bf16)");
         if (S <= Geo<bf16>::RG * MAXR) hipLaunchKernelGGL((in_stats_kernel<bf16, true>), grid, dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh);
@@ -358,6 +553,23 @@ extern "C" int bf_in_bwd(int dtype, const void* dy, const void* x, const void* a
     if (gdiv < 1) gdiv = 1;
     hipStream_t st = (hipStream_t)stream;
     BfProfScope prof(st, "in_bwd", 0.0, (double)frames * S * C * bf_esize(dtype) * (add ? 4.0 : 3.0));
+    const int rows = dtype == BF_DTYPE_BF16 ? slice_rows<bf16>() : slice_rows<float>();
+    if (ws && S > rows) {                         // long frames: slice reduce -> sum -> slice apply
+        const int nsl = bf_cdiv(S, rows);
+        BF_REQUIRE((long)frames * nsl < 2147483647L, "bf_in_bwd: grid too large");
+        float* part = ws + (size_t)2 * frames * C;
+        dim3 sg(frames * nsl, bf_cdiv(C, CPB));
+#define GOS(T, G)                                                                                                                        \
+    do {                                                                                                                                  \
+        hipLaunchKernelGGL((in_bwd_slice_kernel<T, G, 0>), sg, dim3(NT), 0, st, (const T*)dy, (const T*)x, (const T*)add, (T*)dx, S, C, nsl, mean, rstd, w, b, g, gdiv, part, (const float*)ws); \
+        hipLaunchKernelGGL(in_slice_sum_kernel, dim3(bf_cdiv((long)frames * C, NT)), dim3(NT), 0, st, (const float*)part, (long)frames * C, C, nsl, ws); \
+        hipLaunchKernelGGL((in_bwd_slice_kernel<T, G, 1>), sg, dim3(NT), 0, st, (const T*)dy, (const T*)x, (const T*)add, (T*)dx, S, C, nsl, mean, rstd, w, b, g, gdiv, part, (const float*)ws); \
+    } while (0)
+        if (dtype == BF_DTYPE_BF16) { if (gelu) GOS(bf16, true); else GOS(bf16, false); }
+        else { if (gelu) GOS(float, true); else GOS(float, false); }
+#undef GOS
+        BF_CHECK_LAUNCH();
+    } else {
 #define GO(T, G)                                                                                                                         \
     do {                                                                                                                                  \
         if (S <= Geo<T>::RG * MAXR) hipLaunchKernelGGL((in_bwd_kernel<T, G, true>), grid, dim3(NT), 0, st, (const T*)dy, (const T*)x, (const T*)add, (T*)dx, S, C, mean, rstd, w, b, g, gdiv, dw, db, dg, dgb, ws); \
@@ -367,6 +579,7 @@ extern "C" int bf_in_bwd(int dtype, const void* dy, const void* x, const void* a
     else { if (gelu) GO(float, true); else GO(float, false); }
 #undef GO
     BF_CHECK_LAUNCH();
+    }
     if (ws) {
         // no per-group scale / outputs: any grouping is valid -> 16 frames per workgroup keeps the grid wide
         const int rdiv = (!g && !dg && !dgb) ? 16 : gdiv;

@@ -25,9 +25,22 @@ def gemm(dtype, M, N, K, A: L.Operand, B: L.Operand, E: L.Epilogue, splitk=1):
 def in_stats(x, frames, S, Cc, w, b, g=None, gdiv=1, gb=None):
     dev = x.device
     mean, rstd, sc, sh = (torch.empty(frames, Cc, dtype=torch.float32, device=dev) for _ in range(4))
+    ws = torch.empty(L.lib().bf_in_ws_floats(_dt(x.dtype), frames, S, Cc), dtype=torch.float32, device=dev)
     L.check(L.lib().bf_in_stats(_dt(x.dtype), _p(x), frames, S, Cc, _p(w), _p(b), _p(g), gdiv, _p(gb), _p(mean), _p(rstd), _p(sc),
-                                _p(sh), _stream()), "bf_in_stats")
+                                _p(sh), _p(ws), _stream()), "bf_in_stats")
     return mean, rstd, sc, sh
+
+
+def in_bwd(dy, x, frames, S, Cc, mean, rstd, w, b, add=None, g=None, gdiv=1, gelu=False, use_ws=True):
+    """InstanceNorm backward through the C ABI: returns (dx, dw, db)."""
+    dev = x.device
+    dx = torch.empty_like(x)
+    dw = torch.zeros(Cc, dtype=torch.float32, device=dev)
+    db = torch.zeros(Cc, dtype=torch.float32, device=dev)
+    ws = torch.empty(L.lib().bf_in_ws_floats(_dt(x.dtype), frames, S, Cc), dtype=torch.float32, device=dev) if use_ws else None
+    L.check(L.lib().bf_in_bwd(_dt(x.dtype), _p(dy), _p(x), _p(add), _p(dx), frames, S, Cc, _p(mean), _p(rstd), _p(w), _p(b), _p(g), gdiv,
+                              int(gelu), _p(dw), _p(db), None, None, _p(ws), _stream()), "bf_in_bwd")
+    return dx, dw, db
 
 
 def attn_fwd(qkv, out, nseq, Lq, inner, outer_stride, inner_stride, tok_stride, heads, d, qw, qb, kw, kb, emb, hscale, out_scale=1.0,

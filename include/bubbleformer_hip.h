@@ -97,14 +97,18 @@ int bf_gemm(int dtype, int M, int N, int K, const bf_operand* A, const bf_operan
  * mean/rstd [frames][C]; sc = rstd*w (*g), sh = (b - mean*rstd*w) (*g + gb): the affine the consumer GEMM applies.
  * g/gb (optional): [frames/gdiv][C] post scale / shift (FiLM gamma/beta per batch element, or a layer scale). */
 int bf_in_stats(int dtype, const void* x, int frames, int S, int C, const float* w, const float* b, const float* g, int gdiv,
-                const float* gb, float* mean, float* rstd, float* sc, float* sh, bf_stream_t stream);
+                const float* gb, float* mean, float* rstd, float* sc, float* sh,
+                float* ws /* optional, bf_in_ws_floats(): long frames are reduced in slices (frames x slices workgroups) */,
+                bf_stream_t stream);
+/* floats of workspace bf_in_stats / bf_in_bwd want for this problem (2*frames*C, plus slice partials for long frames) */
+int64_t bf_in_ws_floats(int dtype, int frames, int S, int C);
 /* out = [resid +] z * sc[f,c] + sh[f,c] */
 int bf_affine_apply(int dtype, const void* z, const void* resid, const float* sc, const float* sh, void* out, int64_t nrows,
                     int S, int C, bf_stream_t stream);
 /* backward of y = act(xhat*w + b) [*g]; dx = ... [+ add]; dw/db/dg/dgb accumulate (fp32 atomics) */
 int bf_in_bwd(int dtype, const void* dy, const void* x, const void* add, void* dx, int frames, int S, int C, const float* mean,
               const float* rstd, const float* w, const float* b, const float* g, int gdiv, int gelu, float* dw, float* db,
-              float* dg, float* dgb, float* ws /* optional 2*frames*C floats: per-frame partials + reduce instead of atomics */,
+              float* dg, float* dgb, float* ws /* optional, bf_in_ws_floats(): per-frame partials + reduce instead of atomics */,
               bf_stream_t stream);
 /* out[c] += scale[c] * sum_rows x[row][c] */
 int bf_colsum(int dtype, const void* x, int64_t nrows, int C, const float* scale, float* out, bf_stream_t stream);

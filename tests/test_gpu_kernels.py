@@ -102,9 +102,10 @@ def test_gemm_patch_gather_and_scatter(K, dtype):
     assert _rel(up.float().permute(0, 3, 1, 2), ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("S", [37, 1000])     # 1000 tokens per frame: the sliced (frames x slices) path with a ragged last slice
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_in_stats_two_pass(K, dtype):
-    Fr, S, Cc = 5, 37, 72
+def test_in_stats_two_pass(K, dtype, S):
+    Fr, Cc = 5, 72
     g = torch.Generator(device="cuda").manual_seed(5)
     x = (torch.randn(Fr, S, Cc, device="cuda", generator=g) * 3 + 100.0).to(dtype)     # large mean: a one-pass variance would fail
     w = torch.randn(Cc, device="cuda", generator=g)
@@ -121,6 +122,32 @@ def test_in_stats_two_pass(K, dtype):
     _, _, sc2, sh2 = K.in_stats(x2, Fr, S, Cc, w, b)
     x2f = x2.float()
     assert _rel(x2f * sc2[:, None] + sh2[:, None], torch.nn.functional.instance_norm(x2f.permute(0, 2, 1), weight=w, bias=b).permute(0, 2, 1)) < 5e-6
+
+
+@pytest.mark.parametrize("gelu", [False, True])
+@pytest.mark.parametrize("S", [50, 700])      # 700: sliced reduce / sum / apply path (ragged last slice), 50: one workgroup per frame
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_in_bwd_matches_autograd(K, dtype, S, gelu):
+    """nn.InstanceNorm2d(affine) [+ GELU] backward, incl. the residual add and the parameter gradients."""
+    Fr, Cc = 3, 40
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = (torch.randn(Fr, S, Cc, device="cuda", generator=g) * 1.5 + 0.3).to(dtype)
+    dy = torch.randn(Fr, S, Cc, device="cuda", generator=g).to(dtype)
+    add = torch.randn(Fr, S, Cc, device="cuda", generator=g).to(dtype)
+    w = torch.randn(Cc, device="cuda", generator=g)
+    b = torch.randn(Cc, device="cuda", generator=g)
+    mean, rstd, _, _ = K.in_stats(x, Fr, S, Cc, w, b)
+    dx, dw, db = K.in_bwd(dy, x, Fr, S, Cc, mean, rstd, w, b, add=add, gelu=gelu)
+    xr = x.double().requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    y = torch.nn.functional.instance_norm(xr.permute(0, 2, 1), weight=wr, bias=br, eps=1e-5).permute(0, 2, 1)
+    if gelu:
+        y = torch.nn.functional.gelu(y)
+    (y * dy.double()).sum().backward()
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-2
+    assert _rel(dx.double(), xr.grad + add.double()) < tol
+    assert _rel(dw.double(), wr.grad) < tol
+    assert _rel(db.double(), br.grad) < tol
 
 
 def _attn_call(L_lib, qkv, dout, geo, heads, d, prm, generic):
