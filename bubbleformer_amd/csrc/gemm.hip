@@ -147,7 +147,7 @@ struct StagerFixed {
 #pragma unroll
                     for (int j = 0; j < CH; j += 4) {     // 16-byte aligned: channels come in whole chunks
                         const float4 a4 = *reinterpret_cast<const float4*>(tab.sc + o + j);
-                        const float4 b4 = *reinterpret_cast<const float4*>(tab.sh + o + j);
+                        const float4 b4 = tab.sh ? *reinterpret_cast<const float4*>(tab.sh + o + j) : float4{0.f, 0.f, 0.f, 0.f};
                         sc[j] = a4.x; sc[j + 1] = a4.y; sc[j + 2] = a4.z; sc[j + 3] = a4.w;
                         sh[j] = b4.x; sh[j + 1] = b4.y; sh[j + 2] = b4.z; sh[j + 3] = b4.w;
                     }
@@ -386,7 +386,7 @@ extern "C" int bf_gemm(int dtype, int M, int N, int K, const bf_operand* A, cons
                "bf_gemm: output geometry must keep 4-column groups whole");
     for (const bf_operand* o : {A, B}) {
         if (o->pro == BF_PRO_AFFINE || o->pro == BF_PRO_AFFINE_GELU) {
-            BF_REQUIRE(o->sc && o->sh && o->rows_per_frame > 0 && o->nch > 0 && o->nch % ch == 0,
+            BF_REQUIRE(o->sc && o->rows_per_frame > 0 && o->nch > 0 && o->nch % ch == 0,
                        "bf_gemm: affine prologue needs sc/sh, rows_per_frame and nch (multiple of the chunk)");
         }
     }

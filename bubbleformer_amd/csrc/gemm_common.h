@@ -58,7 +58,7 @@ __device__ __forceinline__ ProTab stage_table(const OpDev& op, long r_lo, long r
             const int fi = i / cw, c = c_lo + i % cw;
             const bool v = c < op.nch;
             lds_sc[i] = v ? op.sc[(long)(t.f_lo + fi) * op.nch + c] : 0.f;
-            lds_sh[i] = v ? op.sh[(long)(t.f_lo + fi) * op.nch + c] : 0.f;
+            lds_sh[i] = (v && op.sh) ? op.sh[(long)(t.f_lo + fi) * op.nch + c] : 0.f;     // sh == NULL: pure scale
         }
         t.sc = lds_sc; t.sh = lds_sh;
     } else {

@@ -90,7 +90,7 @@ struct WStager {
 #pragma unroll
                     for (int j = 0; j < 8; j += 4) {
                         const float4 a4 = *reinterpret_cast<const float4*>(tab.sc + o + j);
-                        const float4 b4 = *reinterpret_cast<const float4*>(tab.sh + o + j);
+                        const float4 b4 = tab.sh ? *reinterpret_cast<const float4*>(tab.sh + o + j) : float4{0.f, 0.f, 0.f, 0.f};
                         sc[j] = a4.x; sc[j + 1] = a4.y; sc[j + 2] = a4.z; sc[j + 3] = a4.w;
                         sh[j] = b4.x; sh[j + 1] = b4.y; sh[j + 2] = b4.z; sh[j + 3] = b4.w;
                     }

@@ -199,12 +199,18 @@ __global__ void frame_table_kernel(const float* __restrict__ m, int fdiv, const 
     const int f = (int)(i / C), c = (int)(i % C);
     out[i] = m[f / fdiv] * (v ? v[c] : 1.f);
 }
-__global__ void frame_wcolsum_kernel(const float* __restrict__ t, const float* __restrict__ m, int fdiv, float* __restrict__ dv, int F, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// grid (ceil(C/64), ceil(F/16)), 256 threads = 64 channels x 4 frame lanes; a few atomics per address
+__global__ void __launch_bounds__(256) frame_wcolsum_kernel(const float* __restrict__ t, const float* __restrict__ m, int fdiv, float* __restrict__ dv, int F, int C) {
+    __shared__ float red[4][64];
+    const int l = threadIdx.x & 63, fl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + l;
+    const int f1 = min(F, ((int)blockIdx.y + 1) * 16);
     float acc = 0.f;
-    for (int f = 0; f < F; ++f) acc += m[f / fdiv] * t[(long)f * C + c];
-    dv[c] += acc;
+    if (c < C)
+        for (int f = blockIdx.y * 16 + fl; f < f1; f += 4) acc += m[f / fdiv] * t[(long)f * C + c];
+    red[fl][l] = acc;
+    __syncthreads();
+    if (fl == 0 && c < C) atomicAdd(dv + c, red[0][l] + red[1][l] + red[2][l] + red[3][l]);
 }
 __global__ void fill_kernel(float* p, float v, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
 
@@ -373,7 +379,7 @@ int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* o, 
     BF_CHECK_LAUNCH();
     {   // don = (dout * alpha) @ W     (alpha per reduction column; frame independent)
         bf_operand A = op_plain(dout, d.E, BF_LAY_KC);
-        op_affine(A, BF_PRO_AFFINE, alpha, sc.zeros, d.N, d.E);
+        op_affine(A, BF_PRO_AFFINE, alpha, nullptr, d.N, d.E);
         bf_operand Bo = op_plain(w_c, d.E, BF_LAY_XC);
         bf_epilogue e = epi_store(don, d.E);
         TRY(bf_gemm(d.dtype, (int)d.N, d.E, d.E, &A, &Bo, &e, 1, st));
@@ -455,7 +461,6 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
     Scratch sc(d, scratch);
     const void* win_c = d.dtype == BF_DTYPE_F32 ? (const void*)p->input_head_w : sv.win_c;
     const void* wout_c = d.dtype == BF_DTYPE_F32 ? (const void*)p->output_head_w : sv.wout_c;
-    ZERO(sc.zeros, (size_t)4 * d.E * 4);
     Fork fk(st);            // weight-gradient GEMMs go to the side stream; nothing they read (dbr, t3, s1) is rewritten before the join
     void* don = sc.t1;      // [N][E]
     void* dO = sc.t1b;      // [N][E]
@@ -464,7 +469,7 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
     if (drop) {             // branch = drop[b] * (...): scale the incoming gradient once (2U pass), the rest is unchanged
         hipLaunchKernelGGL(frame_table_kernel, dim3(bf_cdiv(d.F * d.E, 256)), dim3(256), 0, st, drop, d.T, (const float*)nullptr, sv.mtab, (int)d.F, d.E);
         BF_CHECK_LAUNCH();
-        TRY(bf_affine_apply(d.dtype, dout, nullptr, sv.mtab, sc.zeros, sc.t4, d.N, (int)d.S, d.E, st));
+        TRY(bf_affine_apply(d.dtype, dout, nullptr, sv.mtab, nullptr, sc.t4, d.N, (int)d.S, d.E, st));
         dbr = sc.t4;
     }
     TRY(outproj_bwd(d, sc, dbr, sv.o, sv.sc2, sv.sh2, wout_c, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr,
@@ -552,7 +557,6 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     const void* wout_c = f32 ? (const void*)p->output_head_w : sv.wout_c;
     const void* w1_c = f32 ? (const void*)p->fc1_w : sv.w1_c;
     const void* w2_c = f32 ? (const void*)p->fc2_w : sv.w2_c;
-    ZERO(sc.zeros, (size_t)4 * d.E * 4);
     // weight-gradient GEMMs go to the side stream and are joined at the end; every buffer they read (dz = t1, dpre = t4,
     // dx1 = t1b, dbr = e5, dqkv = t3, s1) is written once per call, so the critical path below never recycles one under them.
     Fork fk(st);
@@ -562,7 +566,7 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
         ZERO(sc.dgtab, (size_t)d.F * d.E * 4);
         TRY(bf_in_bwd(d.dtype, dout, sv.z, nullptr, dz, (int)d.F, (int)d.S, d.E, sv.mean3, sv.rstd3, p->mlp_norm_w, p->mlp_norm_b, sv.gtab, 1, 0,
                       g->mlp_norm_w, g->mlp_norm_b, sc.dgtab, nullptr, sc.in_ws, st));
-        hipLaunchKernelGGL(frame_wcolsum_kernel, dim3(bf_cdiv(d.E, 64)), dim3(64), 0, st, (const float*)sc.dgtab, drop_mlp, 1, g->gamma_mlp, (int)d.F, d.E);
+        hipLaunchKernelGGL(frame_wcolsum_kernel, dim3(bf_cdiv(d.E, 64), bf_cdiv(d.F, 16)), dim3(256), 0, st, (const float*)sc.dgtab, drop_mlp, 1, g->gamma_mlp, (int)d.F, d.E);
         BF_CHECK_LAUNCH();
     } else
     TRY(bf_in_bwd(d.dtype, dout, sv.z, nullptr, dz, (int)d.F, (int)d.S, d.E, sv.mean3, sv.rstd3, p->mlp_norm_w, p->mlp_norm_b, p->gamma_mlp,
@@ -587,7 +591,7 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     if (drop_att) {
         hipLaunchKernelGGL(frame_table_kernel, dim3(bf_cdiv(d.F * d.E, 256)), dim3(256), 0, st, drop_att, 1, (const float*)nullptr, sv.mtab, (int)d.F, d.E);
         BF_CHECK_LAUNCH();
-        TRY(bf_affine_apply(d.dtype, dx1, nullptr, sv.mtab, sc.zeros, sc.e5, d.N, (int)d.S, d.E, st));
+        TRY(bf_affine_apply(d.dtype, dx1, nullptr, sv.mtab, nullptr, sc.e5, d.N, (int)d.S, d.E, st));
         dbr = sc.e5;
     }
     TRY(outproj_bwd(d, sc, dbr, sv.o, sv.sc2, sv.sh2, wout_c, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att,

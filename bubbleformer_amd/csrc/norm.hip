@@ -164,25 +164,35 @@ __global__ void __launch_bounds__(NT) in_stats_slice_kernel(const T* __restrict_
         for (int j = 0; j < CH; ++j) { o[2 * j] = mu[j]; o[2 * j + 1] = acc[0][j]; }
     }
 }
-// one thread per (frame, channel): merge the slices, then the same outputs as in_stats_kernel
+// grid (ceil(C/64), frames), 256 threads = 64 channels x 4 slice lanes: merge the slices, then the same outputs as in_stats_kernel
 __global__ void __launch_bounds__(NT) in_stats_merge_kernel(const float* __restrict__ part, int frames, int S, int C, int nsl, int rows,
                                                            const float* __restrict__ w, const float* __restrict__ b,
                                                            const float* __restrict__ g, int gdiv, const float* __restrict__ gb,
                                                            float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ sc,
                                                            float* __restrict__ sh) {
-    const long i = (long)blockIdx.x * NT + threadIdx.x;
-    if (i >= (long)frames * C) return;
-    const int f = (int)(i / C), c = (int)(i % C);
-    const float2* pp = reinterpret_cast<const float2*>(part) + (long)f * nsl * C + c;
+    __shared__ float red[2][4][64];
+    const int l = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + l, f = blockIdx.y;
+    const bool cv = c < C;
+    const float2* pp = reinterpret_cast<const float2*>(part) + (long)f * nsl * C + (cv ? c : 0);
     float tot = 0.f;
-    for (int sl = 0; sl < nsl; ++sl) tot += pp[(long)sl * C].x * (float)min(rows, S - sl * rows);
-    const float mu = tot / (float)S;
+    if (cv)
+        for (int sl = q; sl < nsl; sl += 4) tot += pp[(long)sl * C].x * (float)min(rows, S - sl * rows);
+    red[0][q][l] = tot;
+    __syncthreads();
+    const float mu = (red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l]) / (float)S;
     float m2 = 0.f;
-    for (int sl = 0; sl < nsl; ++sl) {
-        const float2 v = pp[(long)sl * C];
-        const float dm = v.x - mu;
-        m2 += v.y + dm * dm * (float)min(rows, S - sl * rows);
-    }
+    if (cv)
+        for (int sl = q; sl < nsl; sl += 4) {
+            const float2 v = pp[(long)sl * C];
+            const float dm = v.x - mu;
+            m2 += v.y + dm * dm * (float)min(rows, S - sl * rows);
+        }
+    red[1][q][l] = m2;
+    __syncthreads();
+    if (q != 0 || !cv) return;
+    m2 = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+    const long i = (long)f * C + c;
     const float r = rsqrtf(m2 / (float)S + BF_IN_EPS);
     float a = r * w[c];
     float s0 = b[c] - mu * a;
@@ -211,8 +221,14 @@ __global__ void __launch_bounds__(NT) affine_apply_kernel(const T* __restrict__ 
         Chunk<T> v, r, o;
         v.load(z + row * C + c);
         if (resid) r.load(resid + row * C + c);
-        const float* a = sc + f * C + c;
-        const float* b = sh + f * C + c;
+        float a[CH], b[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j += 4) {        // 16-byte aligned: C and c are multiples of the chunk
+            const float4 a4 = *reinterpret_cast<const float4*>(sc + f * C + c + j);
+            const float4 b4 = sh ? *reinterpret_cast<const float4*>(sh + f * C + c + j) : float4{0.f, 0.f, 0.f, 0.f};
+            a[j] = a4.x; a[j + 1] = a4.y; a[j + 2] = a4.z; a[j + 3] = a4.w;
+            b[j] = b4.x; b[j + 1] = b4.y; b[j + 2] = b4.z; b[j + 3] = b4.w;
+        }
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             float t = v.get(j) * a[j] + b[j];
@@ -410,14 +426,21 @@ __global__ void __launch_bounds__(NT) in_bwd_slice_kernel(const T* __restrict__ 
         }
     }
 }
-__global__ void __launch_bounds__(NT) in_slice_sum_kernel(const float* __restrict__ part, long FC, int C, int nsl, float* __restrict__ tot) {
-    const long i = (long)blockIdx.x * NT + threadIdx.x;
-    if (i >= FC) return;
-    const long f = i / C; const int c = (int)(i % C);
-    const float2* pp = reinterpret_cast<const float2*>(part) + f * nsl * C + c;
+// grid (ceil(C/64), frames), 256 threads = 64 channels x 4 slice lanes
+__global__ void __launch_bounds__(NT) in_slice_sum_kernel(const float* __restrict__ part, int C, int nsl, float* __restrict__ tot) {
+    __shared__ float red[2][4][64];
+    const int l = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + l, f = blockIdx.y;
+    const bool cv = c < C;
+    const float2* pp = reinterpret_cast<const float2*>(part) + (long)f * nsl * C + (cv ? c : 0);
     float a = 0.f, b = 0.f;
-    for (int sl = 0; sl < nsl; ++sl) { const float2 v = pp[(long)sl * C]; a += v.x; b += v.y; }
-    reinterpret_cast<float2*>(tot)[i] = make_float2(a, b);
+    if (cv)
+        for (int sl = q; sl < nsl; sl += 4) { const float2 v = pp[(long)sl * C]; a += v.x; b += v.y; }
+    red[0][q][l] = a; red[1][q][l] = b;
+    __syncthreads();
+    if (q != 0 || !cv) return;
+    reinterpret_cast<float2*>(tot)[(long)f * C + c] = make_float2(red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l],
+                                                                 red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l]);
 }
 
 // parameter gradients from the per-frame partials ws[f][c] = {s1, s2}.
@@ -508,7 +531,7 @@ extern "C" int bf_in_stats(int dtype, const void* x, int frames, int S, int C, c
             if (dtype == BF_DTYPE_BF16) hipLaunchKernelGGL(in_stats_slice_kernel<bf16>, sg, dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, S, C, nsl, part);
             else hipLaunchKernelGGL(in_stats_slice_kernel<float>, sg, dim3(NT), 0, (hipStream_t)stream, (const float*)x, S, C, nsl, part);
             BF_CHECK_LAUNCH();
-            hipLaunchKernelGGL(in_stats_merge_kernel, dim3(bf_cdiv((long)frames * C, NT)), dim3(NT), 0, (hipStream_t)stream, (const float*)part, frames, S, C,
+            hipLaunchKernelGGL(in_stats_merge_kernel, dim3(bf_cdiv(C, 64), frames), dim3(NT), 0, (hipStream_t)stream, (const float*)part, frames, S, C,
                                nsl, rows, w, b, g, gdiv, gb, mean, rstd, sc, sh);
             BF_CHECK_LAUNCH();
             return 0;
@@ -529,7 +552,7 @@ extern "C" int bf_in_stats(int dtype, const void* x, int frames, int S, int C, c
 
 extern "C" int bf_affine_apply(int dtype, const void* z, const void* resid, const float* sc, const float* sh, void* out,
                                int64_t nrows, int S, int C, bf_stream_t stream) {
-    BF_REQUIRE(z && sc && sh && out && nrows > 0 && S > 0, "bf_affine_apply: bad arguments");
+    BF_REQUIRE(z && sc && out && nrows > 0 && S > 0, "bf_affine_apply: bad arguments");
     const int ch = dtype == BF_DTYPE_BF16 ? 8 : 4;
     BF_REQUIRE(C % ch == 0, "bf_affine_apply: C must be a multiple of the 16-byte chunk");
     const long total = nrows * (C / ch);
@@ -562,7 +585,7 @@ extern "C" int bf_in_bwd(int dtype, const void* dy, const void* x, const void* a
 #define GOS(T, G)                                                                                                                        \
     do {                                                                                                                                  \
         hipLaunchKernelGGL((in_bwd_slice_kernel<T, G, 0>), sg, dim3(NT), 0, st, (const T*)dy, (const T*)x, (const T*)add, (T*)dx, S, C, nsl, mean, rstd, w, b, g, gdiv, part, (const float*)ws); \
-        hipLaunchKernelGGL(in_slice_sum_kernel, dim3(bf_cdiv((long)frames * C, NT)), dim3(NT), 0, st, (const float*)part, (long)frames * C, C, nsl, ws); \
+        hipLaunchKernelGGL(in_slice_sum_kernel, dim3(bf_cdiv(C, 64), frames), dim3(NT), 0, st, (const float*)part, C, nsl, ws); \
         hipLaunchKernelGGL((in_bwd_slice_kernel<T, G, 1>), sg, dim3(NT), 0, st, (const T*)dy, (const T*)x, (const T*)add, (T*)dx, S, C, nsl, mean, rstd, w, b, g, gdiv, part, (const float*)ws); \
     } while (0)
         if (dtype == BF_DTYPE_BF16) { if (gelu) GOS(bf16, true); else GOS(bf16, false); }

@@ -25,8 +25,11 @@ class SpaceTimeBlock(nn.Module):
         self.spatial = AxialAttentionBlock(embed_dim=embed_dim, num_heads=num_heads, drop_path=drop_path, attn_scale=attn_scale,
                                            feat_scale=feat_scale)
 
-    def forward_tokens(self, tok: torch.Tensor) -> torch.Tensor:
-        return self.spatial.forward_tokens(self.temporal.forward_tokens(tok))
+    def forward_tokens(self, tok: torch.Tensor, drops=None) -> torch.Tensor:
+        """drops: optional (temporal [B], axial attention [B*T], MLP [B*T]) stochastic-depth factors drawn by the caller."""
+        if drops is None:
+            return self.spatial.forward_tokens(self.temporal.forward_tokens(tok))
+        return self.spatial.forward_tokens(self.temporal.forward_tokens(tok, drops[0]), drops[1], drops[2])
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: (B, T, emb, H, W) -> same."""
@@ -49,8 +52,25 @@ class _AxialBase(nn.Module):
         self.debed = HMLPDebed(patch_size=patch_size, embed_dim=embed_dim, out_channels=output_fields)
 
     def _process(self, tok):
-        for blk in self.blocks:
-            tok = blk.forward_tokens(tok)
+        # training mode: the per-sample stochastic-depth factors of ALL blocks come from one uniform draw (2 launches per step
+        # instead of 6 per block); each DropPath call of the reference still gets its own independent Bernoulli(keep) samples.
+        rates = [float(getattr(blk.temporal.drop_path, "drop_prob", 0.0)) for blk in self.blocks]
+        table = None
+        if self.training and any(r > 0.0 for r in rates):
+            B, F = tok.shape[0], tok.shape[0] * tok.shape[1]
+            cache = self.__dict__.setdefault("_keep_cache", {})
+            key = (str(tok.device), tuple(rates))
+            if key not in cache:
+                cache.clear()
+                cache[key] = torch.tensor([1.0 - r for r in rates], dtype=torch.float32, device=tok.device)[:, None]
+            keep = cache[key]
+            table = (torch.rand(len(rates), B + 2 * F, dtype=torch.float32, device=tok.device) < keep).float() / keep
+        for i, blk in enumerate(self.blocks):
+            if table is not None and rates[i] > 0.0:
+                row = table[i]
+                tok = blk.forward_tokens(tok, (row[:B], row[B:B + F], row[B + F:]))
+            else:
+                tok = blk.forward_tokens(tok)
         return tok
 
 

@@ -63,7 +63,7 @@ typedef struct bf_operand {
     int32_t gw, gh, gc;     /* 0 = plain rows */
     int32_t pro;            /* BF_PRO_* */
     const float* sc;        /* [frames][nch] scale  (AFFINE*) */
-    const float* sh;        /* [frames][nch] shift            */
+    const float* sh;        /* [frames][nch] shift (NULL = 0) */
     int32_t rows_per_frame; /* frame = row / rows_per_frame   */
     int32_t nch;            /* channel = col % nch            */
 } bf_operand;
@@ -102,7 +102,7 @@ int bf_in_stats(int dtype, const void* x, int frames, int S, int C, const float*
                 bf_stream_t stream);
 /* floats of workspace bf_in_stats / bf_in_bwd want for this problem (2*frames*C, plus slice partials for long frames) */
 int64_t bf_in_ws_floats(int dtype, int frames, int S, int C);
-/* out = [resid +] z * sc[f,c] + sh[f,c] */
+/* out = [resid +] z * sc[f,c] + sh[f,c]   (sh may be NULL = 0) */
 int bf_affine_apply(int dtype, const void* z, const void* resid, const float* sc, const float* sh, void* out, int64_t nrows,
                     int S, int C, bf_stream_t stream);
 /* backward of y = act(xhat*w + b) [*g]; dx = ... [+ add]; dw/db/dg/dgb accumulate (fp32 atomics) */
