@@ -15,6 +15,7 @@
 //     dV^T[e][j]  = sum_i dO[i][e] A[i][j]          A = dO^T (tr read), B = A^T through the same transpose
 // and finishes LayerNorm backward in the operand layout after one LDS re-layout (16-byte global stores).
 #include "bf_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -32,8 +33,22 @@ __device__ __forceinline__ int t5b(int n) {   // n = query - key  (see attn.hip)
     else if (a < 20) b = 12; else if (a < 23) b = 13; else if (a < 27) b = 14; else b = 15;
     return b + (n < 0 ? 16 : 0);
 }
-__device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
-__device__ __forceinline__ float quad_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64)); return v; }
+// Reductions over a lane quad {l, l+16, l+32, l+48} with the gfx950 row-swap VALU ops (no LDS crossbar round trip):
+// v_permlane16_swap(a, b) exchanges the odd 16-lane rows of a with the even rows of b, v_permlane32_swap the upper half of a
+// with the lower half of b; with a = b = v the two results are v and its xor-16 / xor-32 partner in every lane.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float quad_sum(float v) {
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float quad_max(float v) {
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 
 struct Geo { long nseq; int L; long inner, outer_stride, inner_stride, tok_stride; };
 struct Par { const float *qw, *qb, *kw, *kb, *emb, *hscale; };
@@ -103,8 +118,8 @@ __device__ __forceinline__ void affine_frag(const float (&xh)[KS][8], const floa
 // scores^T for all (key block, query block) pairs -> softmax over keys -> P (and the rescaled A) in registers.
 // sc[jb][ib][r]: lane (i = 16*ib + (l & 15)) x key j = 16*jb + 4*(l >> 4) + r
 template <int NB, int KS>
-__device__ __forceinline__ void scores_softmax(const bf16x8 (&kf)[NB][KS], const bf16x8 (&qf)[NB][KS], const Par& p, int head, int heads, int L,
-                                               int lane, float (&P)[NB][NB][4], float (&A)[NB][NB][4]) {
+__device__ __forceinline__ void scores_softmax(const bf16x8 (&kf)[NB][KS], const bf16x8 (&qf)[NB][KS], const float* emb, int emb_ld,
+                                               const float* hscale, int head, int L, int lane, float (&P)[NB][NB][4], float (&A)[NB][NB][4]) {
     const int g = lane >> 4, i16 = lane & 15;
 #pragma unroll
     for (int jb = 0; jb < NB; ++jb)
@@ -117,12 +132,12 @@ __device__ __forceinline__ void scores_softmax(const bf16x8 (&kf)[NB][KS], const
             for (int r = 0; r < 4; ++r) {
                 const int i = 16 * ib + i16, j = 16 * jb + 4 * g + r;
                 float v = acc[r];
-                if (p.emb) v += p.emb[t5b(i - j) * heads + head];
+                if (emb) v += emb[t5b(i - j) * emb_ld + head];
                 P[jb][ib][r] = j < L ? v : -INFINITY;
             }
         }
     const float invL = 1.0f / (float)L;
-    const float hs = p.hscale ? p.hscale[head] : 1.f;
+    const float hs = hscale ? hscale[head] : 1.f;
 #pragma unroll
     for (int ib = 0; ib < NB; ++ib) {
         float m = -INFINITY;
@@ -144,7 +159,7 @@ __device__ __forceinline__ void scores_softmax(const bf16x8 (&kf)[NB][KS], const
                 const int j = 16 * jb + 4 * g + r;
                 const float pr = P[jb][ib][r] * inv;
                 P[jb][ib][r] = pr;
-                A[jb][ib][r] = j < L ? (p.hscale ? invL + (pr - invL) * hs : pr) : 0.f;
+                A[jb][ib][r] = j < L ? (hscale ? invL + (pr - invL) * hs : pr) : 0.f;
             }
     }
 }
@@ -224,7 +239,7 @@ __global__ void __launch_bounds__(256) attn_fwd_mfma(const bf16* __restrict__ qk
             affine_frag<KS>(x, p.kw, p.kb, 1.f, lane, kf[b]);
         }
         float P[NB][NB][4], A[NB][NB][4];
-        scores_softmax<NB, KS>(kf, qf, p, head, heads, L, lane, P, A);
+        scores_softmax<NB, KS>(kf, qf, p.emb, heads, p.hscale, head, L, lane, P, A);
         wsync();   // V tile visible to the wave
 #pragma unroll
         for (int ib = 0; ib < NB; ++ib) {
@@ -251,14 +266,50 @@ __global__ void __launch_bounds__(256) attn_fwd_mfma(const bf16* __restrict__ qk
     }
 }
 
+// The q / k / v / dO rows of one problem exactly as the MFMA operand layout wants them: lane (i = l & 15, g = l >> 4) holds
+// channels 32*s + 8*g .. +7 of row i.  The backward loads the NEXT problem's rows while it works on the current one: a wave runs
+// ~20 dependent phases per problem, and with only two waves per SIMD every exposed global round trip is paid in full.
+template <int NB, int KS> struct RawRows { bf16x8 q[NB][KS], k[NB][KS], v[NB][KS], d[NB][KS]; };
+template <int NB, int KS> struct OldRows { bf16x8 q[NB][KS], k[NB][KS]; bf16x4 v[NB][2 * KS]; };
+
+template <int NB, int KS>
+__device__ __forceinline__ void load_raw(RawRows<NB, KS>& r, const bf16* __restrict__ qkv, const bf16* __restrict__ dout, const Geo& g, int heads, long pr,
+                                         int lane) {
+    constexpr int D = 32 * KS;
+    const int E = heads * D;
+    const long s = pr / heads;
+    const int head = (int)(pr % heads);
+    const long tok0 = (s / g.inner) * g.outer_stride + (s % g.inner) * g.inner_stride;
+    const int gq = lane >> 4, i16 = lane & 15;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int i = b * 16 + i16, ic = i < g.L ? i : g.L - 1;      // rows >= L: clamped duplicates, masked / never stored later
+        const bf16* rp = qkv + (tok0 + ic * g.tok_stride) * 3L * E + head * 3 * D + 8 * gq;
+        const bf16* dp = dout + (tok0 + ic * g.tok_stride) * (long)E + head * D + 8 * gq;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            r.q[b][ks] = *reinterpret_cast<const bf16x8*>(rp + 32 * ks);
+            r.k[b][ks] = *reinterpret_cast<const bf16x8*>(rp + D + 32 * ks);
+            r.v[b][ks] = *reinterpret_cast<const bf16x8*>(rp + 2 * D + 32 * ks);
+            r.d[b][ks] = *reinterpret_cast<const bf16x8*>(dp + 32 * ks);
+        }
+    }
+}
+
 template <int NB, int KS>
 __global__ void __launch_bounds__(256) attn_bwd_mfma(const bf16* __restrict__ qkv, const bf16* __restrict__ dout, bf16* __restrict__ dqkv, Geo g,
                                                      int heads, Par p, Grd gr, float out_scale, int accumulate, float* __restrict__ ws) {
     constexpr int D = 32 * KS, LD = D + 16, NT16 = D / 16, R = 16 * NB, LDP = 32 + 8, LDF = D + 4;
+    constexpr bool PREFETCH = NB * KS <= 4;      // register budget: 16 * NB * KS VGPRs for the look-ahead rows
     extern __shared__ __attribute__((aligned(16))) bf16 smem_bwd[];
     __shared__ float s_demb[32 * 16];
     __shared__ float s_dhs[16];
     __shared__ float s_ln[4 * 32 * KS];
+    // parameter copies: every problem reads the q/k LayerNorm affine, the T5 bias table and the head scale; from global memory each
+    // of those reads is a dependent round trip in the middle of the problem
+    __shared__ __attribute__((aligned(16))) float s_par[4 * 32 * KS];   // qw | qb | kw | kb
+    __shared__ float s_emb[32 * 16];
+    __shared__ float s_hsc[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     // per-wave: Qn, Kn, dO tiles [R][LD] bf16; A^T and dS^T tiles [R][LDP] bf16 ([key j][query i]); fp32 re-layout buffer aliases the tiles
     constexpr int PER_WAVE = 3 * R * LD + 2 * R * LDP;
@@ -269,62 +320,96 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma(const bf16* __restrict__ qk
     bf16* at_t = do_t + R * LD;
     bf16* ds_t = at_t + R * LDP;
     float* relay = reinterpret_cast<float*>(qn_t);
-    for (int i = threadIdx.x; i < 32 * 16; i += blockDim.x) s_demb[i] = 0.f;
-    if (threadIdx.x < 16) s_dhs[threadIdx.x] = 0.f;
-    for (int i = threadIdx.x; i < 4 * D; i += blockDim.x) s_ln[i] = 0.f;
+    for (int i = threadIdx.x; i < 32 * 16; i += blockDim.x) {
+        s_demb[i] = 0.f;
+        const int t = i >> 4, h = i & 15;
+        s_emb[i] = (p.emb && h < heads) ? p.emb[t * heads + h] : 0.f;
+    }
+    if (threadIdx.x < 16) { s_dhs[threadIdx.x] = 0.f; s_hsc[threadIdx.x] = (p.hscale && (int)threadIdx.x < heads) ? p.hscale[threadIdx.x] : 1.f; }
+    for (int i = threadIdx.x; i < 4 * D; i += blockDim.x) {
+        s_ln[i] = 0.f;
+        const int q = i / D, e = i % D;
+        s_par[i] = (q == 0 ? p.qw : q == 1 ? p.qb : q == 2 ? p.kw : p.kb)[e];
+    }
     __syncthreads();
     const int E = heads * D, L = g.L;
     const float scale = rsqrtf((float)D);
     const long nprob = g.nseq * heads;
     const int gq = lane >> 4, i16 = lane & 15;
+
     float a_qw[KS][8], a_qb[KS][8], a_kw[KS][8], a_kb[KS][8];
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) a_qw[s][j] = a_qb[s][j] = a_kw[s][j] = a_kb[s][j] = 0.f;
-
-    for (long pr = (long)blockIdx.x * wpb + wave; pr < nprob; pr += (long)gridDim.x * wpb) {
+    // When the problem stride is a multiple of `heads` every problem of this wave belongs to ONE head: the T5-bias and head-scale
+    // gradients then accumulate in registers (a lane's (query, key) pairs are fixed) and reach LDS once, at the end.  LDS float
+    // atomics cost ~500 cycles per wave instruction on gfx950: they must stay out of the per-problem path.
+    const long pstep = (long)gridDim.x * wpb;
+    const bool one_head = pstep % heads == 0;
+    float a_emb[NB][NB][4], a_dhs = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+        for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a_emb[jb][ib][r] = 0.f;
+    long pr = (long)blockIdx.x * wpb + wave;
+    RawRows<NB, KS> cur, nxt;
+    if (pr < nprob) load_raw<NB, KS>(cur, qkv, dout, g, heads, pr, lane);
+    for (; pr < nprob; pr += pstep) {
         const long s = pr / heads;
         const int head = (int)(pr % heads);
         const long tok0 = (s / g.inner) * g.outer_stride + (s % g.inner) * g.inner_stride;
-        const bf16* hb = qkv + head * 3 * D;
+        if (PREFETCH && pr + pstep < nprob) load_raw<NB, KS>(nxt, qkv, dout, g, heads, pr + pstep, lane);
+        // gradient rows this problem accumulates into (second axial pass): issued now, consumed at the very end
+        OldRows<NB, KS> old;
+        if (accumulate) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int row = b * 16 + i16, rc = row < L ? row : L - 1;
+                const bf16* ob = dqkv + (tok0 + rc * g.tok_stride) * 3L * E + head * 3 * D;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    old.q[b][ks] = *reinterpret_cast<const bf16x8*>(ob + 32 * ks + 8 * gq);
+                    old.k[b][ks] = *reinterpret_cast<const bf16x8*>(ob + D + 32 * ks + 8 * gq);
+                }
+#pragma unroll
+                for (int t = 0; t < NT16; ++t) old.v[b][t] = *reinterpret_cast<const bf16x4*>(ob + 2 * D + 16 * t + 4 * gq);
+            }
+        }
         float xq[NB][KS][8], xk[NB][KS][8], rq[NB], rk[NB];
         bf16x8 qf[NB][KS], kf[NB][KS], vf[NB][KS], df[NB][KS];
-        stage_tile<NB>(dout + head * D, (long)E, 0, tok0, g.tok_stride, L, D, do_t, LD, lane);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            load_rows_f32<KS>(hb, 3L * E, 0, tok0, g.tok_stride, L, b, lane, xq[b]);
-            rq[b] = ln_quad<KS>(xq[b], D);
-            affine_frag<KS>(xq[b], p.qw, p.qb, scale, lane, qf[b]);
-            load_rows_f32<KS>(hb, 3L * E, D, tok0, g.tok_stride, L, b, lane, xk[b]);
-            rk[b] = ln_quad<KS>(xk[b], D);
-            affine_frag<KS>(xk[b], p.kw, p.kb, 1.f, lane, kf[b]);
-            // V and dO rows straight into operand registers (rows >= L are clamped duplicates; their products are masked / never stored)
-            const int i = b * 16 + i16, ic = i < L ? i : L - 1;
-            const bf16* vp = hb + (tok0 + ic * g.tok_stride) * 3L * E + 2 * D + 8 * gq;
-            const bf16* dp = dout + (tok0 + ic * g.tok_stride) * (long)E + head * D + 8 * gq;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                vf[b][ks] = *reinterpret_cast<const bf16x8*>(vp + 32 * ks);
-                df[b][ks] = *reinterpret_cast<const bf16x8*>(dp + 32 * ks);
-            }
-            // Qn (with the d^-1/2 fold) and Kn tiles for the transposed operands
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { xq[b][ks][j] = (float)cur.q[b][ks][j]; xk[b][ks][j] = (float)cur.k[b][ks][j]; }
+            rq[b] = ln_quad<KS>(xq[b], D);
+            affine_frag<KS>(xq[b], s_par, s_par + D, scale, lane, qf[b]);
+            rk[b] = ln_quad<KS>(xk[b], D);
+            affine_frag<KS>(xk[b], s_par + 2 * D, s_par + 3 * D, 1.f, lane, kf[b]);
+            // Qn (with the d^-1/2 fold), Kn and dO tiles for the transposed operands; rows >= L read as zeros
             const int row = b * 16 + i16;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                bf16x8 zq = qf[b][ks], zk = kf[b][ks];
+                vf[b][ks] = cur.v[b][ks];
+                df[b][ks] = cur.d[b][ks];
+                bf16x8 zq = qf[b][ks], zk = kf[b][ks], zd = df[b][ks];
                 if (row >= L) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { zq[j] = (bf16)0.f; zk[j] = (bf16)0.f; }
+                    for (int j = 0; j < 8; ++j) { zq[j] = (bf16)0.f; zk[j] = (bf16)0.f; zd[j] = (bf16)0.f; }
                 }
                 *reinterpret_cast<bf16x8*>(qn_t + row * LD + 32 * ks + 8 * gq) = zq;
                 *reinterpret_cast<bf16x8*>(kn_t + row * LD + 32 * ks + 8 * gq) = zk;
+                *reinterpret_cast<bf16x8*>(do_t + row * LD + 32 * ks + 8 * gq) = zd;
             }
         }
         float P[NB][NB][4], A[NB][NB][4], dA[NB][NB][4];
-        scores_softmax<NB, KS>(kf, qf, p, head, heads, L, lane, P, A);
+        scores_softmax<NB, KS>(kf, qf, p.emb ? s_emb : nullptr, 16, p.hscale ? s_hsc : nullptr, head, L, lane, P, A);
         // dA^T[j][i] = sum_e V[j][e] dO[i][e] * out_scale
-        const float hs = p.hscale ? p.hscale[head] : 1.f;
+        const float hs = s_hsc[head];
         const float invL = 1.0f / (float)L;
         float dhs = 0.f;
 #pragma unroll
@@ -358,14 +443,16 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma(const bf16* __restrict__ qk
                     const int i = 16 * ib + i16, j = 16 * jb + 4 * gq + r;
                     const float v = (i < L && j < L) ? P[jb][ib][r] * (dA[jb][ib][r] - dot) : 0.f;
                     dA[jb][ib][r] = v;     // now dS
-                    if (gr.demb && i < L && j < L) atomicAdd(&s_demb[t5b(i - j) * 16 + head], v);
+                    if (one_head) a_emb[jb][ib][r] += v;
+                    else if (gr.demb && i < L && j < L) atomicAdd(&s_demb[t5b(i - j) * 16 + head], v);
                     if (i >= L) A[jb][ib][r] = 0.f;
                     // transposed copies [key j][query i] for the products that reduce over queries
                     at_t[j * LDP + i] = (bf16)A[jb][ib][r];
                     ds_t[j * LDP + i] = (bf16)v;
                 }
         }
-        if (p.hscale && gr.dhscale) {
+        if (one_head) a_dhs += dhs;
+        else if (p.hscale && gr.dhscale) {
             dhs = wave_sum(dhs);
             if (lane == 0) atomicAdd(&s_dhs[head], dhs);
         }
@@ -396,9 +483,8 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma(const bf16* __restrict__ qk
                     bf16* dst = dqkv + (tok0 + j * g.tok_stride) * 3L * E + head * 3 * D + 2 * D + 16 * t + 4 * gq;
                     float v[4] = {dv[0] * out_scale, dv[1] * out_scale, dv[2] * out_scale, dv[3] * out_scale};
                     if (accumulate) {
-                        const bf16x4 old = *reinterpret_cast<const bf16x4*>(dst);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += (float)old[r];
+                        for (int r = 0; r < 4; ++r) v[r] += (float)old.v[jb][t][r];
                     }
                     const bf16x4 w4 = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
                     *reinterpret_cast<bf16x4*>(dst) = w4;
@@ -425,7 +511,7 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma(const bf16* __restrict__ qk
                     *reinterpret_cast<float4*>(relay + (16 * b + i16) * LDF + 16 * t + 4 * gq) = v4;
                 }
             wsync();
-            const float* w = part == 0 ? p.qw : p.kw;
+            const float* w = part == 0 ? s_par : s_par + 2 * D;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const int row = 16 * b + i16;
@@ -454,13 +540,11 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma(const bf16* __restrict__ qk
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
                         bf16x8 o;
-                        bf16x8 old;
-                        if (accumulate) old = *reinterpret_cast<const bf16x8*>(dst + 32 * ks);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             const float xh = part == 0 ? xq[b][ks][j] : xk[b][ks][j];
                             float v = rs * (dn[ks][j] - m1 - xh * m2);
-                            if (accumulate) v += (float)old[j];
+                            if (accumulate) v += (float)(part == 0 ? old.q[b][ks][j] : old.k[b][ks][j]);
                             o[j] = (bf16)v;
                         }
                         *reinterpret_cast<bf16x8*>(dst + 32 * ks) = o;
@@ -469,10 +553,28 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma(const bf16* __restrict__ qk
             }
             wsync();
         }
+        if (PREFETCH) cur = nxt;
+        else if (pr + pstep < nprob) load_raw<NB, KS>(cur, qkv, dout, g, heads, pr + pstep, lane);
     }
     // ---- flush parameter gradients.  Thousands of waves adding to the same few hundred addresses serialise at the
-    // memory side, so: lane-group shuffle reduce -> block reduce in LDS -> ONE row of plain stores per block into the
-    // workspace (summed by attn_ws_reduce), or atomics when no workspace is given.
+    // memory side, so: block reduce in LDS -> ONE row of plain stores per block into the workspace (summed by
+    // attn_ws_reduce), or atomics when no workspace is given.
+    if (one_head && pr - pstep >= 0) {        // register-held T5-bias / head-scale gradients of this wave's head
+        const int head = (int)(((long)blockIdx.x * wpb + wave) % heads);
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+            for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * ib + i16, j = 16 * jb + 4 * gq + r;
+                    if (gr.demb && i < L && j < L) atomicAdd(&s_demb[t5b(i - j) * 16 + head], a_emb[jb][ib][r]);
+                }
+        if (p.hscale && gr.dhscale) {
+            a_dhs = wave_sum(a_dhs);
+            if (lane == 0) atomicAdd(&s_dhs[head], a_dhs);
+        }
+    }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -552,7 +654,24 @@ int go_bwd(const bf16* qkv, const bf16* dout, bf16* dqkv, Geo g, int heads, Par 
     if (int rc = set_lds(attn_bwd_mfma<NB, KS>, shm)) return rc;
     const long nprob = g.nseq * heads;
     const int nvals = 4 * D + 32 * heads + heads;
-    long grid = std::min<long>((nprob + wpb - 1) / wpb, 256L * 2);
+    // persistent waves: one resident set of workgroups (what the register / LDS budget admits per CU), each wave loops over problems
+    static int resident = 0;       // per instantiation
+    if (!resident) {
+        int dev = 0, cus = 256, per_cu = 1;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, attn_bwd_mfma<NB, KS>, wpb * 64, shm) != hipSuccess || per_cu < 1) per_cu = 1;
+        static const int bpc = []() { const char* v = getenv("BF_ATTN_BWD_BPC"); return v ? atoi(v) : 0; }();
+        if (bpc > 0) per_cu = bpc;
+        resident = cus * per_cu;
+    }
+    long grid = std::min<long>((nprob + wpb - 1) / wpb, (long)resident);
+    {   // keep (grid * wpb) a multiple of heads when that costs at most a few workgroups: one head per wave (see the kernel)
+        long a = wpb, b = heads;
+        while (b) { const long t = a % b; a = b; b = t; }      // a = gcd(wpb, heads)
+        const long m = heads / a;
+        if (grid >= 8 * m) grid -= grid % m;
+    }
     if (ws && ws_floats < grid * nvals) { grid = ws_floats / nvals; if (grid < 1) ws = nullptr; }
     hipLaunchKernelGGL((attn_bwd_mfma<NB, KS>), dim3((int)grid), dim3(wpb * 64), shm, st, qkv, dout, dqkv, g, heads, p, gr, out_scale, accumulate, ws);
     BF_CHECK_LAUNCH();
