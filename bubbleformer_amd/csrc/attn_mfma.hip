@@ -43,6 +43,14 @@ __device__ __forceinline__ float quad_sum(float v) {
     r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+// total of a 16-lane row in every lane of the row: xor-1 / xor-2 quad permutes, then the half-row and row mirrors (DPP, no LDS)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
 __device__ __forceinline__ float quad_max(float v) {
     u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
@@ -297,14 +305,13 @@ __device__ __forceinline__ void load_raw(RawRows<NB, KS>& r, const bf16* __restr
 }
 
 template <int NB, int KS>
-__global__ void __launch_bounds__(256) attn_bwd_mfma(const bf16* __restrict__ qkv, const bf16* __restrict__ dout, bf16* __restrict__ dqkv, Geo g,
+__global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_mfma(const bf16* __restrict__ qkv, const bf16* __restrict__ dout, bf16* __restrict__ dqkv, Geo g,
                                                      int heads, Par p, Grd gr, float out_scale, int accumulate, float* __restrict__ ws) {
     constexpr int D = 32 * KS, LD = D + 16, NT16 = D / 16, R = 16 * NB, LDP = 32 + 8, LDF = D + 4;
     constexpr bool PREFETCH = NB * KS <= 4;      // register budget: 16 * NB * KS VGPRs for the look-ahead rows
     extern __shared__ __attribute__((aligned(16))) bf16 smem_bwd[];
     __shared__ float s_demb[32 * 16];
     __shared__ float s_dhs[16];
-    __shared__ float s_ln[4 * 32 * KS];
     // parameter copies: every problem reads the q/k LayerNorm affine, the T5 bias table and the head scale; from global memory each
     // of those reads is a dependent round trip in the middle of the problem
     __shared__ __attribute__((aligned(16))) float s_par[4 * 32 * KS];   // qw | qb | kw | kb
@@ -327,7 +334,6 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma(const bf16* __restrict__ qk
     }
     if (threadIdx.x < 16) { s_dhs[threadIdx.x] = 0.f; s_hsc[threadIdx.x] = (p.hscale && (int)threadIdx.x < heads) ? p.hscale[threadIdx.x] : 1.f; }
     for (int i = threadIdx.x; i < 4 * D; i += blockDim.x) {
-        s_ln[i] = 0.f;
         const int q = i / D, e = i % D;
         s_par[i] = (q == 0 ? p.qw : q == 1 ? p.qb : q == 2 ? p.kw : p.kb)[e];
     }
@@ -337,11 +343,13 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma(const bf16* __restrict__ qk
     const long nprob = g.nseq * heads;
     const int gq = lane >> 4, i16 = lane & 15;
 
-    float a_qw[KS][8], a_qb[KS][8], a_kw[KS][8], a_kb[KS][8];
+    // q/k LayerNorm parameter gradients: value v = ((2 * part + {dw: 0, db: 1}) * KS + ks) * 8 + j of channel group gq.  Each
+    // problem's 16-row totals (DPP row reduction, VALU only) are deposited in lane (v & 15) of the row, slot v >> 4: 2 * KS
+    // accumulator registers per lane instead of 32 * KS, which is what lets two waves share a SIMD.
+    constexpr int NACC = 2 * KS;
+    float a_ln[NACC];
 #pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) a_qw[s][j] = a_qb[s][j] = a_kw[s][j] = a_kb[s][j] = 0.f;
+    for (int k = 0; k < NACC; ++k) a_ln[k] = 0.f;
     // When the problem stride is a multiple of `heads` every problem of this wave belongs to ONE head: the T5-bias and head-scale
     // gradients then accumulate in registers (a lane's (query, key) pairs are fixed) and reach LDS once, at the end.  LDS float
     // atomics cost ~500 cycles per wave instruction on gfx950: they must stay out of the per-problem path.
@@ -512,6 +520,11 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma(const bf16* __restrict__ qk
                 }
             wsync();
             const float* w = part == 0 ? s_par : s_par + 2 * D;
+            float pw[KS][8], pb[KS][8];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pw[ks][j] = pb[ks][j] = 0.f;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const int row = 16 * b + i16;
@@ -526,7 +539,8 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma(const bf16* __restrict__ qk
                     for (int j = 0; j < 8; ++j) {
                         const float xh = part == 0 ? xq[b][ks][j] : xk[b][ks][j];
                         const float d0 = row < L ? raw[j] : 0.f;
-                        if (part == 0) { a_qw[ks][j] += d0 * xh; a_qb[ks][j] += d0; } else { a_kw[ks][j] += d0 * xh; a_kb[ks][j] += d0; }
+                        pw[ks][j] += d0 * xh;
+                        pb[ks][j] += d0;
                         const float gg = d0 * w[32 * ks + 8 * gq + j];
                         dn[ks][j] = gg;
                         m1 += gg; m2 += gg * xh;
@@ -551,6 +565,15 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma(const bf16* __restrict__ qk
                     }
                 }
             }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int vw = ((2 * part) * KS + ks) * 8 + j, vb = ((2 * part + 1) * KS + ks) * 8 + j;
+                    const float tw = row16_sum(pw[ks][j]), tb = row16_sum(pb[ks][j]);
+                    if (i16 == (vw & 15)) a_ln[vw >> 4] += tw;
+                    if (i16 == (vb & 15)) a_ln[vb >> 4] += tb;
+                }
             wsync();
         }
         if (PREFETCH) cur = nxt;
@@ -576,27 +599,19 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma(const bf16* __restrict__ qk
         }
     }
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float v[4] = {a_qw[ks][j], a_qb[ks][j], a_kw[ks][j], a_kb[ks][j]};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) v[q] += __shfl_xor(v[q], o, 64);
-            }
-            if (i16 == 0) {
-                const int e = 32 * ks + 8 * gq + j;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) atomicAdd(&s_ln[q * D + e], v[q]);
-            }
-        }
+    for (int k = 0; k < NACC; ++k) {     // plain stores into this wave's (now idle) tile area; the waves are summed below
+        const int v = 16 * k + i16, q = v / (8 * KS), ks = (v >> 3) % KS, j = v & 7;
+        relay[q * D + 32 * ks + 8 * gq + j] = a_ln[k];
+    }
     __syncthreads();
     const int nvals = 4 * D + 32 * heads + heads;
     for (int i = threadIdx.x; i < nvals; i += blockDim.x) {
         float val;
         float* dst;
-        if (i < 4 * D) { val = s_ln[i]; const int q = i / D, e = i % D; dst = (q == 0 ? gr.dqw : q == 1 ? gr.dqb : q == 2 ? gr.dkw : gr.dkb); if (dst) dst += e; }
+        if (i < 4 * D) {
+            val = 0.f;
+            for (int w = 0; w < wpb; ++w) val += reinterpret_cast<const float*>(smem_bwd + w * PER_WAVE)[i];
+            const int q = i / D, e = i % D; dst = (q == 0 ? gr.dqw : q == 1 ? gr.dqb : q == 2 ? gr.dkw : gr.dkb); if (dst) dst += e; }
         else if (i < 4 * D + 32 * heads) { const int t = i - 4 * D; val = s_demb[(t / heads) * 16 + (t % heads)]; dst = gr.demb ? gr.demb + t : nullptr; }
         else { const int t = i - 4 * D - 32 * heads; val = s_dhs[t]; dst = gr.dhscale ? gr.dhscale + t : nullptr; }
         if (ws) ws[(long)blockIdx.x * nvals + i] = val;
