@@ -37,7 +37,7 @@ __device__ __forceinline__ long col_off(int col, int seglen, long segstride) {
 template <typename T, bool XC, int LDT>
 __device__ __forceinline__ int lds_off(int r, int c) {
     if constexpr (sizeof(T) == 2 && !XC) return r * LDT + ((((c >> 3) ^ ((r >> 1) & 7)) << 3) | (c & 7));
-    else if constexpr (sizeof(T) == 2 && XC && (LDT % 128 == 0)) return r * LDT + ((((c >> 2) ^ ((r & 7) << 2)) << 2) | (c & 3));
+    else if constexpr (sizeof(T) == 2 && XC && (LDT % 128 == 0)) return r * LDT + ((((c >> 2) ^ (((r & 3) | ((r >> 1) & 4)) << 2)) << 2) | (c & 3));
     else return r * LDT + c;
 }
 

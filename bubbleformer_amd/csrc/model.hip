@@ -739,19 +739,26 @@ extern "C" int bf_embed_bwd(const bf_dims* dims, const bf_embed_params* p, const
     if (film)
         TRY(bf_film_net_bwd(sv.dgb, sv.chat, p->film_ln_w, p->film_ln_b, p->film_w, g->film_w, g->film_b, g->film_ln_w, g->film_ln_b, d.B,
                             d.nfluid, 2 * d.E, st));
+    // Weight gradients (memset, split-K GEMM into the prepared-layout scratch, un-prepare into the gradient) run on the side
+    // stream while this stream continues with the data gradient and the InstanceNorm backward of the same stage.  The side work
+    // of stage i is joined before stage i-1 forks: the two ping-pong gradient buffers and sc.wg are then never recycled under it.
+    Fork fk(st);
+    hipStream_t ss;
     for (int i = n - 1; i >= 1; --i) {
         const int cp = sv.C[i - 1], K4 = 4 * cp;
         const long rpf = (long)sv.gh[i] * sv.gw[i];
-        ZERO(sc.wg, (size_t)sv.C[i] * K4 * 4);
+        TRY(fk.join());
+        TRY(fk.begin(&ss));
+        ZERO_ON(ss, sc.wg, (size_t)sv.C[i] * K4 * 4);
         {   // dWprep[co][k] = sum_p dy[p][co] * act(patch)[p][k]
             bf_operand A = op_plain(dy, sv.C[i], BF_LAY_XC);
             bf_operand Bo = op_plain(sv.y[i - 1], cp, BF_LAY_XC);
             op_gather(Bo, sv.gw[i], sv.gh[i], cp);
             op_affine(Bo, BF_PRO_AFFINE_GELU, sv.sc[i - 1], sv.sh[i - 1], rpf, cp);
             bf_epilogue e = epi_atomic(sc.wg, K4);
-            TRY(bf_gemm(d.dtype, sv.C[i], K4, (int)sv.P[i], &A, &Bo, &e, splitk_for(sv.C[i], K4, sv.P[i]), st));
+            TRY(bf_gemm(d.dtype, sv.C[i], K4, (int)sv.P[i], &A, &Bo, &e, splitk_for(sv.C[i], K4, sv.P[i]), ss));
         }
-        TRY(bf_wgrad_unprep(1, sc.wg, g->conv_w[i], sv.C[i], K4, K4, 0, st));
+        TRY(bf_wgrad_unprep(1, sc.wg, g->conv_w[i], sv.C[i], K4, K4, 0, ss));
         void* dact = buf(i - 1);
         {   // d(act patch)[p][k] = sum_co dy[p][co] * Wprep[co][k], scattered back to the input grid
             bf_operand A = op_plain(dy, sv.C[i], BF_LAY_KC);
@@ -765,12 +772,14 @@ extern "C" int bf_embed_bwd(const bf_dims* dims, const bf_embed_params* p, const
         dy = dact;
     }
     {   // stage 0
-        ZERO(sc.wg, (size_t)sv.C[0] * sv.Kp * 4);
+        TRY(fk.join());
+        if (dx_in) TRY(fk.begin(&ss)); else ss = st;      // nothing left to overlap with when the input needs no gradient
+        ZERO_ON(ss, sc.wg, (size_t)sv.C[0] * sv.Kp * 4);
         bf_operand A = op_plain(dy, sv.C[0], BF_LAY_XC);
         bf_operand Bo = op_plain(sv.patches, sv.Kp, BF_LAY_XC);
         bf_epilogue e = epi_atomic(sc.wg, sv.Kp);
-        TRY(bf_gemm(d.dtype, sv.C[0], sv.Kp, (int)sv.P[0], &A, &Bo, &e, splitk_for(sv.C[0], sv.Kp, sv.P[0]), st));
-        TRY(bf_wgrad_unprep(0, sc.wg, g->conv_w[0], sv.C[0], 4 * d.cin, sv.Kp, 0, st));
+        TRY(bf_gemm(d.dtype, sv.C[0], sv.Kp, (int)sv.P[0], &A, &Bo, &e, splitk_for(sv.C[0], sv.Kp, sv.P[0]), ss));
+        TRY(bf_wgrad_unprep(0, sc.wg, g->conv_w[0], sv.C[0], 4 * d.cin, sv.Kp, 0, ss));
         if (dx_in) {
             void* dpatch = sc.t1;
             bf_operand A2 = op_plain(dy, sv.C[0], BF_LAY_KC);
@@ -780,7 +789,7 @@ extern "C" int bf_embed_bwd(const bf_dims* dims, const bf_embed_params* p, const
             TRY(bf_col2im_nchw(d.dtype, dpatch, dx_in, (int)d.F, d.cin, H, W, sv.Kp, st));
         }
     }
-    return 0;
+    return fk.join();
 }
 
 // ================================================================================================= debed (+ relative-L2 loss)
@@ -833,6 +842,8 @@ extern "C" int bf_debed_bwd(const bf_dims* dims, const bf_debed_params* p, const
     const int n = d.nst;
     auto buf = [&](int stage) { return (stage & 1) ? sc.t3 : sc.t4; };   // gradient w.r.t. the INPUT of `stage`
     void* dy = nullptr;   // gradient w.r.t. the raw output of stage i-1 == (after IN/GELU backward) input of stage i
+    Fork fk(st);          // weight gradients on the side stream, joined before the next stage forks (see bf_embed_bwd)
+    hipStream_t ss;
     for (int i = n - 1; i >= 0; --i) {
         const bool last = i == n - 1;
         const int cin = sv.Cin[i], co = sv.Co[i];
@@ -842,15 +853,16 @@ extern "C" int bf_debed_bwd(const bf_dims* dims, const bf_debed_params* p, const
         if (last) {
             void* dpm = sc.t1;
             TRY(bf_nchw2pm(d.dtype, dpred, pred, target, sv.coef, loss_scale, dpm, (int)d.F, co, sv.gh[i], sv.gw[i], sv.Np, st));
-            ZERO(sc.wg, (size_t)sv.Np * cin * 4);
+            TRY(fk.begin(&ss));
+            ZERO_ON(ss, sc.wg, (size_t)sv.Np * cin * 4);
             {   // wg[n][ci] = sum_p dpm[p][n] * act[p][ci]
                 bf_operand A = op_plain(dpm, sv.Np, BF_LAY_XC);
                 bf_operand Bo = op_plain(ain, cin, BF_LAY_XC);
                 if (i > 0) op_affine(Bo, BF_PRO_AFFINE_GELU, sv.sc[i - 1], sv.sh[i - 1], rpf, cin);
                 bf_epilogue e = epi_atomic(sc.wg, cin);
-                TRY(bf_gemm(d.dtype, sv.Np, cin, (int)sv.Pin[i], &A, &Bo, &e, splitk_for(sv.Np, cin, sv.Pin[i]), st));
+                TRY(bf_gemm(d.dtype, sv.Np, cin, (int)sv.Pin[i], &A, &Bo, &e, splitk_for(sv.Np, cin, sv.Pin[i]), ss));
             }
-            TRY(bf_wgrad_unprep(0, sc.wg, g->conv_w[i], cin, 4 * co, sv.Np, 1, st));
+            TRY(bf_wgrad_unprep(0, sc.wg, g->conv_w[i], cin, 4 * co, sv.Np, 1, ss));
             {   // dact[p][ci] = sum_n dpm[p][n] * wt[ci][n]
                 bf_operand A = op_plain(dpm, sv.Np, BF_LAY_KC);
                 bf_operand Bo = op_plain(sv.wc[i], sv.Np, BF_LAY_KC);
@@ -859,16 +871,18 @@ extern "C" int bf_debed_bwd(const bf_dims* dims, const bf_debed_params* p, const
             }
         } else {
             const int N4 = 4 * co;
-            ZERO(sc.wg, (size_t)N4 * cin * 4);
+            TRY(fk.join());
+            TRY(fk.begin(&ss));
+            ZERO_ON(ss, sc.wg, (size_t)N4 * cin * 4);
             {   // wg[(q,co)][ci] = sum_p dy_gathered[p][(q,co)] * act[p][ci]
                 bf_operand A = op_plain(dy, co, BF_LAY_XC);
                 op_gather(A, sv.gw[i], sv.gh[i], co);
                 bf_operand Bo = op_plain(ain, cin, BF_LAY_XC);
                 if (i > 0) op_affine(Bo, BF_PRO_AFFINE_GELU, sv.sc[i - 1], sv.sh[i - 1], rpf, cin);
                 bf_epilogue e = epi_atomic(sc.wg, cin);
-                TRY(bf_gemm(d.dtype, N4, cin, (int)sv.Pin[i], &A, &Bo, &e, splitk_for(N4, cin, sv.Pin[i]), st));
+                TRY(bf_gemm(d.dtype, N4, cin, (int)sv.Pin[i], &A, &Bo, &e, splitk_for(N4, cin, sv.Pin[i]), ss));
             }
-            TRY(bf_wgrad_unprep(2, sc.wg, g->conv_w[i], N4, cin, cin, 0, st));
+            TRY(bf_wgrad_unprep(2, sc.wg, g->conv_w[i], N4, cin, cin, 0, ss));
             {
                 bf_operand A = op_plain(dy, co, BF_LAY_KC);
                 op_gather(A, sv.gw[i], sv.gh[i], co);
@@ -883,5 +897,5 @@ extern "C" int bf_debed_bwd(const bf_dims* dims, const bf_debed_params* p, const
             dy = dact;
         }
     }
-    return 0;
+    return fk.join();
 }
