@@ -31,8 +31,10 @@ __device__ __forceinline__ long col_off(int col, int seglen, long segstride) {
 // Element offset of (row r, column c) inside an LDS operand tile.
 //  bf16 KC tile [outer][64]: 128-byte rows; the 16-byte chunk index is XORed with (r >> 1) & 7 so the 16 lanes that one
 //    ds_read_b128 group serves (rows i, i+.., chunk g) land on 16 distinct 16-byte slots of the 256-byte bank row.
-//  bf16 XC tile [k][128]: 256-byte rows; the 8-byte unit index is XORed with 4 * (r & 7) so the 32 lanes of a half-wave of
-//    the transposing read (rows 8g + q, units 4t + p) cover all 64 banks exactly once.  64-wide XC tiles stay linear.
+//  bf16 XC tile [k][128]: 256-byte rows; the 8-byte unit index is XORed with 4 * ((r & 3) | ((r >> 3) & 1) << 2): a half-wave
+//    of the transposing read takes rows {q, 8 + q} (lo) or {4 + q, 12 + q} (hi), q = 0..3, units 4t + p -- eight rows whose
+//    keys are all different, so its 32 lanes cover the 64 banks exactly once (SQ_LDS_BANK_CONFLICT = 0 in the dW GEMMs; keying
+//    on r & 7 alone left rows q and 8 + q on the same banks).  64-wide XC tiles stay linear.
 //  f32 tiles: padded leading dimension, no swizzle.
 template <typename T, bool XC, int LDT>
 __device__ __forceinline__ int lds_off(int r, int c) {
