@@ -90,12 +90,13 @@ int splitk_for(int M, int N, long K) {
 // phases in lock step across the chip; issued on two HIP streams they interleave and fill each other's bubbles.  The library
 // owns one extra stream per device; a stage forks work onto it with an event and joins it before it returns, so the caller
 // still sees plain stream-ordered semantics on ITS stream (and the fork/join pattern is hipGraph-capturable).
-// BF_SIDE_STREAM=0, or the launch profiler being on (per-kernel times must not overlap), runs everything on the caller's stream.
+// BF_SIDE_STREAM=0 runs everything on the caller's stream.  The launch profiler times each kernel with events on the stream it was
+// launched on, so its per-kernel durations are the contended ones of the real schedule (they agree with a rocprofv3 trace).
 struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool failed = false; };
 SideStream* side_stream() {
     static SideStream tab[64];
     static const bool enabled = []() { const char* v = getenv("BF_SIDE_STREAM"); return !(v && atoi(v) == 0); }();
-    if (!enabled || bf_prof_is_on()) return nullptr;
+    if (!enabled) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     SideStream& s = tab[dev];

@@ -38,6 +38,10 @@ def normalise(name: str) -> str:
         ax, bx, ap, bp, tm = m.groups()
         return "gemm_wide_kernel<bf16,%s,%s,pro%s,tm%s>" % ("xc" if ax == "true" else "kc", "xc" if bx == "true" else "kc",
                                                            "A" if ap == "true" else "B" if bp == "true" else "0", tm)
+    for key in ("in_bwd_slice_kernel", "in_stats_slice_kernel", "in_stats_merge_kernel", "in_slice_sum_kernel", "frame_table_kernel", "frame_wcolsum_kernel",
+                "cast4_kernel", "lploss_finalize_kernel", "fill_kernel"):
+        if key in name:
+            return key
     for key in ("attn_bwd_mfma", "attn_fwd_mfma", "attn_ws_reduce", "in_bwd_kernel", "in_stats_kernel", "in_param_reduce_kernel", "affine_apply_kernel",
                 "colsum_kernel", "adamw_kernel", "wprep_kernel", "outproj_finalize_kernel", "outproj_prep_kernel", "pm2nchw_kernel", "nchw2pm_kernel",
                 "im2col_kernel", "film_net_bwd_kernel", "film_net_fwd_kernel", "wgrad_unprep_kernel", "attn_fwd_kernel", "attn_bwd_kernel"):
