@@ -218,36 +218,105 @@ __device__ __forceinline__ void stage_tile(const bf16* __restrict__ base, long r
     }
 }
 
+// q / k / v rows of one problem in the MFMA operand layout: lane (i = l & 15, g = l >> 4) holds channels 32*s + 8*g .. +7 of row i
+template <int NB, int KS> struct FwdRows { bf16x8 q[NB][KS], k[NB][KS], v[NB][KS]; };
+template <int NB, int KS>
+__device__ __forceinline__ void load_fwd_rows(FwdRows<NB, KS>& r, const bf16* __restrict__ qkv, const Geo& g, int heads, long pr, int lane) {
+    constexpr int D = 32 * KS;
+    const int E = heads * D;
+    const long s = pr / heads;
+    const int head = (int)(pr % heads);
+    const long tok0 = (s / g.inner) * g.outer_stride + (s % g.inner) * g.inner_stride;
+    const int gq = lane >> 4, i16 = lane & 15;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int i = b * 16 + i16, ic = i < g.L ? i : g.L - 1;      // rows >= L: clamped duplicates, masked / zeroed later
+        const bf16* rp = qkv + (tok0 + ic * g.tok_stride) * 3L * E + head * 3 * D + 8 * gq;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            r.q[b][ks] = *reinterpret_cast<const bf16x8*>(rp + 32 * ks);
+            r.k[b][ks] = *reinterpret_cast<const bf16x8*>(rp + D + 32 * ks);
+            r.v[b][ks] = *reinterpret_cast<const bf16x8*>(rp + 2 * D + 32 * ks);
+        }
+    }
+}
+
+// Forward: persistent waves, one (sequence, head) problem at a time.  Every global read of a problem is issued at its top (and
+// the next problem's q/k/v rows before that), the LayerNorm affine / T5 table / head scales are staged once per workgroup in
+// LDS: a problem is then one round trip instead of six dependent ones.
 template <int NB, int KS>
 __global__ void __launch_bounds__(256) attn_fwd_mfma(const bf16* __restrict__ qkv, bf16* __restrict__ out, Geo g, int heads, Par p, float out_scale,
                                                      int accumulate) {
     constexpr int D = 32 * KS, LD = D + 16, NT16 = D / 16;
+    constexpr bool PREFETCH = NB * KS <= 4;
     extern __shared__ __attribute__((aligned(16))) bf16 smem_fwd[];
+    __shared__ __attribute__((aligned(16))) float s_par[4 * 32 * KS];   // qw | qb | kw | kb
+    __shared__ float s_emb[32 * 16];
+    __shared__ float s_hsc[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     bf16* vt = smem_fwd + wave * (16 * NB * LD);
+    for (int i = threadIdx.x; i < 32 * 16; i += blockDim.x) {
+        const int t = i >> 4, h = i & 15;
+        s_emb[i] = (p.emb && h < heads) ? p.emb[t * heads + h] : 0.f;
+    }
+    if (threadIdx.x < 16) s_hsc[threadIdx.x] = (p.hscale && (int)threadIdx.x < heads) ? p.hscale[threadIdx.x] : 1.f;
+    for (int i = threadIdx.x; i < 4 * D; i += blockDim.x) {
+        const int q = i / D, e = i % D;
+        s_par[i] = (q == 0 ? p.qw : q == 1 ? p.qb : q == 2 ? p.kw : p.kb)[e];
+    }
+    __syncthreads();
     const int E = heads * D, L = g.L;
     const float scale = rsqrtf((float)D);
     const long nprob = g.nseq * heads;
     const int gq = lane >> 4, i16 = lane & 15;
-    for (long pr = (long)blockIdx.x * wpb + wave; pr < nprob; pr += (long)gridDim.x * wpb) {
+    const long pstep = (long)gridDim.x * wpb;
+    long pr = (long)blockIdx.x * wpb + wave;
+    FwdRows<NB, KS> cur, nxt;
+    if (pr < nprob) load_fwd_rows<NB, KS>(cur, qkv, g, heads, pr, lane);
+    for (; pr < nprob; pr += pstep) {
         const long s = pr / heads;
         const int head = (int)(pr % heads);
         const long tok0 = (s / g.inner) * g.outer_stride + (s % g.inner) * g.inner_stride;
-        const bf16* hb = qkv + head * 3 * D;
-        stage_tile<NB>(hb, 3L * E, 2 * D, tok0, g.tok_stride, L, D, vt, LD, lane);
+        if (PREFETCH && pr + pstep < nprob) load_fwd_rows<NB, KS>(nxt, qkv, g, heads, pr + pstep, lane);
+        bf16x4 old[NB][NT16];
+        if (accumulate) {
+#pragma unroll
+            for (int ib = 0; ib < NB; ++ib) {
+                const int i = 16 * ib + i16, ic = i < L ? i : L - 1;
+#pragma unroll
+                for (int t = 0; t < NT16; ++t)
+                    old[ib][t] = *reinterpret_cast<const bf16x4*>(out + (tok0 + ic * g.tok_stride) * (long)E + head * D + 16 * t + 4 * gq);
+            }
+        }
         bf16x8 qf[NB][KS], kf[NB][KS];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             float x[KS][8];
-            load_rows_f32<KS>(hb, 3L * E, 0, tok0, g.tok_stride, L, b, lane, x);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[ks][j] = (float)cur.q[b][ks][j];
             ln_quad<KS>(x, D);
-            affine_frag<KS>(x, p.qw, p.qb, scale, lane, qf[b]);
-            load_rows_f32<KS>(hb, 3L * E, D, tok0, g.tok_stride, L, b, lane, x);
+            affine_frag<KS>(x, s_par, s_par + D, scale, lane, qf[b]);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[ks][j] = (float)cur.k[b][ks][j];
             ln_quad<KS>(x, D);
-            affine_frag<KS>(x, p.kw, p.kb, 1.f, lane, kf[b]);
+            affine_frag<KS>(x, s_par + 2 * D, s_par + 3 * D, 1.f, lane, kf[b]);
+            const int row = b * 16 + i16;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {      // V tile for the transposing read; rows >= L are zeros
+                bf16x8 zv = cur.v[b][ks];
+                if (row >= L) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) zv[j] = (bf16)0.f;
+                }
+                *reinterpret_cast<bf16x8*>(vt + row * LD + 32 * ks + 8 * gq) = zv;
+            }
         }
         float P[NB][NB][4], A[NB][NB][4];
-        scores_softmax<NB, KS>(kf, qf, p.emb, heads, p.hscale, head, L, lane, P, A);
+        scores_softmax<NB, KS>(kf, qf, p.emb ? s_emb : nullptr, 16, p.hscale ? s_hsc : nullptr, head, L, lane, P, A);
         wsync();   // V tile visible to the wave
 #pragma unroll
         for (int ib = 0; ib < NB; ++ib) {
@@ -261,9 +330,8 @@ __global__ void __launch_bounds__(256) attn_fwd_mfma(const bf16* __restrict__ qk
                     bf16* dst = out + (tok0 + i * g.tok_stride) * (long)E + head * D + 16 * t + 4 * gq;
                     float v[4] = {o[0] * out_scale, o[1] * out_scale, o[2] * out_scale, o[3] * out_scale};
                     if (accumulate) {
-                        const bf16x4 old = *reinterpret_cast<const bf16x4*>(dst);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += (float)old[r];
+                        for (int r = 0; r < 4; ++r) v[r] += (float)old[ib][t][r];
                     }
                     const bf16x4 w4 = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
                     *reinterpret_cast<bf16x4*>(dst) = w4;
@@ -271,6 +339,8 @@ __global__ void __launch_bounds__(256) attn_fwd_mfma(const bf16* __restrict__ qk
             }
         }
         wsync();   // before the next problem overwrites the V tile
+        if (PREFETCH) cur = nxt;
+        else if (pr + pstep < nprob) load_fwd_rows<NB, KS>(cur, qkv, g, heads, pr + pstep, lane);
     }
 }
 
@@ -655,7 +725,9 @@ int go_fwd(const bf16* qkv, bf16* out, Geo g, int heads, Par p, float out_scale,
     const int wpb = 4;
     const size_t shm = (size_t)wpb * 16 * NB * (D + 16) * sizeof(bf16);
     const long nprob = g.nseq * heads;
-    const int grid = (int)std::min<long>((nprob + wpb - 1) / wpb, 256L * 8);
+    // measured (tools/attn_bench.py): 2 workgroups per CU of look-ahead waves beat 8 of plain ones (18.7 vs 21.0 us at the bench shape)
+    static const int bpc = []() { const char* v = getenv("BF_ATTN_FWD_BPC"); return v ? atoi(v) : 2; }();
+    const int grid = (int)std::min<long>((nprob + wpb - 1) / wpb, 256L * bpc);
     hipLaunchKernelGGL((attn_fwd_mfma<NB, KS>), dim3(grid), dim3(wpb * 64), shm, st, qkv, out, g, heads, p, out_scale, accumulate);
     BF_CHECK_LAUNCH();
     return 0;
