@@ -177,7 +177,10 @@ __global__ void __launch_bounds__(NT) gemm_kernel(int M, int N, int K, OpDev A, 
     constexpr int B_ELEMS = BXC ? BK * LDB : BN * LDB;
     constexpr bool ANYPRO = APRO || BPRO;
     constexpr size_t STG_BYTES = (size_t)64 * (BN + 4) * sizeof(float);              // epilogue staging (64 rows x 132 floats)
-    constexpr size_t TILE_BYTES = (size_t)(A_ELEMS + B_ELEMS) * sizeof(T);
+    // bf16, no prologue table, 8 waves: two LDS tile buffers -- tile k+1 is committed while tile k feeds the MFMAs (other waves of
+    // the workgroup), one barrier per K-step instead of two.  2 x 32 KB per workgroup still lets two workgroups share a CU.
+    constexpr bool DB = sizeof(T) == 2 && !ANYPRO && NT == 512 && NSTAGE == 1;      // with the 16 KB prologue table two buffers would exceed the 64 KB static LDS limit
+    constexpr size_t TILE_BYTES = (size_t)(A_ELEMS + B_ELEMS) * sizeof(T) * (DB ? 2 : 1);
     __shared__ __attribute__((aligned(16))) T lds[(TILE_BYTES > STG_BYTES ? TILE_BYTES : STG_BYTES) / sizeof(T)];
     __shared__ __attribute__((aligned(16))) float ltab[ANYPRO ? 2 * TAB : 4];
     T* lA = lds;
@@ -228,6 +231,52 @@ __global__ void __launch_bounds__(NT) gemm_kernel(int M, int N, int K, OpDev A, 
     const bool do_colsum = AXC && E.colsum != nullptr && n0 == 0;
 
     int k0 = kbeg;
+    if constexpr (DB) {
+        constexpr int BUF = A_ELEMS + B_ELEMS;
+        auto colsum_acc = [&]() {
+            if constexpr (AXC) {
+                if (do_colsum) {
+#pragma unroll
+                    for (int i = 0; i < StA::NCH; ++i)
+#pragma unroll
+                        for (int j = 0; j < Chunk<T>::N; ++j) csum[j] += sa[0].data[i].get(j);
+                }
+            }
+        };
+        if (k0 < kend) {      // tile 0 -> buffer 0, tile 1 in flight
+            colsum_acc();
+            fa_.template commit<APRO>(sa[0], A, ta, lA, m0);
+            fb_.template commit<BPRO>(sb[0], B, tb, lB, n0);
+            if (k0 + BK < kend) { fa_.issue(sa[0], A, k0 + BK, kend); fb_.issue(sb[0], B, k0 + BK, kend); }
+        }
+        __syncthreads();
+        int cur = 0;
+        for (; k0 < kend; k0 += BK) {
+            const bf16* cA = (const bf16*)lA + cur * BUF;
+            const bf16* cB = (const bf16*)lB + cur * BUF;
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += Cfg::KSTEP) {
+                bf16x8 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = frag_bf16<AXC, LDA>(cA, wm * (16 * TM) + i * 16, kk, lane);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = frag_bf16<BXC, LDB>(cB, wn * (16 * TN) + j * 16, kk, lane);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            }
+            if (k0 + BK < kend) {      // next tile into the other buffer (nobody reads it until the barrier below)
+                colsum_acc();
+                fa_.template commit<APRO>(sa[0], A, ta, lA + (cur ^ 1) * BUF, m0);
+                fb_.template commit<BPRO>(sb[0], B, tb, lB + (cur ^ 1) * BUF, n0);
+                if (k0 + 2 * BK < kend) { fa_.issue(sa[0], A, k0 + 2 * BK, kend); fb_.issue(sb[0], B, k0 + 2 * BK, kend); }
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else
     while (k0 < kend) {
 #pragma unroll
         for (int s = 0; s < NSTAGE; ++s) {
