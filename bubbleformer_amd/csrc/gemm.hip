@@ -139,11 +139,10 @@ struct StagerFixed {
             if (PRO && op.pro != BF_PRO_NONE && ((s.valid >> i) & 1u)) {
                 float sc[CH], sh[CH];
                 if (op.pro != BF_PRO_GELU) {
-                    int f, ch;
-                    if constexpr (!XC) { f = fidx[i]; ch = s.k0 + cc; }
-                    else { f = (int)((unsigned)(s.k0 + r0 + RSTEP * i) / (unsigned)op.rpf); ch = outer0 + cc; }
-                    if (ch >= op.nch) ch %= op.nch;
-                    const long o = tab.ok ? (long)(f - tab.f_lo) * tab.cw + (ch - tab.c_lo) : (long)f * op.nch + ch;
+                    int f, ch, slot;          // slot: column inside the staged table (KC: the channel itself; XC: the tile column)
+                    if constexpr (!XC) { f = fidx[i]; ch = s.k0 + cc; if (ch >= op.nch) ch %= op.nch; slot = ch - tab.c_lo; }
+                    else { f = (int)((unsigned)(s.k0 + r0 + RSTEP * i) / (unsigned)op.rpf); ch = outer0 + cc; slot = ch - tab.c_lo; if (ch >= op.nch) ch %= op.nch; }
+                    const long o = tab.ok ? (long)(f - tab.f_lo) * tab.cw + slot : (long)f * op.nch + ch;
 #pragma unroll
                     for (int j = 0; j < CH; j += 4) {     // 16-byte aligned: channels come in whole chunks
                         const float4 a4 = *reinterpret_cast<const float4*>(tab.sc + o + j);

@@ -57,10 +57,11 @@ __device__ __forceinline__ ProTab stage_table(const OpDev& op, long r_lo, long r
     t.ok = (op.pro == BF_PRO_AFFINE || op.pro == BF_PRO_AFFINE_GELU) && (long)nf * cw <= TAB;
     if (t.ok) {
         for (int i = tid; i < nf * cw; i += nthreads) {
-            const int fi = i / cw, c = c_lo + i % cw;
-            const bool v = c < op.nch;
-            lds_sc[i] = v ? op.sc[(long)(t.f_lo + fi) * op.nch + c] : 0.f;
-            lds_sh[i] = (v && op.sh) ? op.sh[(long)(t.f_lo + fi) * op.nch + c] : 0.f;     // sh == NULL: pure scale
+            // table slot = column of the tile; its channel wraps with nch (k2s2 patch rows hold 4 pixels x nch channels, so an
+            // outer-contiguous tile at column >= nch still needs channel (column mod nch))
+            const int fi = i / cw, c = (c_lo + i % cw) % op.nch;
+            lds_sc[i] = op.sc[(long)(t.f_lo + fi) * op.nch + c];
+            lds_sh[i] = op.sh ? op.sh[(long)(t.f_lo + fi) * op.nch + c] : 0.f;     // sh == NULL: pure scale
         }
         t.sc = lds_sc; t.sh = lds_sh;
     } else {

@@ -1,0 +1,160 @@
+"""GPU: the HIP path at the shapes BASELINE.json names (configs[0], [1], [3], [4]) -- full `film_avit_small`
+(E=384, 6 heads, 12 blocks, P=16, 9 fluid parameters) with O(1)-perturbed weights, against the oracle executed on this
+box's host cores on the same seeded inputs, plus size-independent properties at the full bench size.
+
+  configs[0]  8x96x96 clip, bs 2                      -> fp32 (1e-4) and bf16 parity, forward / loss / dx / every gradient
+  configs[1]  16x192x192 clip (bench shape)           -> one full-resolution sample against the oracle (bf16 tolerances);
+                                                         bs 8: bit-identical reruns, per-sample independence of the batch
+  configs[3]  32x384x192 long-aspect clip (24x12 tokens, T = 32: the two-block attention paths at full width), bs 1, fp32
+  configs[4]  bs 1 inference: the forward captured in a HIP graph replays bit-identically; 3-step rollout on device
+fp32 tolerance: 1e-4 everywhere, as in tests/test_gpu_parity.py.  bf16 tolerances at FULL depth (12 blocks, E = 384): forward
+<= 8e-2, dx <= 2e-1, all parameter gradients together <= 1.5e-1, each family <= 0.9.  Yardstick (measured in the build
+container, configs[0] shape, same weights): the oracle itself under stock torch.autocast(bfloat16) is off by 5.2e-2 (forward),
+1.3e-1 (dx), 9.0e-2 (all gradients), 1.2e-1 median / 6.4e-1 worst family against its own fp32 run -- bf16 rounding compounds
+over 12 blocks with O(1) layer scales; the 3-block golden models of test_gpu_parity.py sit at 1.3e-2..2.2e-2.
+"""
+import pytest
+import torch
+
+from tests.helpers import rel_l2, structurally_zero
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(input_fields=4, output_fields=4, patch_size=16, embed_dim=384, num_heads=6, processor_blocks=12, num_fluid_params=9)
+
+
+def _inputs(B, T, H, W, seed):
+    from oracle import weights as Wt
+    x = Wt.synthetic_clip(B, T, 4, H, W, 100 + seed)
+    y = Wt.synthetic_clip(B, T, 4, H, W, 200 + seed)
+    c = Wt.synthetic_fluid_params(B, 9, 300 + seed)
+    return x, y, c
+
+
+def _weights(seed):
+    from oracle import weights as Wt
+    return Wt.generate(Wt.param_shapes(**SMALL), seed=seed)
+
+
+def _oracle(B, T, H, W, seed, grads=True):
+    from oracle import filmavit_ref as R
+    torch.set_num_threads(16)
+    sd = {k: v.requires_grad_(grads) for k, v in _weights(seed).items()}
+    x, y, c = _inputs(B, T, H, W, seed)
+    x.requires_grad_(grads)
+    with torch.set_grad_enabled(grads):
+        pred = R.filmavit_forward(sd, x, c, patch_size=16, num_heads=6)
+        loss = R.lp_loss(pred, y)
+    if not grads:
+        return pred, float(loss), None, None
+    loss.backward()
+    return pred.detach(), float(loss), x.grad.detach(), {k: v.grad.detach() for k, v in sd.items()}
+
+
+def _model(seed, dtype, T):
+    from bubbleformer_amd.models import get_model
+    m = get_model("filmavit", time_window=T, drop_path=0.0, compute_dtype=dtype, **SMALL)
+    m.load_state_dict(_weights(seed))
+    return m.cuda()
+
+
+def _product(B, T, H, W, seed, dtype):
+    m = _model(seed, dtype, T)
+    x, y, c = (t.cuda() for t in _inputs(B, T, H, W, seed))
+    x.requires_grad_(True)
+    loss, pred = m.forward_loss(x, c, y)
+    loss.backward()
+    return pred.detach().cpu(), float(loss), x.grad.detach().cpu(), {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+
+
+def _compare(prod, orac, dtype):
+    pred, loss, dx, grads = prod
+    pred_o, loss_o, dx_o, grads_o = orac
+    f32 = dtype == torch.float32
+    ft = 1e-4 if f32 else 8e-2
+    gt = 1e-4 if f32 else 1.5e-1
+    assert rel_l2(pred, pred_o) < ft
+    assert abs(loss - loss_o) / abs(loss_o) < ft
+    assert rel_l2(dx, dx_o) < (1e-4 if f32 else 2e-1)
+    num = den = 0.0
+    gscale = max(float(g.norm()) for g in grads_o.values())
+    for k, g in grads.items():
+        ref = grads_o[k]
+        num += float((g.double() - ref.double()).pow(2).sum())
+        den += float(ref.double().pow(2).sum())
+        if structurally_zero(k):
+            assert float(g.norm()) <= (1e-5 if f32 else 1e-2) * gscale, k
+        else:
+            assert rel_l2(g, ref) < (gt if f32 else 0.9), k
+    assert (num / den) ** 0.5 < gt
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_config0_8x96x96_bs2(dtype):
+    B, T, H, W, seed = 2, 8, 96, 96, 11
+    _compare(_product(B, T, H, W, seed, dtype), _oracle(B, T, H, W, seed), dtype)
+
+
+def test_config1_full_resolution_sample_bf16():
+    B, T, H, W, seed = 1, 16, 192, 192, 12
+    _compare(_product(B, T, H, W, seed, torch.bfloat16), _oracle(B, T, H, W, seed), torch.bfloat16)
+
+
+def test_config3_long_aspect_32x384x192_fp32():
+    """24 x 12 tokens, T = 32: temporal and axial-H attention take the two-block (L > 16) paths at full model width."""
+    B, T, H, W, seed = 1, 32, 384, 192, 13
+    _compare(_product(B, T, H, W, seed, torch.float32), _oracle(B, T, H, W, seed), torch.float32)
+
+
+def test_config1_bench_size_properties():
+    """bs 8 x 16x192x192, bf16, eval: reruns are bit-identical; a sample's prediction does not depend on its batch mates
+    (InstanceNorm is per frame, attention per sequence) beyond bf16 GEMM tiling noise."""
+    B, T, H, W, seed = 8, 16, 192, 192, 14
+    m = _model(seed, torch.bfloat16, T).eval()
+    x, y, c = (t.cuda() for t in _inputs(B, T, H, W, seed))
+    with torch.no_grad():
+        p1 = m(x, c)
+        p2 = m(x, c)
+        assert torch.equal(p1, p2)
+        assert torch.isfinite(p1).all()
+        for i in (0, 5):
+            pi = m(x[i:i + 1], c[i:i + 1])
+            assert rel_l2(pi[0], p1[i]) < 1e-2
+        loss, _ = m.forward_loss(x, c, y)
+        num = ((p1 - y) ** 2).sum(dim=(-1, -2)).sqrt()
+        den = (y ** 2).sum(dim=(-1, -2)).sqrt()
+        assert abs(float(loss) - float((num / den).mean(0).mean(0).sum())) < 2e-3 * float(loss)      # fused loss == LpLoss of the prediction
+
+
+def test_config4_forward_in_hip_graph_and_rollout():
+    """bs 1 inference (scripts/inference.py:239-252): the eval forward is capturable in a HIP graph and replays
+    bit-identically; an autoregressive rollout stays on the device and matches the eager loop."""
+    B, T, H, W, seed = 1, 16, 192, 192, 15
+    m = _model(seed, torch.bfloat16, T).eval()
+    x, _, c = (t.cuda() for t in _inputs(B, T, H, W, seed))
+    with torch.no_grad():
+        eager = m(x, c)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                m(x, c)
+        torch.cuda.current_stream().wait_stream(s)
+        static_x = x.clone()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            static_out = m(static_x, c)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(static_out, eager)
+        # rollout: feed the prediction back (graph replay vs eager)
+        cur = x.clone()
+        for _ in range(3):
+            static_x.copy_(cur)
+            g.replay()
+            cur = static_out.clone()
+        ref = x.clone()
+        for _ in range(3):
+            ref = m(ref, c)
+        assert torch.isfinite(cur).all()
+        assert torch.equal(cur, ref)

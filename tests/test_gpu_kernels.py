@@ -102,6 +102,36 @@ def test_gemm_patch_gather_and_scatter(K, dtype):
     assert _rel(up.float().permute(0, 3, 1, 2), ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Ci", [16, 96])      # 96: 4*Ci = 384 columns = three 128-column tiles whose channels wrap (column mod Ci)
+def test_gemm_conv_weight_gradient_gathered_prologue(K, dtype, Ci):
+    """dW of a k2s2 conv fed by GELU(InstanceNorm-affine(image)): token-reduction GEMM whose B operand is an outer-contiguous
+    2x2 patch gather with an affine+GELU prologue.  The per-(frame, channel) table is indexed by patch COLUMN (ky, kx, ci), so
+    tiles past the first need channel = column mod Ci (regression: embed.in_proj.{3,6}.weight gradients at E = 384)."""
+    from bubbleformer_amd import _lib as L
+    Fr, H, W, Co = 3, 16, 24, 40
+    g = torch.Generator(device="cuda").manual_seed(6)
+    img = torch.randn(Fr, H, W, Ci, device="cuda", generator=g).to(dtype)
+    gh, gw = H // 2, W // 2
+    P = Fr * gh * gw
+    dy = torch.randn(P, Co, device="cuda", generator=g).to(dtype)
+    sc = 1 + 0.3 * torch.randn(Fr, Ci, device="cuda", generator=g)
+    sh = 0.3 * torch.randn(Fr, Ci, device="cuda", generator=g)
+    out = torch.zeros(Co, 4 * Ci, device="cuda", dtype=torch.float32)
+    for splitk in (1, 3):
+        out.zero_()
+        K.gemm(dtype, Co, 4 * Ci, P, K.operand(dy, Co, layout=L.BF_LAY_XC),
+               K.operand(img, Ci, layout=L.BF_LAY_XC, gw=gw, gh=gh, gc=Ci, seglen=2 * Ci, segstride=2 * gw * Ci, pro=L.BF_PRO_AFFINE_GELU,
+                         sc=sc, sh=sh, rows_per_frame=gh * gw, nch=Ci),
+               K.epilogue(out, 4 * Ci, out_mode=L.BF_OUT_ATOMIC_F32), splitk=splitk)
+        act = torch.nn.functional.gelu(img.float() * sc[:, None, None] + sh[:, None, None])
+        if dtype == torch.bfloat16:
+            act = act.bfloat16().float()
+        patches = act.view(Fr, gh, 2, gw, 2, Ci).permute(0, 1, 3, 2, 4, 5).reshape(P, 4 * Ci)      # columns (ky, kx, ci)
+        ref = dy.float().t() @ patches
+        assert _rel(out, ref) < TOL[dtype], splitk
+
+
 @pytest.mark.parametrize("S", [37, 1000])     # 1000 tokens per frame: the sliced (frames x slices) path with a ragged last slice
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_in_stats_two_pass(K, dtype, S):
