@@ -31,9 +31,9 @@ def _inputs(B, T, H, W, seed):
     return x, y, c
 
 
-def _weights(seed):
+def _weights(seed, cfg=None):
     from oracle import weights as Wt
-    return Wt.generate(Wt.param_shapes(**SMALL), seed=seed)
+    return Wt.generate(Wt.param_shapes(**(cfg or SMALL)), seed=seed)
 
 
 def _oracle(B, T, H, W, seed, grads=True):
@@ -158,3 +158,39 @@ def test_config4_forward_in_hip_graph_and_rollout():
             ref = m(ref, c)
         assert torch.isfinite(cur).all()
         assert torch.equal(cur, ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_film_avit_big_width(dtype):
+    """`film_avit_big` width (E = 768, 12 heads of 64; config/model_cfg/film_avit_big.yaml) through the same kernels: 3 blocks,
+    8x64x64 clips, bs 2.  E/4 = 192 intermediate channels: 768-column patch rows, two frames x 768 channels in a prologue table.
+    fp32: 1e-4.  bf16: forward 6e-2, dx 1.5e-1, all gradients 1e-1, family 0.7 -- the autocast yardstick at this shape (16-token
+    frames) is 3.1e-2 / 7.5e-2 / 3.6e-2 / worst family 3.1e-1, and this path also keeps the residual stream in bf16."""
+    from bubbleformer_amd.models import get_model
+    from oracle import filmavit_ref as R
+    big = dict(SMALL, embed_dim=768, num_heads=12, processor_blocks=3)
+    B, T, H, W, seed = 2, 8, 64, 64, 16
+    torch.set_num_threads(16)
+    x, y, c = _inputs(B, T, H, W, seed)
+    sd = {k: v.requires_grad_(True) for k, v in _weights(seed, big).items()}
+    xo = x.clone().requires_grad_(True)
+    pred_o = R.filmavit_forward(sd, xo, c, patch_size=16, num_heads=12)
+    loss_o = R.lp_loss(pred_o, y)
+    loss_o.backward()
+    m = get_model("filmavit", time_window=T, drop_path=0.0, compute_dtype=dtype, **big)
+    m.load_state_dict(_weights(seed, big))
+    m = m.cuda()
+    xg = x.cuda().requires_grad_(True)
+    loss, pred = m.forward_loss(xg, c.cuda(), y.cuda())
+    loss.backward()
+    f32 = dtype == torch.float32
+    assert rel_l2(pred.detach().cpu(), pred_o.detach()) < (1e-4 if f32 else 6e-2)
+    assert rel_l2(xg.grad.cpu(), xo.grad) < (1e-4 if f32 else 1.5e-1)
+    num = den = 0.0
+    for k, p in m.named_parameters():
+        ref = sd[k].grad
+        num += float((p.grad.cpu().double() - ref.double()).pow(2).sum())
+        den += float(ref.double().pow(2).sum())
+        if not structurally_zero(k):
+            assert rel_l2(p.grad.cpu(), ref) < (1e-4 if f32 else 0.7), k
+    assert (num / den) ** 0.5 < (1e-4 if f32 else 1e-1)
