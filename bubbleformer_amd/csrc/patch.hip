@@ -351,6 +351,43 @@ extern "C" int bf_film_net_bwd(const float* dgb, const float* chat, const float*
     return 0;
 }
 
+// ---------------------------------------------------------------------------- Lion (Chen et al. 2023, "Symbolic Discovery of Optimization
+// Algorithms"; the update lion_pytorch.Lion applies at bubbleformer/modules.py:139-140):
+//   p *= 1 - lr*wd;  p -= lr * sign(b1*m + (1-b1)*g);  m = b2*m + (1-b2)*g
+__global__ void __launch_bounds__(NT) lion_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, long n, float lr,
+                                                 float b1, float b2, float wd, float gscale) {
+    const long n4 = n / 4;
+    auto sgn = [](float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); };
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+#define BF_LION1(X)                                                        \
+        { const float gr = gg.X * gscale;                                   \
+          pp.X = pp.X * (1.f - lr * wd) - lr * sgn(b1 * mm.X + (1.f - b1) * gr); \
+          mm.X = b2 * mm.X + (1.f - b2) * gr; }
+        BF_LION1(x) BF_LION1(y) BF_LION1(z) BF_LION1(w)
+#undef BF_LION1
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - n4 * 4) {
+        const long i = n4 * 4 + threadIdx.x;
+        const float gr = g[i] * gscale;
+        p[i] = p[i] * (1.f - lr * wd) - lr * sgn(b1 * m[i] + (1.f - b1) * gr);
+        m[i] = b2 * m[i] + (1.f - b2) * gr;
+    }
+}
+
+extern "C" int bf_lion(float* p, const float* g, float* m, int64_t n, float lr, float beta1, float beta2, float wd, float gscale,
+                       bf_stream_t stream) {
+    BF_REQUIRE(p && g && m && n > 0, "bf_lion: bad arguments");
+    BF_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0), "bf_lion: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(lion_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, (hipStream_t)stream, p, g, m, (long)n, lr, beta1, beta2, wd, gscale);
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int bf_adamw(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float beta1, float beta2,
                         float eps, float wd, float gscale, bf_stream_t stream) {
     BF_REQUIRE(p && g && m && v && n > 0 && step >= 1, "bf_adamw: bad arguments");

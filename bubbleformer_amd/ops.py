@@ -345,6 +345,14 @@ def debed_with_loss(x, target, patch, cout, conv_w, in_w, in_b):
 
 
 # ------------------------------------------------------------------------------------------------ optimizer
+def lion_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, lr: float, betas=(0.9, 0.99), weight_decay: float = 0.0,
+          grad_scale: float = 1.0) -> None:
+    """Fused Lion over flat fp32 buffers (lion_pytorch.Lion semantics, bubbleformer/modules.py:139-140)."""
+    _require_gpu(p)
+    L.check(L.lib().bf_lion(_p(p), _p(g), _p(m), p.numel(), float(lr), float(betas[0]), float(betas[1]), float(weight_decay),
+                            float(grad_scale), _stream()), "bf_lion")
+
+
 def adamw_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float, betas=(0.9, 0.999),
            eps: float = 1e-8, weight_decay: float = 1e-2, grad_scale: float = 1.0) -> None:
     """Fused AdamW over flat fp32 buffers (torch.optim.AdamW semantics, bubbleformer/modules.py:135-136)."""

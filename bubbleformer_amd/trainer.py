@@ -103,16 +103,27 @@ def stage_buckets(model: nn.Module) -> List[int]:
 
 
 class TrainStep:
-    def __init__(self, model: nn.Module, lr: float = 2.5e-4, weight_decay: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8):
+    """optimizer: "adamw" (config/optim_cfg/adamw.yaml; modules.py:135-136) or "lion" (config/optim_cfg/lion.yaml, the reference
+    default; modules.py:139-140).  scheduler: optional object with get_last_lr() / step() (utils.lr_schedulers.CosineWarmupLR),
+    stepped once per optimizer step like the reference's ``interval="step"`` (modules.py:166-171)."""
+
+    def __init__(self, model: nn.Module, lr: float = 2.5e-4, weight_decay: float = 1e-2, betas=None, eps: float = 1e-8,
+                 optimizer: str = "adamw", scheduler=None):
         from . import ops
+        if optimizer not in ("adamw", "lion"):
+            raise ValueError(f"Optimizer {optimizer} not supported")
         self.ops = ops
         self.model = model
         self.flat = FlatParams(model)
         self.reducer = BucketReducer(self.flat, stage_buckets(model))
         self.slots = {p.data_ptr(): p.grad for p in self.flat.params}
+        self.optimizer = optimizer
         self.m = torch.zeros_like(self.flat.flat)
-        self.v = torch.zeros_like(self.flat.flat)
+        self.v = torch.zeros_like(self.flat.flat) if optimizer == "adamw" else None
+        if betas is None:
+            betas = (0.9, 0.999) if optimizer == "adamw" else (0.9, 0.99)
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.scheduler = scheduler
         self.step_no = 0
 
     def __call__(self, x, fluid, target) -> torch.Tensor:
@@ -124,7 +135,13 @@ class TrainStep:
             self.ops.set_direct_grad_slots(None)
         gscale = self.reducer.wait()
         self.step_no += 1
-        self.ops.adamw_(self.flat.flat, self.flat.grad, self.m, self.v, self.step_no, self.lr, self.betas, self.eps, self.wd, gscale)
+        lr = self.scheduler.get_last_lr()[0] if self.scheduler is not None else self.lr
+        if self.optimizer == "adamw":
+            self.ops.adamw_(self.flat.flat, self.flat.grad, self.m, self.v, self.step_no, lr, self.betas, self.eps, self.wd, gscale)
+        else:
+            self.ops.lion_(self.flat.flat, self.flat.grad, self.m, lr, self.betas, self.wd, gscale)
+        if self.scheduler is not None:
+            self.scheduler.step()
         return loss.detach()
 
     def _fwd_bwd(self, x, fluid, target):

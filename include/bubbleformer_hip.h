@@ -26,6 +26,7 @@
  *   bf_debed_last_* .......... HMLPDebed last stage + LpLoss: layers/patching.py:92-100, utils/losses.py:67-94
  *   bf_film_* ................ FiLMMLP.forward: layers/linear_layers.py:63-77
  *   bf_adamw ................. torch.optim.AdamW as configured at bubbleformer/modules.py:135-136
+ *   bf_lion .................. lion_pytorch.Lion (the reference's default optimizer) at bubbleformer/modules.py:139-140
  */
 #ifndef BUBBLEFORMER_HIP_H
 #define BUBBLEFORMER_HIP_H
@@ -146,6 +147,9 @@ int bf_film_net_bwd(const float* dgb, const float* chat, const float* lnw, const
                     float* dbias, float* dlnw, float* dlnb, int B, int P, int E2, bf_stream_t stream);
 int bf_adamw(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float beta1, float beta2, float eps,
              float wd, float gscale, bf_stream_t stream);
+/* Lion: p *= 1 - lr*wd; p -= lr*sign(beta1*m + (1-beta1)*g); m = beta2*m + (1-beta2)*g   (g is multiplied by gscale first) */
+int bf_lion(float* p, const float* g, float* m, int64_t n, float lr, float beta1, float beta2, float wd, float gscale,
+            bf_stream_t stream);
 
 /* ---------------------------------------------------------------- stage-level entry points (what the nn.Modules call) */
 

@@ -289,6 +289,27 @@ def lp_loss(pred: Tensor, y: Tensor) -> Tensor:
     return (num / den).mean(dim=0).mean(dim=0).sum()
 
 
+def lion_step(p: Tensor, g: Tensor, m: Tensor, lr: float, beta1: float = 0.9, beta2: float = 0.99, wd: float = 0.0) -> None:
+    """Lion single-tensor update, in place.  PARITY UNPINNED: the reference calls the third-party ``lion_pytorch.Lion``
+    (bubbleformer/modules.py:139-140; not vendored, version not pinned in env/*.yaml); this restates the published rule
+    (Chen et al. 2023, Algorithm 2; lion_pytorch ``update_fn``): decoupled decay, sign of the beta1-interpolated momentum,
+    then the beta2 momentum update."""
+    p.mul_(1.0 - lr * wd)
+    p.add_(torch.sign(m * beta1 + g * (1.0 - beta1)), alpha=-lr)
+    m.mul_(beta2).add_(g, alpha=1.0 - beta2)
+
+
+def cosine_warmup_lr(step: int, base_lr: float, warmup_iters: int, max_iters: int, eta_min: float = 0.0) -> float:
+    """Learning rate in effect for optimizer step number ``step`` (0-based) under the reference's CosineWarmupLR
+    (bubbleformer/utils/lr_schedulers.py:4-31: SequentialLR[LambdaLR(step / warmup_iters), CosineAnnealingLR(T_max=max_iters,
+    eta_min)], milestone warmup_iters, stepped once per batch, modules.py:153-171).  Closed form of what torch's schedulers
+    produce: linear ramp from 0, then the cosine restarted at the milestone (its own step counter starts at 0 there)."""
+    if step < warmup_iters:
+        return base_lr * step / warmup_iters
+    t = step - warmup_iters
+    return eta_min + (base_lr - eta_min) * (1.0 + math.cos(math.pi * t / max_iters)) / 2.0
+
+
 def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, beta1: float = 0.9,
                beta2: float = 0.999, eps: float = 1e-8, wd: float = 1e-2) -> None:
     """torch.optim.AdamW single-tensor update (decoupled decay), in place."""

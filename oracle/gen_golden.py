@@ -114,10 +114,41 @@ def run_variant(name, spec, ref_models, LpLoss):
     return out
 
 
+def gen_scheduler(gold):
+    """Learning rates produced by the reference's own CosineWarmupLR (utils/lr_schedulers.py:4-31), stepped once per optimizer step
+    as modules.py:153-171 configures it (config/scheduler_cfg/cosine_warmup.yaml + config/optim_cfg/{lion,adamw}.yaml)."""
+    import importlib.util
+    import warnings
+    spec = importlib.util.spec_from_file_location("ref_lr_schedulers", os.path.join(REF, "bubbleformer", "utils", "lr_schedulers.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = {}
+    cases = {"lion_1000_20000": (0.5e-4, 1000, 20000, 1.0e-6, 2500), "adamw_10_50": (2.5e-4, 10, 50, 1.0e-6, 80), "zero_min_3_7": (1.0, 3, 7, 0.0, 12)}
+    for name, (lr, warm, tmax, eta, nsteps) in cases.items():
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=lr)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sch = mod.CosineWarmupLR(opt, warmup_iters=warm, max_iters=tmax, eta_min=eta)
+            lrs = []
+            for _ in range(nsteps):
+                lrs.append(opt.param_groups[0]["lr"])
+                opt.step()
+                sch.step()
+        out[name + "/params"] = np.array([lr, warm, tmax, eta], dtype=np.float64)
+        out[name + "/lr"] = np.array(lrs, dtype=np.float64)
+    np.savez(os.path.join(gold, "cosine_warmup_lr.npz"), **out)
+
+
 def main():
-    ref_models, ref_layers, LpLoss = _import_reference()
     gold = os.path.join(REPO, "tests", "golden")
     os.makedirs(gold, exist_ok=True)
+    if "--only-scheduler" in sys.argv:
+        gen_scheduler(gold)
+        print("wrote cosine_warmup_lr.npz")
+        return
+    gen_scheduler(gold)
+    ref_models, ref_layers, LpLoss = _import_reference()
     for name, spec in VARIANTS.items():
         np.savez(os.path.join(gold, f"model_{name}.npz"), **run_variant(name, spec, ref_models, LpLoss))
 
