@@ -351,6 +351,58 @@ extern "C" int bf_film_net_bwd(const float* dgb, const float* chat, const float*
     return 0;
 }
 
+// ---------------------------------------------------------------------------- clip gather (device-resident trajectories -> batch)
+// out[b][t][c][yo][xo] = (src[field[c]][first[b] + t0 + t][ys(yo)][xs(xo)] - diff[c]) / div[c]
+// ys / xs: identity, or torch's F.interpolate(mode="nearest") source index floor(dst * float(in / out)) clamped to in - 1
+// (bubbleformer/data/dataset.py:138-148).  One thread per 4 output pixels of a row; reads of a full-resolution row are 16-byte.
+__global__ void __launch_bounds__(NT) clip_gather_kernel(const float* __restrict__ src, long field_stride, const int* __restrict__ field,
+                                                        const long* __restrict__ first, int t0, const float* __restrict__ diff,
+                                                        const float* __restrict__ dv, float* __restrict__ out, int B, int T, int C, int H, int W,
+                                                        int Ho, int Wo) {
+    const int wq = (Wo + 3) / 4;
+    const long total = (long)B * T * C * Ho * wq;
+    const float sy = (float)H / (float)Ho, sx = (float)W / (float)Wo;
+    const bool ident = Ho == H && Wo == W;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int xq = (int)(i % wq);
+        long r = i / wq;
+        const int yo = (int)(r % Ho); r /= Ho;
+        const int c = (int)(r % C); r /= C;
+        const int t = (int)(r % T);
+        const int b = (int)(r / T);
+        const int ys = ident ? yo : min((int)floorf((float)yo * sy), H - 1);
+        const float* row = src + (long)field[c] * field_stride + ((first[b] + t0 + t) * H + ys) * (long)W;
+        float* dst = out + ((((long)b * T + t) * C + c) * Ho + yo) * (long)Wo + 4 * xq;
+        const float d = diff[c], q = dv[c];
+        if (ident && (W & 3) == 0) {
+            const float4 v = *reinterpret_cast<const float4*>(row + 4 * xq);
+            *reinterpret_cast<float4*>(dst) = make_float4((v.x - d) / q, (v.y - d) / q, (v.z - d) / q, (v.w - d) / q);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int xo = 4 * xq + j;
+                if (xo < Wo) {
+                    const int xs = ident ? xo : min((int)floorf((float)xo * sx), W - 1);
+                    dst[j] = (row[xs] - d) / q;
+                }
+            }
+        }
+    }
+}
+
+extern "C" int bf_clip_gather(const float* src, int64_t field_stride, const int32_t* field, const int64_t* first, int t0,
+                              const float* diff, const float* div, float* out, int B, int T, int C, int H, int W, int Ho, int Wo,
+                              bf_stream_t stream) {
+    BF_REQUIRE(src && field && first && diff && div && out, "bf_clip_gather: null pointer");
+    BF_REQUIRE(B > 0 && T > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && Ho <= H && Wo <= W && t0 >= 0, "bf_clip_gather: bad sizes");
+    BF_REQUIRE(((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0), "bf_clip_gather: buffers must be 16-byte aligned");
+    const long total = (long)B * T * C * Ho * ((Wo + 3) / 4);
+    hipLaunchKernelGGL(clip_gather_kernel, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, src, (long)field_stride, (const int*)field,
+                       (const long*)first, t0, diff, div, out, B, T, C, H, W, Ho, Wo);
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------- Lion (Chen et al. 2023, "Symbolic Discovery of Optimization
 // Algorithms"; the update lion_pytorch.Lion applies at bubbleformer/modules.py:139-140):
 //   p *= 1 - lr*wd;  p -= lr * sign(b1*m + (1-b1)*g);  m = b2*m + (1-b2)*g

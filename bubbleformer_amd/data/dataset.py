@@ -1,0 +1,167 @@
+"""Clip supply for the training step.
+
+``BubbleForecast`` keeps the reference class's constructor, ``__len__``, ``normalize`` and ``__getitem__`` contract
+(bubbleformer/data/dataset.py:17-184) but reads the trajectory files with the in-tree HDF5 reader (no h5py), and adds the
+MI355X-side path: ``device_store()`` puts every trajectory in HBM once (a BubbleML study is a few GB; one GPU has 288 GB) and
+``DeviceClipStore.gather`` builds a whole batch of normalised (input, target) clips with ONE HIP kernel (`bf_clip_gather`,
+csrc/patch.hip) -- no host-side slicing, stacking or H2D copy per step.
+"""
+import json
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from . import hdf5_lite
+
+FLUID_PARAM_KEYS = ("inv_reynolds", "cpgas", "mugas", "rhogas", "thcogas", "stefan", "prandtl")       # dataset.py:165-178, then heater.*
+
+
+def _fluid_vector(fp: dict) -> List[float]:
+    return [fp[k] for k in FLUID_PARAM_KEYS] + [fp["heater"]["nucWaitTime"], fp["heater"]["wallTemp"]]
+
+
+class BubbleForecast(Dataset):
+    """Dataset class for time series forecasting on the BubbleML dataset (reference: bubbleformer/data/dataset.py:17)."""
+
+    def __init__(self, filenames: List[str], input_fields: Optional[List[str]] = None, output_fields: Optional[List[str]] = None,
+                 norm: str = "none", downsample_factor: int = 1, time_window: int = 16, start_time: int = 50,
+                 return_fluid_params: bool = False):
+        super().__init__()
+        self.filenames = filenames
+        self.input_fields = input_fields if input_fields is not None else ["dfun", "temperature", "velx", "vely"]
+        self.output_fields = output_fields if output_fields is not None else ["dfun", "temperature", "velx", "vely"]
+        self.norm = norm
+        self.downsample_factor = downsample_factor
+        self.time_window = time_window
+        self.start_time = start_time
+        self.data = [hdf5_lite.File(filename, "r") for filename in filenames]
+        self.num_trajs = [1 for _ in self.data]
+        self.traj_lens = [f[self.input_fields[0]].shape[0] for f in self.data]
+        self.input_num_fields = len(self.input_fields)
+        self.output_num_fields = len(self.output_fields)
+        self.fields = list(set(self.input_fields + self.output_fields))
+        self.diff_terms = {k: [] for k in self.fields}
+        self.div_terms = {k: [] for k in self.fields}
+        self.return_fluid_params = return_fluid_params
+        if self.return_fluid_params:
+            self.fluid_params = []
+            for fname in filenames:
+                with open(fname.replace(".hdf5", ".json"), "r", encoding="utf-8") as f:
+                    self.fluid_params.append(json.load(f))
+
+    # ---------------------------------------------------------------- reference contract
+    def _per_traj(self) -> List[int]:
+        return [n * (t - self.start_time - 2 * self.time_window + 1) for n, t in zip(self.num_trajs, self.traj_lens)]
+
+    def __len__(self) -> int:
+        return sum(self._per_traj())
+
+    def normalize(self, diff_terms: Optional[Dict] = None, div_terms: Optional[Dict] = None) -> Tuple[Dict, Dict]:
+        """Channel-wise normalisation constants: mean over files of the per-file statistic (dataset.py:73-117)."""
+        if diff_terms is None and div_terms is None:
+            diff_terms = {k: [] for k in self.fields}
+            div_terms = {k: [] for k in self.fields}
+            for field in self.fields:
+                for h5_file in self.data:
+                    if self.norm == "none":
+                        diff_terms[field].append(0.0)
+                        div_terms[field].append(1.0)
+                        continue
+                    x = h5_file[field][...]
+                    if self.norm == "std":
+                        diff_terms[field].append(x.mean())
+                        div_terms[field].append(x.std())
+                    elif self.norm == "minmax":
+                        diff_terms[field].append(x.min())
+                        div_terms[field].append(x.max() - x.min())
+                    elif self.norm == "tanh":
+                        diff_terms[field].append((x.max() + x.min()) / 2.0)
+                        div_terms[field].append((x.max() - x.min()) / 2.0)
+                    else:
+                        raise ValueError(f"Unknown normalization type: {self.norm}")
+                diff_terms[field] = np.mean(diff_terms[field]).item()
+                div_terms[field] = np.mean(div_terms[field]).item() + 1e-8
+        self.diff_terms = diff_terms
+        self.div_terms = div_terms
+        return self.diff_terms, self.div_terms
+
+    def locate(self, idx: int) -> Tuple[int, int]:
+        """Sample index -> (file index, first input frame) (dataset.py:120-128)."""
+        cumulative = np.cumsum(self._per_traj())
+        file_idx = int(np.searchsorted(cumulative, idx, side="right"))
+        start = idx + self.start_time - (int(cumulative[file_idx - 1]) if file_idx > 0 else 0)
+        return file_idx, int(start)
+
+    def _field_clip(self, file_idx: int, field: str, sl: slice) -> torch.Tensor:
+        item = torch.from_numpy(np.array(self.data[file_idx][field][sl], dtype=np.float32))
+        if self.downsample_factor > 1:
+            _, h, w = item.shape
+            item = torch.nn.functional.interpolate(item.unsqueeze(1), size=(h // self.downsample_factor, w // self.downsample_factor),
+                                                   mode="nearest").squeeze(1)
+        return (item - self.diff_terms[field]) / self.div_terms[field]
+
+    def __getitem__(self, idx: int):
+        file_idx, start = self.locate(idx)
+        tw = self.time_window
+        inp = torch.stack([self._field_clip(file_idx, f, slice(start, start + tw)) for f in self.input_fields])          # (C, T, H, W)
+        out = torch.stack([self._field_clip(file_idx, f, slice(start + tw, start + 2 * tw)) for f in self.output_fields])
+        if self.return_fluid_params:
+            fp = torch.tensor(_fluid_vector(self.fluid_params[file_idx]), dtype=torch.float32)
+            return inp.float().permute(1, 0, 2, 3), out.float().permute(1, 0, 2, 3), fp
+        return inp.float().permute(1, 0, 2, 3), out.float().permute(1, 0, 2, 3)
+
+    # ---------------------------------------------------------------- device-resident path
+    def device_store(self, device) -> "DeviceClipStore":
+        return DeviceClipStore(self, device)
+
+
+class DeviceClipStore:
+    """Every trajectory of the dataset resident in HBM as one fp32 tensor ``[field][frame][H][W]`` (files concatenated along the
+    frame axis); ``gather(indices)`` returns the batch the reference's DataLoader would have collated from ``dataset[i]``:
+    ``(B, T, C_in, H', W')``, ``(B, T, C_out, H', W')`` [, ``(B, 9)`` fluid parameters] -- built by one kernel launch."""
+
+    def __init__(self, ds: BubbleForecast, device):
+        self.ds = ds
+        self.device = torch.device(device)
+        shapes = {tuple(f[ds.fields[0]].shape[1:]) for f in ds.data}
+        if len(shapes) != 1:
+            raise ValueError(f"device store needs one spatial resolution per dataset, got {sorted(shapes)}")
+        (self.H, self.W), = shapes
+        self.fields = sorted(ds.fields)
+        self.frame0 = np.concatenate([[0], np.cumsum(ds.traj_lens)]).astype(np.int64)       # first frame of each file on the frame axis
+        total = int(self.frame0[-1])
+        host = torch.empty((len(self.fields), total, self.H, self.W), dtype=torch.float32)
+        for fi, f in enumerate(ds.data):
+            for ci, name in enumerate(self.fields):
+                host[ci, self.frame0[fi]:self.frame0[fi + 1]] = torch.from_numpy(np.array(f[name][...], dtype=np.float32))
+        self.frames = host.to(self.device)
+        self.fluid = None
+        if ds.return_fluid_params:
+            self.fluid = torch.tensor([_fluid_vector(fp) for fp in ds.fluid_params], dtype=torch.float32, device=self.device)
+        self._tables()
+
+    def _tables(self):
+        """Per-output-channel field index and normalisation constants; call again after ``ds.normalize()`` changed them."""
+        ds = self.ds
+        def tab(names):
+            ids = torch.tensor([self.fields.index(n) for n in names], dtype=torch.int32, device=self.device)
+            diff = torch.tensor([float(ds.diff_terms[n]) if not isinstance(ds.diff_terms[n], list) else 0.0 for n in names], dtype=torch.float32, device=self.device)
+            div = torch.tensor([float(ds.div_terms[n]) if not isinstance(ds.div_terms[n], list) else 1.0 for n in names], dtype=torch.float32, device=self.device)
+            return ids, diff, div
+        self.in_tab, self.out_tab = tab(ds.input_fields), tab(ds.output_fields)
+
+    def gather(self, indices: Sequence[int]):
+        from .. import ops
+        ds = self.ds
+        loc = [ds.locate(int(i)) for i in indices]
+        first = torch.tensor([self.frame0[fi] + st for fi, st in loc], dtype=torch.int64).to(self.device, non_blocking=True)
+        tw, f = ds.time_window, ds.downsample_factor
+        ho, wo = (self.H // f, self.W // f) if f > 1 else (self.H, self.W)
+        inp = ops.clip_gather(self.frames, first, 0, tw, self.in_tab, ho, wo)
+        out = ops.clip_gather(self.frames, first, tw, tw, self.out_tab, ho, wo)
+        if self.fluid is not None:
+            fidx = torch.tensor([fi for fi, _ in loc], dtype=torch.int64, device=self.device)
+            return inp, out, self.fluid[fidx]
+        return inp, out

@@ -345,6 +345,19 @@ def debed_with_loss(x, target, patch, cout, conv_w, in_w, in_b):
 
 
 # ------------------------------------------------------------------------------------------------ optimizer
+def clip_gather(frames: torch.Tensor, first: torch.Tensor, t0: int, T: int, table, Ho: int, Wo: int) -> torch.Tensor:
+    """frames [fields][total_frames][H][W] fp32 (device), first [B] int64 absolute first input frame per sample, table =
+    (field ids int32 [C], diff fp32 [C], div fp32 [C]) -> (B, T, C, Ho, Wo) fp32 normalised clips (data/dataset.py)."""
+    _require_gpu(frames)
+    ids, diff, div = table
+    nf, total, H, W = frames.shape
+    B, Cn = first.numel(), ids.numel()
+    out = torch.empty((B, T, Cn, Ho, Wo), dtype=torch.float32, device=frames.device)
+    L.check(L.lib().bf_clip_gather(_p(frames), total * H * W, _p(ids), _p(first), int(t0), _p(diff), _p(div), _p(out), B, T, Cn, H, W, Ho, Wo,
+                                   _stream()), "bf_clip_gather")
+    return out
+
+
 def lion_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, lr: float, betas=(0.9, 0.99), weight_decay: float = 0.0,
           grad_scale: float = 1.0) -> None:
     """Fused Lion over flat fp32 buffers (lion_pytorch.Lion semantics, bubbleformer/modules.py:139-140)."""

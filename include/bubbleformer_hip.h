@@ -26,6 +26,7 @@
  *   bf_debed_last_* .......... HMLPDebed last stage + LpLoss: layers/patching.py:92-100, utils/losses.py:67-94
  *   bf_film_* ................ FiLMMLP.forward: layers/linear_layers.py:63-77
  *   bf_adamw ................. torch.optim.AdamW as configured at bubbleformer/modules.py:135-136
+ *   bf_clip_gather ........... BubbleForecast.__getitem__ + DataLoader collate for a batch of clips: bubbleformer/data/dataset.py:120-182
  *   bf_lion .................. lion_pytorch.Lion (the reference's default optimizer) at bubbleformer/modules.py:139-140
  */
 #ifndef BUBBLEFORMER_HIP_H
@@ -147,6 +148,11 @@ int bf_film_net_bwd(const float* dgb, const float* chat, const float* lnw, const
                     float* dbias, float* dlnw, float* dlnb, int B, int P, int E2, bf_stream_t stream);
 int bf_adamw(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float beta1, float beta2, float eps,
              float wd, float gscale, bf_stream_t stream);
+/* Batch of normalised clips from device-resident trajectories src [fields][frames][H][W] (fp32):
+ * out[b][t][c][yo][xo] = (src[field[c]][first[b] + t0 + t][ys][xs] - diff[c]) / div[c], (ys, xs) = nearest-neighbour source pixel of
+ * (yo, xo) when Ho x Wo < H x W (F.interpolate(mode="nearest") index rule), identity otherwise.  out is (B, T, C, Ho, Wo) fp32. */
+int bf_clip_gather(const float* src, int64_t field_stride, const int32_t* field, const int64_t* first, int t0, const float* diff,
+                   const float* div, float* out, int B, int T, int C, int H, int W, int Ho, int Wo, bf_stream_t stream);
 /* Lion: p *= 1 - lr*wd; p -= lr*sign(beta1*m + (1-beta1)*g); m = beta2*m + (1-beta2)*g   (g is multiplied by gscale first) */
 int bf_lion(float* p, const float* g, float* m, int64_t n, float lr, float beta1, float beta2, float wd, float gscale,
             bf_stream_t stream);
