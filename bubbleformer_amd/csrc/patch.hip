@@ -351,6 +351,69 @@ extern "C" int bf_film_net_bwd(const float* dgb, const float* chat, const float*
     return 0;
 }
 
+// ---------------------------------------------------------------------------- physics metrics of a rollout
+// Eikonal residual of a signed-distance field (utils/losses.py:5-15): torch.gradient(edge_order=1, spacing=dx) along H and W
+// (central differences inside, one-sided at the borders), out += sum over pixels of (|grad phi| - 1)^2   (caller divides by the count)
+__global__ void __launch_bounds__(NT) eikonal_kernel(const float* __restrict__ phi, long frames, int H, int W, float inv_dx, double* __restrict__ out) {
+    __shared__ double red[NT / 64];
+    const long total = frames * H * W;
+    double acc = 0.0;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const float* p = phi + i;
+        float gy, gx;
+        if (H == 1) gy = 0.f;
+        else if (y == 0) gy = (p[W] - p[0]) * inv_dx;
+        else if (y == H - 1) gy = (p[0] - p[-W]) * inv_dx;
+        else gy = (p[W] - p[-W]) * (0.5f * inv_dx);
+        if (W == 1) gx = 0.f;
+        else if (x == 0) gx = (p[1] - p[0]) * inv_dx;
+        else if (x == W - 1) gx = (p[0] - p[-1]) * inv_dx;
+        else gx = (p[1] - p[-1]) * (0.5f * inv_dx);
+        const float r = sqrtf(gy * gy + gx * gx) - 1.f;
+        acc += (double)(r * r);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < NT / 64; ++i) t += red[i];
+        atomicAdd(out, t);
+    }
+}
+// Heater heat flux of FC-72 pool boiling per frame (utils/heatflux.py:17-38): bottom row y = 0 of a W-column grid spanning
+// x in [x_min, x_min + W*dx); flux[t] = mean_x( [ |x| <= 5 and dfun < 0 ] * (heater_temp - temp) ) * 0.054 / (dx * lc)
+__global__ void __launch_bounds__(64) heatflux_kernel(const float* __restrict__ dfun, const float* __restrict__ temp, long frame_stride, int W,
+                                                     float x_min, float dx, float heater_temp, float coef, float* __restrict__ flux) {
+    const float* d = dfun + (long)blockIdx.x * frame_stride;
+    const float* t = temp + (long)blockIdx.x * frame_stride;
+    double acc = 0.0;
+    for (int x = threadIdx.x; x < W; x += 64) {
+        const double xc = (double)x_min + ((double)x + 0.5) * (double)dx;
+        if (xc >= -5.0 && xc <= 5.0 && d[x] < 0.f) acc += (double)(heater_temp - t[x]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (threadIdx.x == 0) flux[blockIdx.x] = (float)(acc / (double)W * (double)coef);
+}
+
+extern "C" int bf_eikonal_sum(const float* phi, int64_t frames, int H, int W, float dx, double* out, bf_stream_t stream) {
+    BF_REQUIRE(phi && out && frames > 0 && H > 0 && W > 0 && dx > 0.f, "bf_eikonal_sum: bad arguments");
+    hipLaunchKernelGGL(eikonal_kernel, dim3(grid_for(frames * H * W)), dim3(NT), 0, (hipStream_t)stream, phi, (long)frames, H, W, 1.f / dx, out);
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int bf_heatflux_rows(const float* dfun, const float* temp, int64_t frames, int64_t frame_stride, int W, float x_min, float dx,
+                                float heater_temp, float lc, float* flux, bf_stream_t stream) {
+    BF_REQUIRE(dfun && temp && flux && frames > 0 && W > 0 && dx > 0.f && lc > 0.f, "bf_heatflux_rows: bad arguments");
+    hipLaunchKernelGGL(heatflux_kernel, dim3((unsigned)frames), dim3(64), 0, (hipStream_t)stream, dfun, temp, (long)frame_stride, W, x_min, dx,
+                       heater_temp, 0.054f / (dx * lc), flux);
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------- clip gather (device-resident trajectories -> batch)
 // out[b][t][c][yo][xo] = (src[field[c]][first[b] + t0 + t][ys(yo)][xs(xo)] - diff[c]) / div[c]
 // ys / xs: identity, or torch's F.interpolate(mode="nearest") source index floor(dst * float(in / out)) clamped to in - 1

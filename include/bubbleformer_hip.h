@@ -27,6 +27,7 @@
  *   bf_film_* ................ FiLMMLP.forward: layers/linear_layers.py:63-77
  *   bf_adamw ................. torch.optim.AdamW as configured at bubbleformer/modules.py:135-136
  *   bf_clip_gather ........... BubbleForecast.__getitem__ + DataLoader collate for a batch of clips: bubbleformer/data/dataset.py:120-182
+ *   bf_eikonal_sum / bf_heatflux_rows .. eikonal_loss utils/losses.py:5-15, heatflux utils/heatflux.py:3-38
  *   bf_lion .................. lion_pytorch.Lion (the reference's default optimizer) at bubbleformer/modules.py:139-140
  */
 #ifndef BUBBLEFORMER_HIP_H
@@ -153,6 +154,13 @@ int bf_adamw(float* p, const float* g, float* m, float* v, int64_t n, int step, 
  * (yo, xo) when Ho x Wo < H x W (F.interpolate(mode="nearest") index rule), identity otherwise.  out is (B, T, C, Ho, Wo) fp32. */
 int bf_clip_gather(const float* src, int64_t field_stride, const int32_t* field, const int64_t* first, int t0, const float* diff,
                    const float* div, float* out, int B, int T, int C, int H, int W, int Ho, int Wo, bf_stream_t stream);
+/* Rollout physics metrics (scripts/inference.py; utils/losses.py:5-15, utils/heatflux.py:17-38).
+ * bf_eikonal_sum: *out (fp64, caller zeroes) += sum over frames x H x W of (|grad phi| - 1)^2, gradients as torch.gradient(spacing=dx).
+ * bf_heatflux_rows: flux[t] = mean over the W bottom-row cells of [|x_c| <= 5 and dfun < 0] * (heater_temp - temp) * 0.054 / (dx * lc),
+ * x_c = x_min + (i + 0.5) * dx; dfun / temp point at row 0 of frame 0, frames are frame_stride elements apart. */
+int bf_eikonal_sum(const float* phi, int64_t frames, int H, int W, float dx, double* out, bf_stream_t stream);
+int bf_heatflux_rows(const float* dfun, const float* temp, int64_t frames, int64_t frame_stride, int W, float x_min, float dx,
+                     float heater_temp, float lc, float* flux, bf_stream_t stream);
 /* Lion: p *= 1 - lr*wd; p -= lr*sign(beta1*m + (1-beta1)*g); m = beta2*m + (1-beta2)*g   (g is multiplied by gscale first) */
 int bf_lion(float* p, const float* g, float* m, int64_t n, float lr, float beta1, float beta2, float wd, float gscale,
             bf_stream_t stream);

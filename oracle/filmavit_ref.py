@@ -299,6 +299,34 @@ def lion_step(p: Tensor, g: Tensor, m: Tensor, lr: float, beta1: float = 0.9, be
     m.mul_(beta2).add_(g, alpha=1.0 - beta2)
 
 
+def eikonal_loss(phi: Tensor) -> Tensor:
+    """utils/losses.py:5-15: mean of (|grad phi| - 1)^2, torch.gradient semantics (spacing 1/32, edge_order 1) written out:
+    central differences in the interior, one-sided first differences on the border, along H (dim -2) and W (dim -1)."""
+    dx = 1.0 / 32
+
+    def grad(a: Tensor, dim: int) -> Tensor:
+        a = a.movedim(dim, -1)
+        g = torch.empty_like(a)
+        g[..., 1:-1] = (a[..., 2:] - a[..., :-2]) / (2 * dx)
+        g[..., 0] = (a[..., 1] - a[..., 0]) / dx
+        g[..., -1] = (a[..., -1] - a[..., -2]) / dx
+        return g.movedim(-1, dim)
+    gy, gx = grad(phi, -2), grad(phi, -1)
+    return ((torch.sqrt(gy ** 2 + gx ** 2) - 1.0) ** 2).mean()
+
+
+def heatflux(dfun, temp, heater_temp: float):
+    """utils/heatflux.py:3-38 (numpy arrays (T, 512, 512)): bottom-row flux of the liquid cells over the heater |x| <= 5 on the
+    16 x 16 domain at dx = 1/32, 0.054 * (T_heater - T) / (dx * lc) with lc = 0.0007; returns (mean, max) over frames."""
+    import numpy as np
+    dx, lc = 1 / 32, 0.0007
+    xc = -8 + (np.arange(512) + 0.5) * dx
+    mask = (xc >= -5.0) & (xc <= 5.0)
+    row = (mask[None, :] & (dfun[:, 0, :] < 0)).astype(float) * (heater_temp - temp[:, 0, :])
+    fl = (0.054 * row / (dx * lc)).mean(axis=1)
+    return float(np.mean(fl)), float(np.max(fl))
+
+
 def cosine_warmup_lr(step: int, base_lr: float, warmup_iters: int, max_iters: int, eta_min: float = 0.0) -> float:
     """Learning rate in effect for optimizer step number ``step`` (0-based) under the reference's CosineWarmupLR
     (bubbleformer/utils/lr_schedulers.py:4-31: SequentialLR[LambdaLR(step / warmup_iters), CosineAnnealingLR(T_max=max_iters,

@@ -140,14 +140,43 @@ def gen_scheduler(gold):
     np.savez(os.path.join(gold, "cosine_warmup_lr.npz"), **out)
 
 
+def physics_inputs(seed=21, T=3):
+    """Seeded inputs of the physics-metric goldens (shared with tests/test_rollout_physics.py; numpy RandomState is stable)."""
+    rs = np.random.RandomState(seed)
+    phi = (rs.standard_normal((2, 3, 20, 24)) * 0.2 + np.linspace(-1, 1, 24)[None, None, None, :] * 0.7).astype(np.float32)
+    dfun = (rs.standard_normal((T, 512, 512)) - 0.3).astype(np.float32)
+    temp = np.abs(rs.standard_normal((T, 512, 512)) * 0.3).astype(np.float32)
+    return phi, dfun, temp
+
+
+def gen_physics(gold):
+    """eikonal_loss (utils/losses.py:5-15) and heatflux (utils/heatflux.py:3-38) evaluated by the reference's own functions."""
+    import importlib.util
+
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, "bubbleformer", "utils", rel))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    losses, hf = load("ref_losses", "losses.py"), load("ref_heatflux", "heatflux.py")
+    phi, dfun, temp = physics_inputs()
+    eik32 = float(losses.eikonal_loss(torch.from_numpy(phi)))
+    eik64 = float(losses.eikonal_loss(torch.from_numpy(phi).double()))
+    mean, mx = hf.heatflux(dfun, temp, 1.0)
+    np.savez(os.path.join(gold, "physics.npz"), eikonal_f32=np.array(eik32), eikonal_f64=np.array(eik64), heatflux_mean=np.array(mean),
+             heatflux_max=np.array(mx), seed=np.array(21), frames=np.array(3), heater_temp=np.array(1.0))
+
+
 def main():
     gold = os.path.join(REPO, "tests", "golden")
     os.makedirs(gold, exist_ok=True)
-    if "--only-scheduler" in sys.argv:
+    if "--only-scheduler" in sys.argv or "--only-small" in sys.argv:
         gen_scheduler(gold)
-        print("wrote cosine_warmup_lr.npz")
+        gen_physics(gold)
+        print("wrote cosine_warmup_lr.npz, physics.npz")
         return
     gen_scheduler(gold)
+    gen_physics(gold)
     ref_models, ref_layers, LpLoss = _import_reference()
     for name, spec in VARIANTS.items():
         np.savez(os.path.join(gold, f"model_{name}.npz"), **run_variant(name, spec, ref_models, LpLoss))

@@ -1,0 +1,60 @@
+"""Rollout-side pieces: physics metrics and the device-resident autoregressive loop.
+
+tests/golden/physics.npz holds eikonal_loss / heatflux evaluated by the reference's own functions (utils/losses.py:5-15,
+utils/heatflux.py:3-38; oracle/gen_golden.py) on seeded inputs that `oracle.gen_golden.physics_inputs` regenerates.  CPU: the
+oracle restatements reproduce those values.  GPU: the HIP kernels do, and the HIP-graph rollout equals the eager loop."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "physics.npz")
+
+
+def _inputs():
+    from oracle.gen_golden import physics_inputs
+    return physics_inputs()
+
+
+def test_oracle_physics_match_reference_values():
+    from oracle import filmavit_ref as R
+    z = np.load(GOLDEN)
+    phi, dfun, temp = _inputs()
+    assert float(R.eikonal_loss(torch.from_numpy(phi).double())) == pytest.approx(float(z["eikonal_f64"]), rel=1e-12)
+    assert float(R.eikonal_loss(torch.from_numpy(phi))) == pytest.approx(float(z["eikonal_f32"]), rel=2e-6)
+    mean, mx = R.heatflux(dfun, temp, float(z["heater_temp"]))
+    assert mean == pytest.approx(float(z["heatflux_mean"]), rel=1e-12) and mx == pytest.approx(float(z["heatflux_max"]), rel=1e-12)
+
+
+@pytest.mark.gpu
+def test_physics_kernels_match_reference_values():
+    from bubbleformer_amd.utils import physics
+    z = np.load(GOLDEN)
+    phi, dfun, temp = _inputs()
+    assert float(physics.eikonal_loss(torch.from_numpy(phi).cuda())) == pytest.approx(float(z["eikonal_f64"]), rel=2e-6)
+    mean, mx = physics.heatflux(torch.from_numpy(dfun).cuda(), torch.from_numpy(temp).cuda(), float(z["heater_temp"]))
+    assert float(mean) == pytest.approx(float(z["heatflux_mean"]), rel=2e-6) and float(mx) == pytest.approx(float(z["heatflux_max"]), rel=2e-6)
+    # degenerate axes behave like torch.gradient would not allow (needs >= 2 points): a 1-wide axis contributes a zero derivative
+    one = torch.linspace(0, 1, 9, device="cuda").view(1, 9, 1) / 32
+    assert float(physics.eikonal_loss(one)) == pytest.approx(float(((torch.full((9,), 1 / 8.0) - 1) ** 2).mean()), rel=1e-5)
+
+
+@pytest.mark.gpu
+def test_graphed_rollout_equals_eager_and_scores_steps():
+    from bubbleformer_amd.models import get_model
+    from bubbleformer_amd.utils.rollout import autoregressive_rollout, relative_l2_per_step
+    from oracle import weights as Wt
+    cfg = dict(input_fields=4, output_fields=4, patch_size=4, embed_dim=64, num_heads=2, processor_blocks=2)
+    model = get_model("avit", time_window=4, drop_path=0.0, **cfg)
+    model.load_state_dict(Wt.generate(Wt.param_shapes(**cfg), seed=3))
+    model = model.cuda().eval()
+    x0 = Wt.synthetic_clip(1, 4, 4, 32, 32, 5)[0].cuda()
+    tg = [Wt.synthetic_clip(1, 4, 4, 32, 32, 50 + s)[0].cuda() for s in range(3)]
+    pg, eg = autoregressive_rollout(model, x0, 3, use_graph=True, target_fn=lambda s: tg[s])
+    pe, ee = autoregressive_rollout(model, x0, 3, use_graph=False, target_fn=lambda s: tg[s])
+    assert pg.shape == (12, 4, 32, 32) and torch.equal(pg, pe)
+    assert len(eg) == 3 and all(torch.equal(a, b) for a, b in zip(eg, ee))
+    num = (pg[:4] - tg[0]).flatten(-2).norm(dim=-1)
+    den = tg[0].flatten(-2).norm(dim=-1)
+    assert float(relative_l2_per_step(pg[:4], tg[0])) == pytest.approx(float((num / den).mean()), rel=1e-6)
