@@ -80,11 +80,14 @@ __device__ __forceinline__ float erf_fast(float x) {
     return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
-// d/dx gelu(x) = Phi(x) + x * phi(x)
+// d/dx gelu(x) = Phi(x) + x * phi(x).  The exponential inside erf_fast(x / sqrt 2) is exp(-x^2 / 2), i.e. phi's: evaluated once.
 __device__ __forceinline__ float dgelu_f(float x) {
-    const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    const float ax = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = __expf(-0.5f * x * x);
+    const float cdf = 0.5f * (1.0f + copysignf(1.0f - poly * e, x));
+    return cdf + x * (0.39894228040143267794f * e);
 }
 
 // ---------------------------------------------------------------- wave / block reductions (64 lanes)
