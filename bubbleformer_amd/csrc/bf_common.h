@@ -38,6 +38,9 @@ struct BfProfScope {
     ~BfProfScope() { if (idx >= 0) bf_prof_end(idx, st, name, flops, bytes); }
 };
 
+// out = z * m[(row / S) / fdiv] (norm.hip; internal)
+int bf_frame_scale(int dtype, const void* z, const float* m, int fdiv, void* out, long nrows, int S, int C, hipStream_t st);
+
 int bf_fail(hipError_t e, const char* file, int line);
 int bf_fail_msg(const char* msg, const char* file, int line);
 

@@ -135,11 +135,11 @@ struct Fork {
 
 // ------------------------------------------------------------------------------------------------ small param kernels
 // out-projection fold.  mc[n] = <W[n,:], nb> + bias[n]; alpha = gamma*(1+hi); beta = gamma*(bias*(1+hi) + mc*(lo-hi))
-__global__ void outproj_prep_kernel(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ nb,
-                                    const float* __restrict__ gamma, const float* __restrict__ lo, const float* __restrict__ hi,
-                                    float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ mc, int E) {
+struct PrepArgs { const float *W, *bias, *nb, *gamma, *lo, *hi; float *alpha, *beta, *mc; int E; };
+__device__ __forceinline__ void outproj_prep_row(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ nb,
+                                                 const float* __restrict__ gamma, const float* __restrict__ lo, const float* __restrict__ hi,
+                                                 float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ mc, int E, int n) {
     __shared__ float red[4];
-    const int n = blockIdx.x;
     float acc = 0.f;
     if (lo) for (int k = threadIdx.x; k < E; k += blockDim.x) acc += W[(long)n * E + k] * nb[k];
     acc = wave_sum(acc);
@@ -153,6 +153,9 @@ __global__ void outproj_prep_kernel(const float* __restrict__ W, const float* __
         beta[n] = g * (bias[n] * (1.f + h) + (lo ? m * (l - h) : 0.f));
         mc[n] = m;
     }
+}
+__global__ void __launch_bounds__(256) outproj_prep_kernel(PrepArgs a) {
+    outproj_prep_row(a.W, a.bias, a.nb, a.gamma, a.lo, a.hi, a.alpha, a.beta, a.mc, a.E, blockIdx.x);
 }
 // parameter gradients of the fold (see header comment).  grid = E rows.
 __global__ void outproj_finalize_kernel(const float* __restrict__ G, const float* __restrict__ csum, const float* __restrict__ W,
@@ -227,13 +230,34 @@ __global__ void __launch_bounds__(256) cast4_kernel(Cast4 j) {
         *reinterpret_cast<bf16x4*>(j.dst[w] + 4 * i) = o;
     }
 }
-// weights[i] (fp32, count n[i], multiples of 4) -> compute-dtype operands: one cast launch in bf16 mode, aliases in f32 mode
-int wviews(const D& d, int cnt, const float* const* src, void* const* dst, const long* n, const void** out, hipStream_t st) {
-    if (d.dtype == BF_DTYPE_F32) { for (int i = 0; i < cnt; ++i) out[i] = src[i]; return 0; }
+// the same casts plus the out-projection fold (grid row cnt, one workgroup per output channel): a stage's parameter-only work in ONE launch
+__global__ void __launch_bounds__(256) stage_prep_kernel(Cast4 j, int cnt, PrepArgs a) {
+    if ((int)blockIdx.y == cnt) {
+        if ((int)blockIdx.x < a.E) outproj_prep_row(a.W, a.bias, a.nb, a.gamma, a.lo, a.hi, a.alpha, a.beta, a.mc, a.E, blockIdx.x);
+        return;
+    }
+    const int w = blockIdx.y;
+    const long n4 = j.n[w] / 4;
+    const float4* s4 = reinterpret_cast<const float4*>(j.src[w]);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = s4[i];
+        const bf16x4 o = {(bf16)v.x, (bf16)v.y, (bf16)v.z, (bf16)v.w};
+        *reinterpret_cast<bf16x4*>(j.dst[w] + 4 * i) = o;
+    }
+}
+// weights[i] (fp32, count n[i], multiples of 4) -> compute-dtype operands: one cast launch in bf16 mode, aliases in f32 mode;
+// `prep` (optional): the out-projection fold of the stage, computed in the same launch
+int wviews(const D& d, int cnt, const float* const* src, void* const* dst, const long* n, const void** out, hipStream_t st, const PrepArgs* prep = nullptr) {
+    if (d.dtype == BF_DTYPE_F32) {
+        for (int i = 0; i < cnt; ++i) out[i] = src[i];
+        if (prep) { hipLaunchKernelGGL(outproj_prep_kernel, dim3(prep->E), dim3(256), 0, st, *prep); BF_CHECK_LAUNCH(); }
+        return 0;
+    }
     Cast4 j;
     for (int i = 0; i < 4; ++i) { j.src[i] = src[i < cnt ? i : 0]; j.dst[i] = (bf16*)dst[i < cnt ? i : 0]; j.n[i] = i < cnt ? n[i] : 0; out[i < cnt ? i : 0] = dst[i < cnt ? i : 0]; }
     for (int i = 0; i < cnt; ++i) out[i] = dst[i];
-    hipLaunchKernelGGL(cast4_kernel, dim3(64, cnt), dim3(256), 0, st, j);
+    if (prep) hipLaunchKernelGGL(stage_prep_kernel, dim3(std::max(64, prep->E), cnt + 1), dim3(256), 0, st, j, cnt, *prep);
+    else hipLaunchKernelGGL(cast4_kernel, dim3(64, cnt), dim3(256), 0, st, j);
     BF_CHECK_LAUNCH();
     return 0;
 }
@@ -247,7 +271,7 @@ int wview(const D& d, int mode, const float* src, void* dst, int R, int K, int K
 
 // ------------------------------------------------------------------------------------------------ saved-record layouts
 struct TemporalSaved {
-    float *mean1, *rstd1, *sc1, *sh1, *mean2, *rstd2, *sc2, *sh2, *alpha, *beta, *mc, *mtab;
+    float *mean1, *rstd1, *sc1, *sh1, *mean2, *rstd2, *sc2, *sh2, *alpha, *beta, *mc;
     void *qkv, *o, *win_c, *wout_c;
     size_t bytes;
     TemporalSaved(const D& d, void* base) {
@@ -255,7 +279,7 @@ struct TemporalSaved {
         const size_t fe = (size_t)d.F * d.E;
         mean1 = a.f32(fe); rstd1 = a.f32(fe); sc1 = a.f32(fe); sh1 = a.f32(fe);
         mean2 = a.f32(fe); rstd2 = a.f32(fe); sc2 = a.f32(fe); sh2 = a.f32(fe);
-        alpha = a.f32(d.E); beta = a.f32(d.E); mc = a.f32(d.E); mtab = a.f32(fe);
+        alpha = a.f32(d.E); beta = a.f32(d.E); mc = a.f32(d.E);
         qkv = a.take((size_t)d.N * 3 * d.E * d.es);
         o = a.take((size_t)d.N * d.E * d.es);
         win_c = a.take((size_t)3 * d.E * d.E * d.es);
@@ -264,7 +288,7 @@ struct TemporalSaved {
     }
 };
 struct SpatialSaved {
-    float *mean1, *rstd1, *sc1, *sh1, *mean2, *rstd2, *sc2, *sh2, *mean3, *rstd3, *sc3, *sh3, *alpha, *beta, *mc, *mtab, *gtab;
+    float *mean1, *rstd1, *sc1, *sh1, *mean2, *rstd2, *sc2, *sh2, *mean3, *rstd3, *sc3, *sh3, *alpha, *beta, *mc, *gtab;
     void *qkv, *o, *x1, *pre, *hid, *z, *win_c, *wout_c, *w1_c, *w2_c;
     size_t bytes;
     SpatialSaved(const D& d, void* base) {
@@ -273,7 +297,7 @@ struct SpatialSaved {
         mean1 = a.f32(fe); rstd1 = a.f32(fe); sc1 = a.f32(fe); sh1 = a.f32(fe);
         mean2 = a.f32(fe); rstd2 = a.f32(fe); sc2 = a.f32(fe); sh2 = a.f32(fe);
         mean3 = a.f32(fe); rstd3 = a.f32(fe); sc3 = a.f32(fe); sh3 = a.f32(fe);
-        alpha = a.f32(d.E); beta = a.f32(d.E); mc = a.f32(d.E); mtab = a.f32(fe); gtab = a.f32(fe);
+        alpha = a.f32(d.E); beta = a.f32(d.E); mc = a.f32(d.E); gtab = a.f32(fe);
         qkv = a.take((size_t)d.N * 3 * d.E * d.es);
         o = a.take((size_t)d.N * d.E * d.es);
         x1 = a.take((size_t)d.N * d.E * d.es);
@@ -437,7 +461,8 @@ extern "C" int bf_temporal_fwd(const bf_dims* dims, const bf_temporal_params* p,
         void* dst[2] = {sv.win_c, sv.wout_c};
         const long n[2] = {3L * d.E * d.E, (long)d.E * d.E};
         const void* out[4];
-        TRY(wviews(d, 2, src, dst, n, out, st));
+        const PrepArgs prep{p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr, sv.alpha, sv.beta, sv.mc, d.E};
+        TRY(wviews(d, 2, src, dst, n, out, st, &prep));
         win_c = out[0]; wout_c = out[1];
     }
     TRY(bf_in_stats(d.dtype, x, (int)d.F, (int)d.S, d.E, p->norm1_w, p->norm1_b, nullptr, 1, nullptr, sv.mean1, sv.rstd1, sv.sc1, sv.sh1, sc.in_ws, st));
@@ -446,9 +471,6 @@ extern "C" int bf_temporal_fwd(const bf_dims* dims, const bf_temporal_params* p,
     TRY(bf_attn_fwd(d.dtype, sv.qkv, sv.o, (long)d.B * d.S, d.T, d.S, (long)d.T * d.S, 1, d.S, d.heads, d.d, p->qnorm_w, p->qnorm_b,
                     p->knorm_w, p->knorm_b, p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor : nullptr, 1.f, 0, st));
     TRY(bf_in_stats(d.dtype, sv.o, (int)d.F, (int)d.S, d.E, p->norm2_w, p->norm2_b, nullptr, 1, nullptr, sv.mean2, sv.rstd2, sv.sc2, sv.sh2, sc.in_ws, st));
-    hipLaunchKernelGGL(outproj_prep_kernel, dim3(d.E), dim3(256), 0, st, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma,
-                       (const float*)nullptr, (const float*)nullptr, sv.alpha, sv.beta, sv.mc, d.E);
-    BF_CHECK_LAUNCH();
     TRY(outproj_gemm(d, sv.o, sv.sc2, sv.sh2, wout_c, sv.alpha, sv.beta, x, out, drop, (long)d.T * d.S, st));   // mask per batch element
     return 0;
 }
@@ -468,9 +490,7 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
     void* dqkv = sc.t3;     // [N][3E]
     const void* dbr = dout; // gradient entering the attention branch
     if (drop) {             // branch = drop[b] * (...): scale the incoming gradient once (2U pass), the rest is unchanged
-        hipLaunchKernelGGL(frame_table_kernel, dim3(bf_cdiv(d.F * d.E, 256)), dim3(256), 0, st, drop, d.T, (const float*)nullptr, sv.mtab, (int)d.F, d.E);
-        BF_CHECK_LAUNCH();
-        TRY(bf_affine_apply(d.dtype, dout, nullptr, sv.mtab, nullptr, sc.t4, d.N, (int)d.S, d.E, st));
+        TRY(bf_frame_scale(d.dtype, dout, drop, d.T, sc.t4, d.N, (int)d.S, d.E, st));
         dbr = sc.t4;
     }
     TRY(outproj_bwd(d, sc, dbr, sv.o, sv.sc2, sv.sh2, wout_c, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr,
@@ -501,7 +521,9 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
         void* dst[4] = {sv.win_c, sv.wout_c, sv.w1_c, sv.w2_c};
         const long n[4] = {3L * d.E * d.E, (long)d.E * d.E, 4L * d.E * d.E, 4L * d.E * d.E};
         const void* out[4];
-        TRY(wviews(d, 4, src, dst, n, out, st));
+        const PrepArgs prep{p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att, d.feat_scale ? p->low_freq_scalar : nullptr,
+                            d.feat_scale ? p->high_freq_scalar : nullptr, sv.alpha, sv.beta, sv.mc, d.E};
+        TRY(wviews(d, 4, src, dst, n, out, st, &prep));
         win_c = out[0]; wout_c = out[1]; w1_c = out[2]; w2_c = out[3];
     }
     TRY(bf_in_stats(d.dtype, x, (int)d.F, (int)d.S, d.E, p->norm1_w, p->norm1_b, nullptr, 1, nullptr, sv.mean1, sv.rstd1, sv.sc1, sv.sh1, sc.in_ws, st));
@@ -513,9 +535,6 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
     TRY(bf_attn_fwd(d.dtype, sv.qkv, sv.o, d.F * d.w, d.h, d.w, d.S, 1, d.w, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
                     p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_y : nullptr, 0.5f, 1, st));
     TRY(bf_in_stats(d.dtype, sv.o, (int)d.F, (int)d.S, d.E, p->norm2_w, p->norm2_b, nullptr, 1, nullptr, sv.mean2, sv.rstd2, sv.sc2, sv.sh2, sc.in_ws, st));
-    hipLaunchKernelGGL(outproj_prep_kernel, dim3(d.E), dim3(256), 0, st, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att,
-                       d.feat_scale ? p->low_freq_scalar : nullptr, d.feat_scale ? p->high_freq_scalar : nullptr, sv.alpha, sv.beta, sv.mc, d.E);
-    BF_CHECK_LAUNCH();
     TRY(outproj_gemm(d, sv.o, sv.sc2, sv.sh2, wout_c, sv.alpha, sv.beta, x, sv.x1, drop_att, d.S, st));     // mask per frame
     {   // pre = x1 @ W1^T + b1 ; hid = gelu(pre) (both kept: pre for gelu', hid as the fc2 operand -- no erf in any prologue)
         bf_operand A = op_plain(sv.x1, d.E, BF_LAY_KC);
@@ -590,9 +609,7 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     void* don = sc.e6;
     const void* dbr = dx1;  // gradient entering the attention branch (dx1 itself continues down the residual)
     if (drop_att) {
-        hipLaunchKernelGGL(frame_table_kernel, dim3(bf_cdiv(d.F * d.E, 256)), dim3(256), 0, st, drop_att, 1, (const float*)nullptr, sv.mtab, (int)d.F, d.E);
-        BF_CHECK_LAUNCH();
-        TRY(bf_affine_apply(d.dtype, dx1, nullptr, sv.mtab, nullptr, sc.e5, d.N, (int)d.S, d.E, st));
+        TRY(bf_frame_scale(d.dtype, dx1, drop_att, 1, sc.e5, d.N, (int)d.S, d.E, st));
         dbr = sc.e5;
     }
     TRY(outproj_bwd(d, sc, dbr, sv.o, sv.sc2, sv.sh2, wout_c, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att,

@@ -239,6 +239,24 @@ __global__ void __launch_bounds__(NT) affine_apply_kernel(const T* __restrict__ 
     }
 }
 
+// out = z * m[(row / S) / fdiv]: one scalar per frame group (the stochastic-depth factor of a branch gradient)
+template <typename T>
+__global__ void __launch_bounds__(NT) frame_scale_kernel(const T* __restrict__ z, const float* __restrict__ m, int fdiv, T* __restrict__ out,
+                                                        long nrows, int S, int C) {
+    constexpr int CH = Chunk<T>::N;
+    const int cpr = C / CH;
+    const long total = nrows * cpr;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const long row = i / cpr;
+        const float f = m[(row / S) / fdiv];
+        Chunk<T> v, o;
+        v.load(z + i * CH);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) o.set(j, v.get(j) * f);
+        o.store(out + i * CH);
+    }
+}
+
 // ------------------------------------------------------------------------------------ backward
 // y = act( xhat * w + b ) [* g],  xhat = (x - mean) * rstd, act = identity | GELU.
 // Given dy: s1 = sum_s dyn, s2 = sum_s dyn * xhat  (dyn = dy * act'),  per (frame, channel)
@@ -562,6 +580,19 @@ extern "C" int bf_affine_apply(int dtype, const void* z, const void* resid, cons
         hipLaunchKernelGGL(affine_apply_kernel<bf16>, dim3(grid), dim3(NT), 0, (hipStream_t)stream, (const bf16*)z, (const bf16*)resid, sc, sh, (bf16*)out, (long)nrows, S, C);
     else
         hipLaunchKernelGGL(affine_apply_kernel<float>, dim3(grid), dim3(NT), 0, (hipStream_t)stream, (const float*)z, (const float*)resid, sc, sh, (float*)out, (long)nrows, S, C);
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
+int bf_frame_scale(int dtype, const void* z, const float* m, int fdiv, void* out, long nrows, int S, int C, hipStream_t st) {
+    BF_REQUIRE(z && m && out && nrows > 0 && S > 0 && fdiv > 0, "bf_frame_scale: bad arguments");
+    const int ch = dtype == BF_DTYPE_BF16 ? 8 : 4;
+    BF_REQUIRE(C % ch == 0, "bf_frame_scale: C must be a multiple of the 16-byte chunk");
+    const long total = nrows * (C / ch);
+    BfProfScope prof(st, "frame_scale", 0.0, (double)nrows * C * bf_esize(dtype) * 2.0);
+    const int grid = (int)std::min<long>((total + NT - 1) / NT, 256 * 16);
+    if (dtype == BF_DTYPE_BF16) hipLaunchKernelGGL(frame_scale_kernel<bf16>, dim3(grid), dim3(NT), 0, st, (const bf16*)z, m, fdiv, (bf16*)out, nrows, S, C);
+    else hipLaunchKernelGGL(frame_scale_kernel<float>, dim3(grid), dim3(NT), 0, st, (const float*)z, m, fdiv, (float*)out, nrows, S, C);
     BF_CHECK_LAUNCH();
     return 0;
 }
