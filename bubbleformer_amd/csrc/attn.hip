@@ -364,7 +364,7 @@ int bf_attn_fwd_mfma(const void* qkv, void* out, long nseq, int L, long inner, l
 int bf_attn_bwd_mfma(const void* qkv, const void* dout, void* dqkv, long nseq, int L, long inner, long outer_stride, long inner_stride,
                      long tok_stride, int heads, int d, const float* qw, const float* qb, const float* kw, const float* kb, const float* emb,
                      const float* hscale, float* dqw, float* dqb, float* dkw, float* dkb, float* demb, float* dhscale, float out_scale,
-                     int accumulate, float* ws, long ws_floats, hipStream_t st);
+                     int accumulate, float* ws, long ws_floats, int* rows_out, hipStream_t st);
 static bool use_mfma(int dtype, int d) { return !g_force_generic && dtype == BF_DTYPE_BF16 && d % 32 == 0 && d <= 128; }
 
 extern "C" void bf_debug_force_generic_attn(int on) { g_force_generic = on != 0; }
@@ -396,17 +396,18 @@ extern "C" int bf_attn_fwd(int dtype, const void* qkv, void* out, int64_t nseq, 
     return 0;
 }
 
-extern "C" int bf_attn_bwd(int dtype, const void* qkv, const void* dout, void* dqkv, int64_t nseq, int L, int64_t inner,
-                           int64_t outer_stride, int64_t inner_stride, int64_t tok_stride, int heads, int d, const float* qw,
-                           const float* qb, const float* kw, const float* kb, const float* emb, const float* hscale,
-                           float* dqw, float* dqb, float* dkw, float* dkb, float* demb, float* dhscale, float out_scale,
-                           int accumulate, float* ws, int64_t ws_floats, bf_stream_t stream) {
+static int attn_bwd_impl(int dtype, const void* qkv, const void* dout, void* dqkv, int64_t nseq, int L, int64_t inner,
+                         int64_t outer_stride, int64_t inner_stride, int64_t tok_stride, int heads, int d, const float* qw,
+                         const float* qb, const float* kw, const float* kb, const float* emb, const float* hscale,
+                         float* dqw, float* dqb, float* dkw, float* dkb, float* demb, float* dhscale, float out_scale,
+                         int accumulate, float* ws, int64_t ws_floats, int* rows_out, bf_stream_t stream) {
+    if (rows_out) *rows_out = 0;
     BF_REQUIRE(qkv && dout && dqkv && qw && qb && kw && kb && nseq > 0 && inner > 0, "bf_attn_bwd: bad arguments");
     if (int rc = check_geo("bf_attn_bwd", dtype, heads, d, L)) return rc;
     if (use_mfma(dtype, d)) {
         BfProfScope prof((hipStream_t)stream, "attn_bwd", 10.0 * nseq * heads * L * L * d, (double)nseq * heads * L * d * 2.0 * (accumulate ? 10.0 : 7.0));
         return bf_attn_bwd_mfma(qkv, dout, dqkv, nseq, L, inner, outer_stride, inner_stride, tok_stride, heads, d, qw, qb, kw, kb, emb, hscale, dqw,
-                                dqb, dkw, dkb, demb, dhscale, out_scale, accumulate, ws, (long)ws_floats, (hipStream_t)stream);
+                                dqb, dkw, dkb, demb, dhscale, out_scale, accumulate, ws, (long)ws_floats, rows_out, (hipStream_t)stream);
     }
     SeqGeo g{nseq, L, inner, outer_stride, inner_stride, tok_stride};
     AttnParams p{qw, qb, kw, kb, emb, hscale};
@@ -423,4 +424,22 @@ extern "C" int bf_attn_bwd(int dtype, const void* qkv, const void* dout, void* d
         hipLaunchKernelGGL(attn_bwd_kernel<float>, dim3(grid), dim3(WPB * 64), shm, (hipStream_t)stream, (const float*)qkv, (const float*)dout, (float*)dqkv, g, heads, d, p, gr, out_scale, accumulate);
     BF_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int bf_attn_bwd(int dtype, const void* qkv, const void* dout, void* dqkv, int64_t nseq, int L, int64_t inner,
+                           int64_t outer_stride, int64_t inner_stride, int64_t tok_stride, int heads, int d, const float* qw,
+                           const float* qb, const float* kw, const float* kb, const float* emb, const float* hscale,
+                           float* dqw, float* dqb, float* dkw, float* dkb, float* demb, float* dhscale, float out_scale,
+                           int accumulate, float* ws, int64_t ws_floats, bf_stream_t stream) {
+    return attn_bwd_impl(dtype, qkv, dout, dqkv, nseq, L, inner, outer_stride, inner_stride, tok_stride, heads, d, qw, qb, kw, kb, emb, hscale, dqw,
+                         dqb, dkw, dkb, demb, dhscale, out_scale, accumulate, ws, ws_floats, nullptr, stream);
+}
+// Same, but the parameter-gradient rows the MFMA kernel leaves in ws are NOT reduced: *rows = number of rows for a later
+// AttnReduceJob (0 when the kernel accumulated the parameter gradients itself: fp32 / generic path, or no workspace).
+int bf_attn_bwd_partials(int dtype, const void* qkv, const void* dout, void* dqkv, int64_t nseq, int L, int64_t inner, int64_t outer_stride,
+                         int64_t inner_stride, int64_t tok_stride, int heads, int d, const float* qw, const float* qb, const float* kw,
+                         const float* kb, const float* emb, const float* hscale, float* dqw, float* dqb, float* dkw, float* dkb, float* demb,
+                         float* dhscale, float out_scale, int accumulate, float* ws, int64_t ws_floats, int* rows, hipStream_t stream) {
+    return attn_bwd_impl(dtype, qkv, dout, dqkv, nseq, L, inner, outer_stride, inner_stride, tok_stride, heads, d, qw, qb, kw, kb, emb, hscale, dqw,
+                         dqb, dkw, dkb, demb, dhscale, out_scale, accumulate, ws, ws_floats, rows, (bf_stream_t)stream);
 }

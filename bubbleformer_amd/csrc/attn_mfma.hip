@@ -15,6 +15,7 @@
 //     dV^T[e][j]  = sum_i dO[i][e] A[i][j]          A = dO^T (tr read), B = A^T through the same transpose
 // and finishes LayerNorm backward in the operand layout after one LDS re-layout (16-byte global stores).
 #include "bf_common.h"
+#include "param_reduce.h"
 #include <stdlib.h>
 
 namespace {
@@ -689,25 +690,10 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
     }
 }
 
-// dst += sum over workspace rows.  grid (ceil(nvals / 64), row slices); 4 row groups per block; a handful of atomics per value.
-__global__ void __launch_bounds__(256) attn_ws_reduce(const float* __restrict__ ws, int rows, int D, int heads, Grd gr) {
-    __shared__ float red[4][64];
-    const int nvals = 4 * D + 32 * heads + heads;
-    const int i = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
-    const int per = (rows + gridDim.y - 1) / gridDim.y;
-    const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
-    float acc = 0.f;
-    if (i < nvals)
-        for (int r = r0 + rg; r < r1; r += 4) acc += ws[(long)r * nvals + i];
-    red[rg][threadIdx.x & 63] = acc;
-    __syncthreads();
-    if (rg != 0 || i >= nvals) return;
-    acc = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    float* dst;
-    if (i < 4 * D) { const int q = i / D, e = i % D; dst = (q == 0 ? gr.dqw : q == 1 ? gr.dqb : q == 2 ? gr.dkw : gr.dkb); if (dst) dst += e; }
-    else if (i < 4 * D + 32 * heads) dst = gr.demb ? gr.demb + (i - 4 * D) : nullptr;
-    else dst = gr.dhscale ? gr.dhscale + (i - 4 * D - 32 * heads) : nullptr;
-    if (dst && acc != 0.f) atomicAdd(dst, acc);
+// dst += sum over workspace rows (param_reduce.h)
+__global__ void __launch_bounds__(256) attn_ws_reduce(AttnReduceJob j) {
+    __shared__ float red[1][4][64];
+    attn_reduce_block(j, blockIdx.x, blockIdx.y, gridDim.y, red);
 }
 
 template <typename K>
@@ -734,7 +720,7 @@ int go_fwd(const bf16* qkv, bf16* out, Geo g, int heads, Par p, float out_scale,
 }
 template <int NB, int KS>
 int go_bwd(const bf16* qkv, const bf16* dout, bf16* dqkv, Geo g, int heads, Par p, Grd gr, float out_scale, int accumulate, float* ws,
-           long ws_floats, hipStream_t st) {
+           long ws_floats, int* rows_out, hipStream_t st) {
     constexpr int D = 32 * KS, R = 16 * NB;
     const int wpb = NB == 1 ? 4 : 2;
     const size_t shm = (size_t)wpb * (3 * R * (D + 16) + 2 * R * 40) * sizeof(bf16);
@@ -762,8 +748,10 @@ int go_bwd(const bf16* qkv, const bf16* dout, bf16* dqkv, Geo g, int heads, Par 
     if (ws && ws_floats < grid * nvals) { grid = ws_floats / nvals; if (grid < 1) ws = nullptr; }
     hipLaunchKernelGGL((attn_bwd_mfma<NB, KS>), dim3((int)grid), dim3(wpb * 64), shm, st, qkv, dout, dqkv, g, heads, p, gr, out_scale, accumulate, ws);
     BF_CHECK_LAUNCH();
+    if (rows_out) { *rows_out = ws ? (int)grid : 0; return 0; }       // the caller reduces the workspace rows later (AttnReduceJob)
     if (ws) {
-        hipLaunchKernelGGL(attn_ws_reduce, dim3(bf_cdiv(nvals, 64), 16), dim3(256), 0, st, (const float*)ws, (int)grid, D, heads, gr);
+        const AttnReduceJob j{ws, (int)grid, D, heads, gr.dqw, gr.dqb, gr.dkw, gr.dkb, gr.demb, gr.dhscale};
+        hipLaunchKernelGGL(attn_ws_reduce, dim3(bf_cdiv(nvals, 64), 16), dim3(256), 0, st, j);
         BF_CHECK_LAUNCH();
     }
     return 0;
@@ -786,12 +774,12 @@ int bf_attn_fwd_mfma(const void* qkv, void* out, long nseq, int L, long inner, l
 int bf_attn_bwd_mfma(const void* qkv, const void* dout, void* dqkv, long nseq, int L, long inner, long outer_stride, long inner_stride,
                      long tok_stride, int heads, int d, const float* qw, const float* qb, const float* kw, const float* kb, const float* emb,
                      const float* hscale, float* dqw, float* dqb, float* dkw, float* dkb, float* demb, float* dhscale, float out_scale,
-                     int accumulate, float* ws, long ws_floats, hipStream_t st) {
+                     int accumulate, float* ws, long ws_floats, int* rows_out, hipStream_t st) {
     Geo g{nseq, L, inner, outer_stride, inner_stride, tok_stride};
     Par p{qw, qb, kw, kb, emb, hscale};
     Grd gr{dqw, dqb, dkw, dkb, demb, dhscale};
     const int nb = L <= 16 ? 1 : 2, ks = d / 32;
-#define GO(NB, KS) if (nb == NB && ks == KS) return go_bwd<NB, KS>((const bf16*)qkv, (const bf16*)dout, (bf16*)dqkv, g, heads, p, gr, out_scale, accumulate, ws, ws_floats, st)
+#define GO(NB, KS) if (nb == NB && ks == KS) return go_bwd<NB, KS>((const bf16*)qkv, (const bf16*)dout, (bf16*)dqkv, g, heads, p, gr, out_scale, accumulate, ws, ws_floats, rows_out, st)
     GO(1, 1); GO(1, 2); GO(1, 3); GO(1, 4); GO(2, 1); GO(2, 2); GO(2, 3); GO(2, 4);
 #undef GO
     return bf_fail_msg("bf_attn_bwd_mfma: unsupported shape", __FILE__, __LINE__);

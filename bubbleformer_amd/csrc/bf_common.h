@@ -38,6 +38,13 @@ struct BfProfScope {
     ~BfProfScope() { if (idx >= 0) bf_prof_end(idx, st, name, flops, bytes); }
 };
 
+// internal halves of bf_in_bwd / bf_attn_bwd: everything but the parameter-gradient reduction of the workspace (param_reduce.h)
+int bf_in_bwd_partials(int dtype, const void* dy, const void* x, const void* add, void* dx, int frames, int S, int C, const float* mean,
+                       const float* rstd, const float* w, const float* b, const float* g, int gdiv, int gelu, float* ws, hipStream_t stream);
+int bf_attn_bwd_partials(int dtype, const void* qkv, const void* dout, void* dqkv, int64_t nseq, int L, int64_t inner, int64_t outer_stride,
+                         int64_t inner_stride, int64_t tok_stride, int heads, int d, const float* qw, const float* qb, const float* kw,
+                         const float* kb, const float* emb, const float* hscale, float* dqw, float* dqb, float* dkw, float* dkb, float* demb,
+                         float* dhscale, float out_scale, int accumulate, float* ws, int64_t ws_floats, int* rows, hipStream_t stream);
 // out = z * m[(row / S) / fdiv] (norm.hip; internal)
 int bf_frame_scale(int dtype, const void* z, const float* m, int fdiv, void* out, long nrows, int S, int C, hipStream_t st);
 

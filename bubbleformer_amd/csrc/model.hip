@@ -13,6 +13,7 @@
 //  * parameter gradients of those folds come from G = dout^T @ on (one split-K GEMM) instead of a saved y:
 //       dW = alpha * G (+ dmc x norm2.bias), dalpha[n] = <W[n, :], G[n, :]>, dbeta = colsum(dout).
 #include "bf_common.h"
+#include "param_reduce.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -196,25 +197,12 @@ __global__ void outproj_finalize_kernel(const float* __restrict__ G, const float
         dW[(long)n * E + k] += v;
     }
 }
-// stochastic-depth helpers: out[f][c] = m[f / fdiv] * (v ? v[c] : 1);   dv[c] += sum_f m[f / fdiv] * t[f][c]
+// stochastic-depth helper: out[f][c] = m[f / fdiv] * (v ? v[c] : 1)
 __global__ void frame_table_kernel(const float* __restrict__ m, int fdiv, const float* __restrict__ v, float* __restrict__ out, int F, int C) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)F * C) return;
     const int f = (int)(i / C), c = (int)(i % C);
     out[i] = m[f / fdiv] * (v ? v[c] : 1.f);
-}
-// grid (ceil(C/64), ceil(F/16)), 256 threads = 64 channels x 4 frame lanes; a few atomics per address
-__global__ void __launch_bounds__(256) frame_wcolsum_kernel(const float* __restrict__ t, const float* __restrict__ m, int fdiv, float* __restrict__ dv, int F, int C) {
-    __shared__ float red[4][64];
-    const int l = threadIdx.x & 63, fl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + l;
-    const int f1 = min(F, ((int)blockIdx.y + 1) * 16);
-    float acc = 0.f;
-    if (c < C)
-        for (int f = blockIdx.y * 16 + fl; f < f1; f += 4) acc += m[f / fdiv] * t[(long)f * C + c];
-    red[fl][l] = acc;
-    __syncthreads();
-    if (fl == 0 && c < C) atomicAdd(dv + c, red[0][l] + red[1][l] + red[2][l] + red[3][l]);
 }
 __global__ void fill_kernel(float* p, float v, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
 
@@ -314,7 +302,7 @@ struct SpatialSaved {
 
 // transient scratch (backward is the larger user)
 struct Scratch {
-    float *G, *csum, *zeros, *ones, *wg, *attn_ws, *in_ws, *dgtab;   // wg: prepared-layout weight gradient scratch
+    float *G, *csum, *zeros, *ones, *wg, *attn_ws, *attn_ws2, *in_ws, *in_ws2, *in_ws3;   // wg: prepared-layout weight gradient scratch
     static constexpr long ATTN_WS_FLOATS = 1024L * (4 * 128 + 32 * 16 + 16);
     void *t1, *t3, *t4, *t1b;
     void *s1, *e5, *e6, *e7;     // [N][E] each: s1 feeds side-stream GEMMs only; e5..e7 keep side-stream inputs from being recycled within a stage
@@ -331,13 +319,16 @@ struct Scratch {
         ones = a.f32((size_t)4 * d.E);
         wg = a.f32(wgn);
         attn_ws = a.f32(ATTN_WS_FLOATS);
+        attn_ws2 = a.f32(ATTN_WS_FLOATS);       // second axial pass: both passes' rows are reduced together at the end of the stage
         {   // InstanceNorm workspace: the trunk (S tokens x E) and every embed / debed resolution (S * 4^i tokens x E/4)
             int64_t n = bf_in_ws_floats(d.dtype, (int)d.F, (int)d.S, d.E);
             long Si = d.S;
             for (int i = 1; i < d.nst; ++i) { Si *= 4; n = std::max(n, bf_in_ws_floats(d.dtype, (int)d.F, (int)Si, cm)); }
             in_ws = a.f32((size_t)n);
+            // one partials region per InstanceNorm of a block: their reductions run together at the end of the stage
+            const size_t nt = (size_t)bf_in_ws_floats(d.dtype, (int)d.F, (int)d.S, d.E);
+            in_ws2 = a.f32(nt); in_ws3 = a.f32(nt);
         }
-        dgtab = a.f32((size_t)d.F * d.E);
         // activation-sized transients; embed/debed stages work at up to (patch/2)^2 * N pixels of E/4 (or cin/cout) channels
         size_t tok = (size_t)d.N * d.E;
         size_t big = tok * 4;
@@ -354,6 +345,35 @@ struct Scratch {
         bytes = a.off;
     }
 };
+
+// ------------------------------------------------------------------------------------------------ stage-end parameter reductions
+// All InstanceNorm / attention parameter-gradient reductions of one stage backward in ONE launch (grid z = job): nothing on the
+// critical path reads them, and eight dependent ~5 us launches per block are worth ~3 % of the step.
+struct ReduceJobs { int n_in = 0, n_attn = 0; InReduceJob in[3]; AttnReduceJob at[2]; };
+__global__ void __launch_bounds__(256) stage_param_reduce_kernel(ReduceJobs J) {
+    __shared__ float red[5][4][64];
+    const int z = blockIdx.z;
+    if (z < J.n_in) {
+        const InReduceJob& j = J.in[z];
+        if ((int)blockIdx.x < (j.C + 63) / 64 && (int)blockIdx.y < (j.frames + j.rdiv() - 1) / j.rdiv()) in_reduce_block(j, blockIdx.x, blockIdx.y, red);
+    } else {
+        const AttnReduceJob& j = J.at[z - J.n_in];
+        const int nvals = 4 * j.D + 32 * j.heads + j.heads;
+        if ((int)blockIdx.x < (nvals + 63) / 64 && blockIdx.y < 16) attn_reduce_block(j, blockIdx.x, blockIdx.y, 16, red);
+    }
+}
+int launch_reduce_jobs(ReduceJobs& J, hipStream_t st) {
+    int k = 0;                                   // drop attention jobs without rows (fp32 / generic path accumulated directly)
+    for (int i = 0; i < J.n_attn; ++i) if (J.at[i].rows > 0) J.at[k++] = J.at[i];
+    J.n_attn = k;
+    if (J.n_in + J.n_attn == 0) return 0;
+    int gx = 1, gy = 1;
+    for (int i = 0; i < J.n_in; ++i) { gx = std::max(gx, bf_cdiv(J.in[i].C, 64)); gy = std::max(gy, bf_cdiv(J.in[i].frames, J.in[i].rdiv())); }
+    for (int i = 0; i < J.n_attn; ++i) { gx = std::max(gx, bf_cdiv(4 * J.at[i].D + 33 * J.at[i].heads, 64)); gy = std::max(gy, 16); }
+    hipLaunchKernelGGL(stage_param_reduce_kernel, dim3(gx, gy, J.n_in + J.n_attn), dim3(256), 0, st, J);
+    BF_CHECK_LAUNCH();
+    return 0;
+}
 
 int launch_fill(float* p, float v, int n, hipStream_t st) {
     hipLaunchKernelGGL(fill_kernel, dim3(bf_cdiv(n, 256)), dim3(256), 0, st, p, v, n);
@@ -495,15 +515,23 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
     }
     TRY(outproj_bwd(d, sc, dbr, sv.o, sv.sc2, sv.sh2, wout_c, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr,
                     sv.alpha, sv.mc, g->output_head_w, g->output_head_b, nullptr, g->gamma, nullptr, nullptr, don, st, fk));
-    TRY(bf_in_bwd(d.dtype, don, sv.o, nullptr, dO, (int)d.F, (int)d.S, d.E, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, nullptr, 1, 0,
-                  g->norm2_w, g->norm2_b, nullptr, nullptr, sc.in_ws, st));
-    TRY(bf_attn_bwd(d.dtype, sv.qkv, dO, dqkv, (long)d.B * d.S, d.T, d.S, (long)d.T * d.S, 1, d.S, d.heads, d.d, p->qnorm_w, p->qnorm_b,
-                    p->knorm_w, p->knorm_b, p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor : nullptr, g->qnorm_w, g->qnorm_b,
-                    g->knorm_w, g->knorm_b, g->rel_pos_emb, d.attn_scale ? g->attn_scale_factor : nullptr, 1.f, 0, sc.attn_ws, Scratch::ATTN_WS_FLOATS, st));
+    ReduceJobs jobs;        // parameter-gradient reductions, all launched together at the end
+    TRY(bf_in_bwd_partials(d.dtype, don, sv.o, nullptr, dO, (int)d.F, (int)d.S, d.E, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, nullptr, 1, 0, sc.in_ws2, st));
+    jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws2, (int)d.F, d.E, p->norm2_w, p->norm2_b, nullptr, 1, g->norm2_w, g->norm2_b, nullptr, nullptr, nullptr, nullptr};
+    {
+        int rows = 0;
+        TRY(bf_attn_bwd_partials(d.dtype, sv.qkv, dO, dqkv, (long)d.B * d.S, d.T, d.S, (long)d.T * d.S, 1, d.S, d.heads, d.d, p->qnorm_w, p->qnorm_b,
+                                 p->knorm_w, p->knorm_b, p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor : nullptr, g->qnorm_w, g->qnorm_b,
+                                 g->knorm_w, g->knorm_b, g->rel_pos_emb, d.attn_scale ? g->attn_scale_factor : nullptr, 1.f, 0, sc.attn_ws,
+                                 Scratch::ATTN_WS_FLOATS, &rows, st));
+        jobs.at[jobs.n_attn++] = AttnReduceJob{sc.attn_ws, rows, d.d, d.heads, g->qnorm_w, g->qnorm_b, g->knorm_w, g->knorm_b, g->rel_pos_emb,
+                                               d.attn_scale ? g->attn_scale_factor : nullptr};
+    }
     void* dxn = sc.t1;      // don is dead
     TRY(linear_bwd(d, sc, dqkv, 3 * d.E, x, d.E, BF_PRO_AFFINE, sv.sc1, sv.sh1, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk));
-    TRY(bf_in_bwd(d.dtype, dxn, x, dout, dx, (int)d.F, (int)d.S, d.E, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, nullptr, 1, 0,
-                  g->norm1_w, g->norm1_b, nullptr, nullptr, sc.in_ws, st));
+    TRY(bf_in_bwd_partials(d.dtype, dxn, x, dout, dx, (int)d.F, (int)d.S, d.E, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, nullptr, 1, 0, sc.in_ws, st));
+    jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws, (int)d.F, d.E, p->norm1_w, p->norm1_b, nullptr, 1, g->norm1_w, g->norm1_b, nullptr, nullptr, nullptr, nullptr};
+    TRY(launch_reduce_jobs(jobs, st));
     return fk.join();
 }
 
@@ -582,15 +610,17 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     Fork fk(st);
     // out = x1 + gamma_mlp * IN(z)
     void* dz = sc.t1;
-    if (drop_mlp) {   // gtab[f][c] = drop_mlp[f] * gamma_mlp[c] was the scale: its gradient comes back per frame, then d gamma = sum_f drop * dgtab
-        ZERO(sc.dgtab, (size_t)d.F * d.E * 4);
-        TRY(bf_in_bwd(d.dtype, dout, sv.z, nullptr, dz, (int)d.F, (int)d.S, d.E, sv.mean3, sv.rstd3, p->mlp_norm_w, p->mlp_norm_b, sv.gtab, 1, 0,
-                      g->mlp_norm_w, g->mlp_norm_b, sc.dgtab, nullptr, sc.in_ws, st));
-        hipLaunchKernelGGL(frame_wcolsum_kernel, dim3(bf_cdiv(d.E, 64), bf_cdiv(d.F, 16)), dim3(256), 0, st, (const float*)sc.dgtab, drop_mlp, 1, g->gamma_mlp, (int)d.F, d.E);
-        BF_CHECK_LAUNCH();
-    } else
-    TRY(bf_in_bwd(d.dtype, dout, sv.z, nullptr, dz, (int)d.F, (int)d.S, d.E, sv.mean3, sv.rstd3, p->mlp_norm_w, p->mlp_norm_b, p->gamma_mlp,
-                  (int)d.F, 0, g->mlp_norm_w, g->mlp_norm_b, g->gamma_mlp, nullptr, sc.in_ws, st));
+    ReduceJobs jobs;        // parameter-gradient reductions, all launched together at the end
+    if (drop_mlp) {   // gtab[f][c] = drop_mlp[f] * gamma_mlp[c] was the scale: d gamma_mlp = sum_f drop_mlp[f] * (w s2 + b s1), folded in the reduction
+        TRY(bf_in_bwd_partials(d.dtype, dout, sv.z, nullptr, dz, (int)d.F, (int)d.S, d.E, sv.mean3, sv.rstd3, p->mlp_norm_w, p->mlp_norm_b, sv.gtab, 1, 0, sc.in_ws3, st));
+        jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws3, (int)d.F, d.E, p->mlp_norm_w, p->mlp_norm_b, sv.gtab, 1, g->mlp_norm_w, g->mlp_norm_b, nullptr, nullptr,
+                                           drop_mlp, g->gamma_mlp};
+    } else {
+        TRY(bf_in_bwd_partials(d.dtype, dout, sv.z, nullptr, dz, (int)d.F, (int)d.S, d.E, sv.mean3, sv.rstd3, p->mlp_norm_w, p->mlp_norm_b, p->gamma_mlp,
+                               (int)d.F, 0, sc.in_ws3, st));
+        jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws3, (int)d.F, d.E, p->mlp_norm_w, p->mlp_norm_b, p->gamma_mlp, (int)d.F, g->mlp_norm_w, g->mlp_norm_b,
+                                           g->gamma_mlp, nullptr, nullptr, nullptr};
+    }
     // fc2: z = gelu(pre) @ W2^T + b2 ; dpre = (dz @ W2) * gelu'(pre)
     void* dpre = sc.t4;
     {
@@ -617,19 +647,27 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
                     g->output_head_w, g->output_head_b, g->norm2_b, g->gamma_att, d.feat_scale ? g->low_freq_scalar : nullptr,
                     d.feat_scale ? g->high_freq_scalar : nullptr, don, st, fk));
     void* dO = sc.e7;       // [N][E]
-    TRY(bf_in_bwd(d.dtype, don, sv.o, nullptr, dO, (int)d.F, (int)d.S, d.E, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, nullptr, 1, 0,
-                  g->norm2_w, g->norm2_b, nullptr, nullptr, sc.in_ws, st));
+    TRY(bf_in_bwd_partials(d.dtype, don, sv.o, nullptr, dO, (int)d.F, (int)d.S, d.E, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, nullptr, 1, 0, sc.in_ws2, st));
+    jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws2, (int)d.F, d.E, p->norm2_w, p->norm2_b, nullptr, 1, g->norm2_w, g->norm2_b, nullptr, nullptr, nullptr, nullptr};
     void* dqkv = sc.t3;
-    TRY(bf_attn_bwd(d.dtype, sv.qkv, dO, dqkv, d.F * d.h, d.w, 1, d.w, 0, 1, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
-                    p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_x : nullptr, g->qnorm_w, g->qnorm_b, g->knorm_w, g->knorm_b,
-                    g->rel_pos_emb, d.attn_scale ? g->attn_scale_factor_x : nullptr, 0.5f, 0, sc.attn_ws, Scratch::ATTN_WS_FLOATS, st));
-    TRY(bf_attn_bwd(d.dtype, sv.qkv, dO, dqkv, d.F * d.w, d.h, d.w, d.S, 1, d.w, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
-                    p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_y : nullptr, g->qnorm_w, g->qnorm_b, g->knorm_w, g->knorm_b,
-                    g->rel_pos_emb, d.attn_scale ? g->attn_scale_factor_y : nullptr, 0.5f, 1, sc.attn_ws, Scratch::ATTN_WS_FLOATS, st));
+    {
+        int rows = 0;
+        TRY(bf_attn_bwd_partials(d.dtype, sv.qkv, dO, dqkv, d.F * d.h, d.w, 1, d.w, 0, 1, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
+                                 p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_x : nullptr, g->qnorm_w, g->qnorm_b, g->knorm_w, g->knorm_b,
+                                 g->rel_pos_emb, d.attn_scale ? g->attn_scale_factor_x : nullptr, 0.5f, 0, sc.attn_ws, Scratch::ATTN_WS_FLOATS, &rows, st));
+        jobs.at[jobs.n_attn++] = AttnReduceJob{sc.attn_ws, rows, d.d, d.heads, g->qnorm_w, g->qnorm_b, g->knorm_w, g->knorm_b, g->rel_pos_emb,
+                                               d.attn_scale ? g->attn_scale_factor_x : nullptr};
+        TRY(bf_attn_bwd_partials(d.dtype, sv.qkv, dO, dqkv, d.F * d.w, d.h, d.w, d.S, 1, d.w, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
+                                 p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_y : nullptr, g->qnorm_w, g->qnorm_b, g->knorm_w, g->knorm_b,
+                                 g->rel_pos_emb, d.attn_scale ? g->attn_scale_factor_y : nullptr, 0.5f, 1, sc.attn_ws2, Scratch::ATTN_WS_FLOATS, &rows, st));
+        jobs.at[jobs.n_attn++] = AttnReduceJob{sc.attn_ws2, rows, d.d, d.heads, g->qnorm_w, g->qnorm_b, g->knorm_w, g->knorm_b, g->rel_pos_emb,
+                                               d.attn_scale ? g->attn_scale_factor_y : nullptr};
+    }
     void* dxn = sc.e6;      // don is dead (it was only read on this stream)
     TRY(linear_bwd(d, sc, dqkv, 3 * d.E, x, d.E, BF_PRO_AFFINE, sv.sc1, sv.sh1, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk));
-    TRY(bf_in_bwd(d.dtype, dxn, x, dx1, dx, (int)d.F, (int)d.S, d.E, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, nullptr, 1, 0,
-                  g->norm1_w, g->norm1_b, nullptr, nullptr, sc.in_ws, st));
+    TRY(bf_in_bwd_partials(d.dtype, dxn, x, dx1, dx, (int)d.F, (int)d.S, d.E, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, nullptr, 1, 0, sc.in_ws, st));
+    jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws, (int)d.F, d.E, p->norm1_w, p->norm1_b, nullptr, 1, g->norm1_w, g->norm1_b, nullptr, nullptr, nullptr, nullptr};
+    TRY(launch_reduce_jobs(jobs, st));
     return fk.join();
 }
 

@@ -3,6 +3,7 @@
 // All statistics and reductions are fp32 whatever the activation dtype; global access is in 16-byte
 // chunks (8 bf16 / 4 f32) so a 64-channel slab row is one 128-/256-byte coalesced segment.
 #include "bf_common.h"
+#include "param_reduce.h"
 
 namespace {
 
@@ -461,31 +462,10 @@ __global__ void __launch_bounds__(NT) in_slice_sum_kernel(const float* __restric
                                                                  red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l]);
 }
 
-// parameter gradients from the per-frame partials ws[f][c] = {s1, s2}.
-// grid (ceil(C/64), frame groups): one workgroup sums the frames of ONE frame group (gdiv frames; 256 threads = 64 channels x
-// 4 frame lanes) and adds its share to dw/db (a few atomics per address) and, if asked, stores dg/dgb of that group.
-__global__ void __launch_bounds__(NT) in_param_reduce_kernel(const float* __restrict__ ws, int frames, int C, const float* __restrict__ w,
-                                                            const float* __restrict__ b, const float* __restrict__ g, int gdiv,
-                                                            float* __restrict__ dw, float* __restrict__ db, float* __restrict__ dg,
-                                                            float* __restrict__ dgb) {
-    __shared__ float red[2][4][64];
-    const int l = threadIdx.x & 63, fl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + l, fg = blockIdx.y;
-    const bool cv = c < C;
-    const int f1 = min(frames, (fg + 1) * gdiv);
-    float s1 = 0.f, s2 = 0.f;
-    if (cv)
-        for (int f = fg * gdiv + fl; f < f1; f += 4) { s1 += ws[((long)f * C + c) * 2]; s2 += ws[((long)f * C + c) * 2 + 1]; }
-    red[0][fl][l] = s1; red[1][fl][l] = s2;
-    __syncthreads();
-    if (fl != 0 || !cv) return;
-    const float t1 = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
-    const float t2 = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
-    const float gg = g ? g[(long)fg * C + c] : 1.f;
-    if (dw) atomicAdd(dw + c, gg * t2);
-    if (db) atomicAdd(db + c, gg * t1);
-    if (dg) dg[(long)fg * C + c] += w[c] * t2 + b[c] * t1;
-    if (dgb) dgb[(long)fg * C + c] += t1;
+// parameter gradients from the per-frame partials ws[f][c] = {s1, s2}: see param_reduce.h
+__global__ void __launch_bounds__(NT) in_param_reduce_kernel(InReduceJob j) {
+    __shared__ float red[5][4][64];
+    in_reduce_block(j, blockIdx.x, blockIdx.y, red);
 }
 
 // ------------------------------------------------------------------------------------ column sums
@@ -597,9 +577,9 @@ int bf_frame_scale(int dtype, const void* z, const float* m, int fdiv, void* out
     return 0;
 }
 
-extern "C" int bf_in_bwd(int dtype, const void* dy, const void* x, const void* add, void* dx, int frames, int S, int C,
-                         const float* mean, const float* rstd, const float* w, const float* b, const float* g, int gdiv,
-                         int gelu, float* dw, float* db, float* dg, float* dgb, float* ws, bf_stream_t stream) {
+static int in_bwd_impl(int dtype, const void* dy, const void* x, const void* add, void* dx, int frames, int S, int C,
+                       const float* mean, const float* rstd, const float* w, const float* b, const float* g, int gdiv,
+                       int gelu, float* dw, float* db, float* dg, float* dgb, float* ws, bool reduce, bf_stream_t stream) {
     BF_REQUIRE(dy && x && dx && mean && rstd && w && b, "bf_in_bwd: null pointer");
     const int ch = dtype == BF_DTYPE_BF16 ? 8 : 4;
     BF_REQUIRE(C % ch == 0, "bf_in_bwd: C must be a multiple of the 16-byte chunk");
@@ -634,13 +614,24 @@ extern "C" int bf_in_bwd(int dtype, const void* dy, const void* x, const void* a
 #undef GO
     BF_CHECK_LAUNCH();
     }
-    if (ws) {
-        // no per-group scale / outputs: any grouping is valid -> 16 frames per workgroup keeps the grid wide
-        const int rdiv = (!g && !dg && !dgb) ? 16 : gdiv;
-        hipLaunchKernelGGL(in_param_reduce_kernel, dim3(bf_cdiv(C, 64), bf_cdiv(frames, rdiv)), dim3(NT), 0, st, (const float*)ws, frames, C, w, b, g, rdiv, dw, db, dg, dgb);
+    if (ws && reduce) {
+        const InReduceJob j{ws, frames, C, w, b, g, gdiv, dw, db, dg, dgb, nullptr, nullptr};
+        hipLaunchKernelGGL(in_param_reduce_kernel, dim3(bf_cdiv(C, 64), bf_cdiv(frames, j.rdiv())), dim3(NT), 0, st, j);
         BF_CHECK_LAUNCH();
     }
     return 0;
+}
+
+extern "C" int bf_in_bwd(int dtype, const void* dy, const void* x, const void* add, void* dx, int frames, int S, int C,
+                         const float* mean, const float* rstd, const float* w, const float* b, const float* g, int gdiv,
+                         int gelu, float* dw, float* db, float* dg, float* dgb, float* ws, bf_stream_t stream) {
+    return in_bwd_impl(dtype, dy, x, add, dx, frames, S, C, mean, rstd, w, b, g, gdiv, gelu, dw, db, dg, dgb, ws, true, stream);
+}
+// data gradient only: the per-frame partials stay in ws (required) for a later InReduceJob (model.hip runs a stage's jobs in one launch)
+int bf_in_bwd_partials(int dtype, const void* dy, const void* x, const void* add, void* dx, int frames, int S, int C, const float* mean,
+                       const float* rstd, const float* w, const float* b, const float* g, int gdiv, int gelu, float* ws, hipStream_t stream) {
+    BF_REQUIRE(ws, "bf_in_bwd_partials: workspace required");
+    return in_bwd_impl(dtype, dy, x, add, dx, frames, S, C, mean, rstd, w, b, g, gdiv, gelu, nullptr, nullptr, nullptr, nullptr, ws, false, (bf_stream_t)stream);
 }
 
 extern "C" int bf_colsum(int dtype, const void* x, int64_t nrows, int C, const float* scale, float* out, bf_stream_t stream) {
