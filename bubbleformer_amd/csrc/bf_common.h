@@ -45,6 +45,9 @@ int bf_attn_bwd_partials(int dtype, const void* qkv, const void* dout, void* dqk
                          int64_t inner_stride, int64_t tok_stride, int heads, int d, const float* qw, const float* qb, const float* kw,
                          const float* kb, const float* emb, const float* hscale, float* dqw, float* dqb, float* dkw, float* dkb, float* demb,
                          float* dhscale, float out_scale, int accumulate, float* ws, int64_t ws_floats, int* rows, hipStream_t stream);
+// InstanceNorm statistics of x fused with out = resid + x * sc + sh (norm.hip; internal)
+int bf_in_stats_apply(int dtype, const void* x, int frames, int S, int C, const float* w, const float* b, const float* g, int gdiv, const float* gb,
+                      float* mean, float* rstd, float* sc, float* sh, float* ws, const void* resid, void* out, hipStream_t stream);
 // out = z * m[(row / S) / fdiv] (norm.hip; internal)
 int bf_frame_scale(int dtype, const void* z, const float* m, int fdiv, void* out, long nrows, int S, int C, hipStream_t st);
 

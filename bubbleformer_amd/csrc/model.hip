@@ -587,9 +587,8 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
         BF_CHECK_LAUNCH();
         g3 = sv.gtab; g3div = 1;
     }
-    TRY(bf_in_stats(d.dtype, sv.z, (int)d.F, (int)d.S, d.E, p->mlp_norm_w, p->mlp_norm_b, g3, g3div, nullptr, sv.mean3, sv.rstd3,
-                    sv.sc3, sv.sh3, sc.in_ws, st));
-    TRY(bf_affine_apply(d.dtype, sv.z, sv.x1, sv.sc3, sv.sh3, out, d.N, (int)d.S, d.E, st));
+    TRY(bf_in_stats_apply(d.dtype, sv.z, (int)d.F, (int)d.S, d.E, p->mlp_norm_w, p->mlp_norm_b, g3, g3div, nullptr, sv.mean3, sv.rstd3,
+                          sv.sc3, sv.sh3, sc.in_ws, sv.x1, out, st));
     return 0;
 }
 

@@ -48,7 +48,8 @@ template <typename T, bool CACHED>
 __global__ void __launch_bounds__(NT) in_stats_kernel(const T* __restrict__ x, int S, int C, const float* __restrict__ w,
                                                      const float* __restrict__ b, const float* __restrict__ g, int gdiv,
                                                      const float* __restrict__ gb, float* __restrict__ mean,
-                                                     float* __restrict__ rstd, float* __restrict__ sc, float* __restrict__ sh) {
+                                                     float* __restrict__ rstd, float* __restrict__ sc, float* __restrict__ sh,
+                                                     const T* __restrict__ resid, T* __restrict__ out) {
     constexpr int CH = Chunk<T>::N, LC = Geo<T>::LC, RG = Geo<T>::RG;
     __shared__ float sm[NT * CH];
     const int f = blockIdx.x, c0 = blockIdx.y * CPB;
@@ -99,7 +100,8 @@ __global__ void __launch_bounds__(NT) in_stats_kernel(const T* __restrict__ x, i
         }
     }
     reduce_rows<T, 1>(acc, sm);
-    if (cv && rg == 0) {
+    float aa[CH], ss[CH];
+    if (cv && (rg == 0 || (CACHED && out))) {
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const float r = rsqrtf(acc[0][j] / (float)S + BF_IN_EPS);
@@ -112,10 +114,24 @@ __global__ void __launch_bounds__(NT) in_stats_kernel(const T* __restrict__ x, i
                 a *= gg;
                 s0 = s0 * gg + (gb ? gb[gi] : 0.f);
             }
-            mean[o] = mu[j];
-            rstd[o] = r;
-            sc[o] = a;
-            sh[o] = s0;
+            aa[j] = a; ss[j] = s0;
+            if (rg == 0) { mean[o] = mu[j]; rstd[o] = r; sc[o] = a; sh[o] = s0; }
+        }
+    }
+    if constexpr (CACHED) {
+        if (out && cv) {          // fused apply: out = resid + x * sc + sh from the rows still in registers (one launch and one read of x less)
+#pragma unroll
+            for (int q = 0; q < MAXR; ++q) {
+                const int s = rg + RG * q;
+                if (s < S) {
+                    const long off = ((long)f * S + s) * C + c;
+                    Chunk<T> rr, oo;
+                    if (resid) rr.load(resid + off);
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) oo.set(j, keep[q].get(j) * aa[j] + ss[j] + (resid ? rr.get(j) : 0.f));
+                    oo.store(out + off);
+                }
+            }
         }
     }
 }
@@ -510,9 +526,11 @@ extern "C" int64_t bf_in_ws_floats(int dtype, int frames, int S, int C) {
     return S > rows ? fc2 * (1 + bf_cdiv(S, rows)) : fc2;
 }
 
-extern "C" int bf_in_stats(int dtype, const void* x, int frames, int S, int C, const float* w, const float* b,
-                           const float* g, int gdiv, const float* gb, float* mean, float* rstd, float* sc, float* sh,
-                           float* ws, bf_stream_t stream) {
+// statistics, optionally followed by out = resid + x * sc + sh in the same kernel (short frames); *applied tells the caller
+static int in_stats_impl(int dtype, const void* x, int frames, int S, int C, const float* w, const float* b,
+                         const float* g, int gdiv, const float* gb, float* mean, float* rstd, float* sc, float* sh,
+                         float* ws, const void* resid, void* out, bool* applied, bf_stream_t stream) {
+    if (applied) *applied = false;
     BF_REQUIRE(x && w && b && mean && rstd && sc && sh, "bf_in_stats: null pointer");
     BF_REQUIRE(frames > 0 && S > 0 && C > 0, "bf_in_stats: empty");
     dim3 grid(frames, bf_cdiv(C, CPB));
@@ -535,17 +553,36 @@ extern "C" int bf_in_stats(int dtype, const void* x, int frames, int S, int C, c
             return 0;
         }
     }
+    const int cached_rows = dtype == BF_DTYPE_BF16 ? Geo<bf16>::RG * MAXR : Geo<float>::RG * MAXR;
+    const bool fuse = out != nullptr && S <= cached_rows;      // the apply needs the frame in registers
+    const void* RS = fuse ? resid : nullptr;
+    void* OU = fuse ? out : nullptr;
+    if (applied) *applied = fuse;
     if (dtype == BF_DTYPE_BF16) {
         BF_REQUIRE(chunk_ok<bf16>(C), "bf_in_stats: C must be a multiple of 8 (bf16)");
-        if (S <= Geo<bf16>::RG * MAXR) hipLaunchKernelGGL((in_stats_kernel<bf16, true>), grid, dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh);
-        else hipLaunchKernelGGL((in_stats_kernel<bf16, false>), grid, dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh);
+        if (S <= Geo<bf16>::RG * MAXR) hipLaunchKernelGGL((in_stats_kernel<bf16, true>), grid, dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh, (const bf16*)RS, (bf16*)OU);
+        else hipLaunchKernelGGL((in_stats_kernel<bf16, false>), grid, dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh, (const bf16*)RS, (bf16*)OU);
     } else {
         BF_REQUIRE(chunk_ok<float>(C), "bf_in_stats: C must be a multiple of 4 (f32)");
-        if (S <= Geo<float>::RG * MAXR) hipLaunchKernelGGL((in_stats_kernel<float, true>), grid, dim3(NT), 0, (hipStream_t)stream, (const float*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh);
-        else hipLaunchKernelGGL((in_stats_kernel<float, false>), grid, dim3(NT), 0, (hipStream_t)stream, (const float*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh);
+        if (S <= Geo<float>::RG * MAXR) hipLaunchKernelGGL((in_stats_kernel<float, true>), grid, dim3(NT), 0, (hipStream_t)stream, (const float*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh, (const float*)RS, (float*)OU);
+        else hipLaunchKernelGGL((in_stats_kernel<float, false>), grid, dim3(NT), 0, (hipStream_t)stream, (const float*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh, (const float*)RS, (float*)OU);
     }
     BF_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int bf_in_stats(int dtype, const void* x, int frames, int S, int C, const float* w, const float* b,
+                           const float* g, int gdiv, const float* gb, float* mean, float* rstd, float* sc, float* sh,
+                           float* ws, bf_stream_t stream) {
+    return in_stats_impl(dtype, x, frames, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh, ws, nullptr, nullptr, nullptr, stream);
+}
+// statistics of x and out = resid + x * sc + sh: one kernel when a frame fits the register cache, else statistics + bf_affine_apply
+int bf_in_stats_apply(int dtype, const void* x, int frames, int S, int C, const float* w, const float* b, const float* g, int gdiv, const float* gb,
+                      float* mean, float* rstd, float* sc, float* sh, float* ws, const void* resid, void* out, hipStream_t stream) {
+    bool applied = false;
+    if (int rc = in_stats_impl(dtype, x, frames, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh, ws, resid, out, &applied, (bf_stream_t)stream)) return rc;
+    if (applied) return 0;
+    return bf_affine_apply(dtype, x, resid, sc, sh, out, (int64_t)frames * S, S, C, (bf_stream_t)stream);
 }
 
 extern "C" int bf_affine_apply(int dtype, const void* z, const void* resid, const float* sc, const float* sh, void* out,
