@@ -10,16 +10,17 @@ namespace {
 constexpr int NT = 256;
 constexpr int CPB = 64;  // channels per block
 
-template <typename T> struct Geo {
+template <typename T, int CPB_ = CPB, int NT_ = NT> struct Geo {
     static constexpr int CH = Chunk<T>::N;
-    static constexpr int LC = CPB / CH;   // chunk lanes per row
-    static constexpr int RG = NT / LC;    // row groups
+    static constexpr int LC = CPB_ / CH;   // chunk lanes per row
+    static constexpr int RG = NT_ / LC;    // row groups (a power of two: reduce_rows halves it)
 };
 
 // block-wide reduction of CH per-thread partials over the RG row groups; result valid in every thread
-template <typename T, int NV>
+template <typename T, int NV, int CPB_ = CPB, int NT_ = NT>
 __device__ __forceinline__ void reduce_rows(float (&v)[NV][Chunk<T>::N], float* sm) {
-    constexpr int CH = Chunk<T>::N, LC = Geo<T>::LC, RG = Geo<T>::RG;
+    constexpr int CH = Chunk<T>::N, LC = Geo<T, CPB_, NT_>::LC, RG = Geo<T, CPB_, NT_>::RG;
+    static_assert((RG & (RG - 1)) == 0 && LC * RG == NT_, "row groups must be a power of two and fill the block");
     const int tid = threadIdx.x, lc = tid % LC, rg = tid / LC;
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
@@ -140,11 +141,13 @@ __global__ void __launch_bounds__(NT) in_stats_kernel(const T* __restrict__ x, i
 // is frames x slices x channel blocks instead of frames x channel blocks (which left most CUs idle and every wave with one
 // load in flight).  A slice is read ONCE into registers; slices are merged exactly (Chan et al. pairwise update):
 //   part[(f * nsl + sl) * C + c] = {slice mean, slice centred second moment}
-template <typename T>
-__global__ void __launch_bounds__(NT) in_stats_slice_kernel(const T* __restrict__ x, int S, int C, int nsl, float* __restrict__ part) {
-    constexpr int CH = Chunk<T>::N, LC = Geo<T>::LC, RG = Geo<T>::RG;
-    __shared__ float sm[NT * CH];
-    const int f = blockIdx.x / nsl, sl = blockIdx.x % nsl, c0 = blockIdx.y * CPB;
+// CPB_ channels per workgroup of NT_ threads: 64 / 256 by default, 96 / 192 when C is a multiple of 96 (the E/4 = 96-channel
+// embed / debed maps: no half-empty second channel block, whole 192-byte rows per row group)
+template <typename T, int CPB_, int NT_>
+__global__ void __launch_bounds__(NT_) in_stats_slice_kernel(const T* __restrict__ x, int S, int C, int nsl, float* __restrict__ part) {
+    constexpr int CH = Chunk<T>::N, LC = Geo<T, CPB_, NT_>::LC, RG = Geo<T, CPB_, NT_>::RG;
+    __shared__ float sm[NT_ * CH];
+    const int f = blockIdx.x / nsl, sl = blockIdx.x % nsl, c0 = blockIdx.y * CPB_;
     const int tid = threadIdx.x, lc = tid % LC, rg = tid / LC;
     const int c = c0 + lc * CH;
     const bool cv = c < C;
@@ -163,7 +166,7 @@ __global__ void __launch_bounds__(NT) in_stats_slice_kernel(const T* __restrict_
     for (int q = 0; q < MAXR; ++q)
 #pragma unroll
         for (int j = 0; j < CH; ++j) acc[0][j] += keep[q].get(j);
-    reduce_rows<T, 1>(acc, sm);
+    reduce_rows<T, 1, CPB_, NT_>(acc, sm);
     float mu[CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) { mu[j] = acc[0][j] / (float)n; acc[0][j] = 0.f; }
@@ -174,7 +177,7 @@ __global__ void __launch_bounds__(NT) in_stats_slice_kernel(const T* __restrict_
             for (int j = 0; j < CH; ++j) { const float d = keep[q].get(j) - mu[j]; acc[0][j] += d * d; }
         }
     }
-    reduce_rows<T, 1>(acc, sm);
+    reduce_rows<T, 1, CPB_, NT_>(acc, sm);
     if (cv && rg == 0) {
         float* o = part + (((long)f * nsl + sl) * C + c) * 2;
 #pragma unroll
@@ -379,15 +382,15 @@ __global__ void __launch_bounds__(NT) in_bwd_kernel(const T* __restrict__ dy, co
 
 // Long frames, as for the statistics: phase 0 reduces {s1, s2} per slice into part[(f * nsl + sl) * C + c], in_slice_sum_kernel
 // adds the slices into ws[f][c], phase 1 applies over the same slices (grid = frames * slices x channel blocks).
-template <typename T, bool GELU, int PHASE>
-__global__ void __launch_bounds__(NT) in_bwd_slice_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ add,
+template <typename T, bool GELU, int PHASE, int CPB_, int NT_>
+__global__ void __launch_bounds__(NT_) in_bwd_slice_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ add,
                                                          T* __restrict__ dx, int S, int C, int nsl, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, const float* __restrict__ w,
                                                          const float* __restrict__ b, const float* __restrict__ g, int gdiv,
                                                          float* __restrict__ part, const float* __restrict__ tot) {
-    constexpr int CH = Chunk<T>::N, LC = Geo<T>::LC, RG = Geo<T>::RG;
-    __shared__ float sm[NT * CH];
-    const int f = blockIdx.x / nsl, sl = blockIdx.x % nsl, c0 = blockIdx.y * CPB;
+    constexpr int CH = Chunk<T>::N, LC = Geo<T, CPB_, NT_>::LC, RG = Geo<T, CPB_, NT_>::RG;
+    __shared__ float sm[NT_ * CH];
+    const int f = blockIdx.x / nsl, sl = blockIdx.x % nsl, c0 = blockIdx.y * CPB_;
     const int tid = threadIdx.x, lc = tid % LC, rg = tid / LC;
     const int c = c0 + lc * CH;
     const bool cv = c < C;
@@ -428,7 +431,7 @@ __global__ void __launch_bounds__(NT) in_bwd_slice_kernel(const T* __restrict__ 
                 }
             }
         }
-        reduce_rows<T, 2>(acc, sm);
+        reduce_rows<T, 2, CPB_, NT_>(acc, sm);
         if (cv && rg == 0) {
             float* o = part + (((long)f * nsl + sl) * C + c) * 2;
 #pragma unroll
@@ -518,12 +521,24 @@ int chunk_ok(int C) { return C % Chunk<T>::N == 0; }
 
 }  // namespace
 
-template <typename T> int slice_rows() { return Geo<T>::RG * MAXR; }
+// frames longer than the register cache of the one-workgroup-per-frame kernels are cut into slices; multiples of 96 channels take
+// the 96-channel x 192-thread geometry (whole 192-byte rows), everything else 64 x 256
+constexpr int WCPB = 96, WNT = 192;
+struct SliceCfg { bool sliced, wide; int rows; };
+SliceCfg slice_cfg(int dtype, int S, int C) {
+    const bool bf = dtype == BF_DTYPE_BF16;
+    const int cached = bf ? Geo<bf16>::RG * MAXR : Geo<float>::RG * MAXR;
+    SliceCfg c;
+    c.sliced = S > cached;
+    c.wide = C % WCPB == 0;
+    c.rows = c.wide ? (bf ? Geo<bf16, WCPB, WNT>::RG : Geo<float, WCPB, WNT>::RG) * MAXR : cached;
+    return c;
+}
 
 extern "C" int64_t bf_in_ws_floats(int dtype, int frames, int S, int C) {
-    const int rows = dtype == BF_DTYPE_BF16 ? slice_rows<bf16>() : slice_rows<float>();
+    const SliceCfg c = slice_cfg(dtype, S, C);
     const int64_t fc2 = (int64_t)2 * frames * C;
-    return S > rows ? fc2 * (1 + bf_cdiv(S, rows)) : fc2;
+    return c.sliced ? fc2 * (1 + bf_cdiv(S, c.rows)) : fc2;
 }
 
 // statistics, optionally followed by out = resid + x * sc + sh in the same kernel (short frames); *applied tells the caller
@@ -537,15 +552,22 @@ static int in_stats_impl(int dtype, const void* x, int frames, int S, int C, con
     if (gdiv < 1) gdiv = 1;
     BfProfScope prof((hipStream_t)stream, "in_stats", 0.0, (double)frames * S * C * bf_esize(dtype));
     {
-        const int rows = dtype == BF_DTYPE_BF16 ? slice_rows<bf16>() : slice_rows<float>();
-        if (ws && S > rows) {                     // long frames: slices + exact merge
+        const SliceCfg cfg = slice_cfg(dtype, S, C);
+        const int rows = cfg.rows;
+        if (ws && cfg.sliced) {                   // long frames: slices + exact merge
             BF_REQUIRE(C % (dtype == BF_DTYPE_BF16 ? 8 : 4) == 0, "bf_in_stats: C must be a multiple of the 16-byte chunk");
             const int nsl = bf_cdiv(S, rows);
             BF_REQUIRE((long)frames * nsl < 2147483647L, "bf_in_stats: grid too large");
             float* part = ws + (size_t)2 * frames * C;
-            dim3 sg(frames * nsl, bf_cdiv(C, CPB));
-            if (dtype == BF_DTYPE_BF16) hipLaunchKernelGGL(in_stats_slice_kernel<bf16>, sg, dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, S, C, nsl, part);
-            else hipLaunchKernelGGL(in_stats_slice_kernel<float>, sg, dim3(NT), 0, (hipStream_t)stream, (const float*)x, S, C, nsl, part);
+            if (cfg.wide) {
+                dim3 sg(frames * nsl, C / WCPB);
+                if (dtype == BF_DTYPE_BF16) hipLaunchKernelGGL((in_stats_slice_kernel<bf16, WCPB, WNT>), sg, dim3(WNT), 0, (hipStream_t)stream, (const bf16*)x, S, C, nsl, part);
+                else hipLaunchKernelGGL((in_stats_slice_kernel<float, WCPB, WNT>), sg, dim3(WNT), 0, (hipStream_t)stream, (const float*)x, S, C, nsl, part);
+            } else {
+                dim3 sg(frames * nsl, bf_cdiv(C, CPB));
+                if (dtype == BF_DTYPE_BF16) hipLaunchKernelGGL((in_stats_slice_kernel<bf16, CPB, NT>), sg, dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, S, C, nsl, part);
+                else hipLaunchKernelGGL((in_stats_slice_kernel<float, CPB, NT>), sg, dim3(NT), 0, (hipStream_t)stream, (const float*)x, S, C, nsl, part);
+            }
             BF_CHECK_LAUNCH();
             hipLaunchKernelGGL(in_stats_merge_kernel, dim3(bf_cdiv(C, 64), frames), dim3(NT), 0, (hipStream_t)stream, (const float*)part, frames, S, C,
                                nsl, rows, w, b, g, gdiv, gb, mean, rstd, sc, sh);
@@ -624,20 +646,22 @@ static int in_bwd_impl(int dtype, const void* dy, const void* x, const void* add
     if (gdiv < 1) gdiv = 1;
     hipStream_t st = (hipStream_t)stream;
     BfProfScope prof(st, "in_bwd", 0.0, (double)frames * S * C * bf_esize(dtype) * (add ? 4.0 : 3.0));
-    const int rows = dtype == BF_DTYPE_BF16 ? slice_rows<bf16>() : slice_rows<float>();
-    if (ws && S > rows) {                         // long frames: slice reduce -> sum -> slice apply
-        const int nsl = bf_cdiv(S, rows);
+    const SliceCfg cfg = slice_cfg(dtype, S, C);
+    if (ws && cfg.sliced) {                       // long frames: slice reduce -> sum -> slice apply
+        const int nsl = bf_cdiv(S, cfg.rows);
         BF_REQUIRE((long)frames * nsl < 2147483647L, "bf_in_bwd: grid too large");
         float* part = ws + (size_t)2 * frames * C;
-        dim3 sg(frames * nsl, bf_cdiv(C, CPB));
-#define GOS(T, G)                                                                                                                        \
+#define GOS(T, G, CP, TH)                                                                                                                \
     do {                                                                                                                                  \
-        hipLaunchKernelGGL((in_bwd_slice_kernel<T, G, 0>), sg, dim3(NT), 0, st, (const T*)dy, (const T*)x, (const T*)add, (T*)dx, S, C, nsl, mean, rstd, w, b, g, gdiv, part, (const float*)ws); \
+        dim3 sg(frames * nsl, bf_cdiv(C, CP));                                                                                            \
+        hipLaunchKernelGGL((in_bwd_slice_kernel<T, G, 0, CP, TH>), sg, dim3(TH), 0, st, (const T*)dy, (const T*)x, (const T*)add, (T*)dx, S, C, nsl, mean, rstd, w, b, g, gdiv, part, (const float*)ws); \
         hipLaunchKernelGGL(in_slice_sum_kernel, dim3(bf_cdiv(C, 64), frames), dim3(NT), 0, st, (const float*)part, C, nsl, ws); \
-        hipLaunchKernelGGL((in_bwd_slice_kernel<T, G, 1>), sg, dim3(NT), 0, st, (const T*)dy, (const T*)x, (const T*)add, (T*)dx, S, C, nsl, mean, rstd, w, b, g, gdiv, part, (const float*)ws); \
+        hipLaunchKernelGGL((in_bwd_slice_kernel<T, G, 1, CP, TH>), sg, dim3(TH), 0, st, (const T*)dy, (const T*)x, (const T*)add, (T*)dx, S, C, nsl, mean, rstd, w, b, g, gdiv, part, (const float*)ws); \
     } while (0)
-        if (dtype == BF_DTYPE_BF16) { if (gelu) GOS(bf16, true); else GOS(bf16, false); }
-        else { if (gelu) GOS(float, true); else GOS(float, false); }
+#define GOS2(T, G) do { if (cfg.wide) GOS(T, G, WCPB, WNT); else GOS(T, G, CPB, NT); } while (0)
+        if (dtype == BF_DTYPE_BF16) { if (gelu) GOS2(bf16, true); else GOS2(bf16, false); }
+        else { if (gelu) GOS2(float, true); else GOS2(float, false); }
+#undef GOS2
 #undef GOS
         BF_CHECK_LAUNCH();
     } else {

@@ -132,10 +132,10 @@ def test_gemm_conv_weight_gradient_gathered_prologue(K, dtype, Ci):
         assert _rel(out, ref) < TOL[dtype], splitk
 
 
-@pytest.mark.parametrize("S", [37, 1000])     # 1000 tokens per frame: the sliced (frames x slices) path with a ragged last slice
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_in_stats_two_pass(K, dtype, S):
-    Fr, Cc = 5, 72
+@pytest.mark.parametrize("S,Cc", [(37, 72), (1000, 72), (1000, 96)])     # 1000 tokens per frame: the sliced (frames x slices) path, ragged last
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])          # slice; 96 channels: the 96-channel x 192-thread geometry
+def test_in_stats_two_pass(K, dtype, S, Cc):
+    Fr = 5
     g = torch.Generator(device="cuda").manual_seed(5)
     x = (torch.randn(Fr, S, Cc, device="cuda", generator=g) * 3 + 100.0).to(dtype)     # large mean: a one-pass variance would fail
     w = torch.randn(Cc, device="cuda", generator=g)
@@ -155,11 +155,11 @@ def test_in_stats_two_pass(K, dtype, S):
 
 
 @pytest.mark.parametrize("gelu", [False, True])
-@pytest.mark.parametrize("S", [50, 700])      # 700: sliced reduce / sum / apply path (ragged last slice), 50: one workgroup per frame
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_in_bwd_matches_autograd(K, dtype, S, gelu):
+@pytest.mark.parametrize("S,Cc", [(50, 40), (700, 40), (700, 192)])      # 700: sliced reduce / sum / apply path (ragged last slice), 50: one
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])       # workgroup per frame; 192 channels: the 96-channel slice geometry
+def test_in_bwd_matches_autograd(K, dtype, S, Cc, gelu):
     """nn.InstanceNorm2d(affine) [+ GELU] backward, incl. the residual add and the parameter gradients."""
-    Fr, Cc = 3, 40
+    Fr = 3
     g = torch.Generator(device="cuda").manual_seed(11)
     x = (torch.randn(Fr, S, Cc, device="cuda", generator=g) * 1.5 + 0.3).to(dtype)
     dy = torch.randn(Fr, S, Cc, device="cuda", generator=g).to(dtype)
