@@ -260,7 +260,7 @@ int wview(const D& d, int mode, const float* src, void* dst, int R, int K, int K
 // ------------------------------------------------------------------------------------------------ saved-record layouts
 struct TemporalSaved {
     float *mean1, *rstd1, *sc1, *sh1, *mean2, *rstd2, *sc2, *sh2, *alpha, *beta, *mc;
-    void *qkv, *o, *win_c, *wout_c;
+    void *qkv, *o, *xn, *on, *win_c, *wout_c;      // xn / on: InstanceNorm'd block input / attention output (GEMM operands, fwd and dW)
     size_t bytes;
     TemporalSaved(const D& d, void* base) {
         Arena a(base);
@@ -270,6 +270,8 @@ struct TemporalSaved {
         alpha = a.f32(d.E); beta = a.f32(d.E); mc = a.f32(d.E);
         qkv = a.take((size_t)d.N * 3 * d.E * d.es);
         o = a.take((size_t)d.N * d.E * d.es);
+        xn = a.take((size_t)d.N * d.E * d.es);
+        on = a.take((size_t)d.N * d.E * d.es);
         win_c = a.take((size_t)3 * d.E * d.E * d.es);
         wout_c = a.take((size_t)d.E * d.E * d.es);
         bytes = a.off;
@@ -277,7 +279,7 @@ struct TemporalSaved {
 };
 struct SpatialSaved {
     float *mean1, *rstd1, *sc1, *sh1, *mean2, *rstd2, *sc2, *sh2, *mean3, *rstd3, *sc3, *sh3, *alpha, *beta, *mc, *gtab;
-    void *qkv, *o, *x1, *pre, *hid, *z, *win_c, *wout_c, *w1_c, *w2_c;
+    void *qkv, *o, *xn, *on, *x1, *pre, *hid, *z, *win_c, *wout_c, *w1_c, *w2_c;
     size_t bytes;
     SpatialSaved(const D& d, void* base) {
         Arena a(base);
@@ -288,6 +290,8 @@ struct SpatialSaved {
         alpha = a.f32(d.E); beta = a.f32(d.E); mc = a.f32(d.E); gtab = a.f32(fe);
         qkv = a.take((size_t)d.N * 3 * d.E * d.es);
         o = a.take((size_t)d.N * d.E * d.es);
+        xn = a.take((size_t)d.N * d.E * d.es);
+        on = a.take((size_t)d.N * d.E * d.es);
         x1 = a.take((size_t)d.N * d.E * d.es);
         pre = a.take((size_t)d.N * 4 * d.E * d.es);
         hid = a.take((size_t)d.N * 4 * d.E * d.es);
@@ -382,19 +386,19 @@ int launch_fill(float* p, float v, int n, hipStream_t st) {
 }
 
 // QKV projection + attention shared pieces -------------------------------------------------------
-int qkv_gemm(const D& d, const void* x, const float* sc, const float* sh, const void* w_c, const float* bias, void* qkv, hipStream_t st) {
-    bf_operand A = op_plain(x, d.E, BF_LAY_KC);
-    op_affine(A, BF_PRO_AFFINE, sc, sh, d.S, d.E);
+// The InstanceNorm'd operand is materialised by the statistics kernel itself (bf_in_stats_apply: the frame is in registers there),
+// so the projection GEMMs run the prologue-free, double-buffered-LDS kernel and the weight-gradient GEMMs reuse the same tensor.
+int qkv_gemm(const D& d, const void* xn, const void* w_c, const float* bias, void* qkv, hipStream_t st) {
+    bf_operand A = op_plain(xn, d.E, BF_LAY_KC);
     bf_operand Bo = op_plain(w_c, d.E, BF_LAY_KC);
     bf_epilogue e = epi_store(qkv, 3L * d.E);
     e.bias = bias;
     return bf_gemm(d.dtype, (int)d.N, 3 * d.E, d.E, &A, &Bo, &e, 1, st);
 }
 // out = x + alpha * (affine(o) @ W^T) + beta
-int outproj_gemm(const D& d, const void* o, const float* sc, const float* sh, const void* w_c, const float* alpha, const float* beta,
+int outproj_gemm(const D& d, const void* on, const void* w_c, const float* alpha, const float* beta,
                  const void* resid, void* out, const float* drop, long rows_per_group, hipStream_t st) {
-    bf_operand A = op_plain(o, d.E, BF_LAY_KC);
-    op_affine(A, BF_PRO_AFFINE, sc, sh, d.S, d.E);
+    bf_operand A = op_plain(on, d.E, BF_LAY_KC);
     bf_operand Bo = op_plain(w_c, d.E, BF_LAY_KC);
     bf_epilogue e = epi_store(out, d.E);
     e.colscale = alpha; e.colshift = beta; e.aux_mode = BF_AUX_ADD; e.aux = resid; e.ld_aux = d.E;
@@ -402,19 +406,16 @@ int outproj_gemm(const D& d, const void* o, const float* sc, const float* sh, co
     return bf_gemm(d.dtype, (int)d.N, d.E, d.E, &A, &Bo, &e, 1, st);
 }
 // backward of the folded out-projection: param grads + don = (dout * alpha) @ W
-int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* o, const float* sc2, const float* sh2, const void* w_c,
+int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on, const void* w_c,
                 const float* W, const float* bias, const float* nb, const float* gamma, const float* lo, const float* hi,
                 const float* alpha, const float* mc, float* dW, float* dbias, float* dnb, float* dgamma, float* dlo, float* dhi,
                 void* don, hipStream_t st, Fork& fk) {
-    hipStream_t ss;                                   // parameter-gradient side: memset, normalised operand, G GEMM, finalize
+    hipStream_t ss;                                   // parameter-gradient side: memset, G GEMM, finalize
     TRY(fk.begin(&ss));
-    void* tmp = sc.s1;
     ZERO_ON(ss, sc.G, (size_t)((char*)sc.csum - (char*)sc.G) + (size_t)d.E * 4);     // G and csum are adjacent in the arena: one memset
-    {   // G[n][k] = sum_m dout[m][n] * on[m][k].  The normalised operand is materialised first (one 2U element-wise pass,
-        // ~7 us) because applying the affine inside the token-reduction GEMM's staging costs ~20 us (tools/gemm_bench.py)
-        TRY(bf_affine_apply(d.dtype, o, nullptr, sc2, sh2, tmp, d.N, (int)d.S, d.E, ss));
+    {   // G[n][k] = sum_m dout[m][n] * on[m][k]; `on` is the normalised operand the forward saved
         bf_operand A = op_plain(dout, d.E, BF_LAY_XC);
-        bf_operand Bo = op_plain(tmp, d.E, BF_LAY_XC);
+        bf_operand Bo = op_plain(on, d.E, BF_LAY_XC);
         bf_epilogue e = epi_atomic(sc.G, d.E);
         e.colsum = sc.csum;                  // dbeta = colsum(dout), fused into the same pass over dout
         TRY(bf_gemm(d.dtype, d.E, d.E, (int)d.N, &A, &Bo, &e, splitk_for(d.E, d.E, d.N), ss));
@@ -485,13 +486,15 @@ extern "C" int bf_temporal_fwd(const bf_dims* dims, const bf_temporal_params* p,
         TRY(wviews(d, 2, src, dst, n, out, st, &prep));
         win_c = out[0]; wout_c = out[1];
     }
-    TRY(bf_in_stats(d.dtype, x, (int)d.F, (int)d.S, d.E, p->norm1_w, p->norm1_b, nullptr, 1, nullptr, sv.mean1, sv.rstd1, sv.sc1, sv.sh1, sc.in_ws, st));
-    TRY(qkv_gemm(d, x, sv.sc1, sv.sh1, win_c, p->input_head_b, sv.qkv, st));
+    TRY(bf_in_stats_apply(d.dtype, x, (int)d.F, (int)d.S, d.E, p->norm1_w, p->norm1_b, nullptr, 1, nullptr, sv.mean1, sv.rstd1, sv.sc1, sv.sh1, sc.in_ws,
+                          nullptr, sv.xn, st));
+    TRY(qkv_gemm(d, sv.xn, win_c, p->input_head_b, sv.qkv, st));
     // sequences along T for every (b, y, x): token = b*T*S + pos + t*S
     TRY(bf_attn_fwd(d.dtype, sv.qkv, sv.o, (long)d.B * d.S, d.T, d.S, (long)d.T * d.S, 1, d.S, d.heads, d.d, p->qnorm_w, p->qnorm_b,
                     p->knorm_w, p->knorm_b, p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor : nullptr, 1.f, 0, st));
-    TRY(bf_in_stats(d.dtype, sv.o, (int)d.F, (int)d.S, d.E, p->norm2_w, p->norm2_b, nullptr, 1, nullptr, sv.mean2, sv.rstd2, sv.sc2, sv.sh2, sc.in_ws, st));
-    TRY(outproj_gemm(d, sv.o, sv.sc2, sv.sh2, wout_c, sv.alpha, sv.beta, x, out, drop, (long)d.T * d.S, st));   // mask per batch element
+    TRY(bf_in_stats_apply(d.dtype, sv.o, (int)d.F, (int)d.S, d.E, p->norm2_w, p->norm2_b, nullptr, 1, nullptr, sv.mean2, sv.rstd2, sv.sc2, sv.sh2, sc.in_ws,
+                          nullptr, sv.on, st));
+    TRY(outproj_gemm(d, sv.on, wout_c, sv.alpha, sv.beta, x, out, drop, (long)d.T * d.S, st));   // mask per batch element
     return 0;
 }
 
@@ -513,7 +516,7 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
         TRY(bf_frame_scale(d.dtype, dout, drop, d.T, sc.t4, d.N, (int)d.S, d.E, st));
         dbr = sc.t4;
     }
-    TRY(outproj_bwd(d, sc, dbr, sv.o, sv.sc2, sv.sh2, wout_c, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr,
+    TRY(outproj_bwd(d, sc, dbr, sv.on, wout_c, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr,
                     sv.alpha, sv.mc, g->output_head_w, g->output_head_b, nullptr, g->gamma, nullptr, nullptr, don, st, fk));
     ReduceJobs jobs;        // parameter-gradient reductions, all launched together at the end
     TRY(bf_in_bwd_partials(d.dtype, don, sv.o, nullptr, dO, (int)d.F, (int)d.S, d.E, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, nullptr, 1, 0, sc.in_ws2, st));
@@ -528,7 +531,7 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
                                                d.attn_scale ? g->attn_scale_factor : nullptr};
     }
     void* dxn = sc.t1;      // don is dead
-    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, x, d.E, BF_PRO_AFFINE, sv.sc1, sv.sh1, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk));
+    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, sv.xn, d.E, BF_PRO_NONE, nullptr, nullptr, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk));
     TRY(bf_in_bwd_partials(d.dtype, dxn, x, dout, dx, (int)d.F, (int)d.S, d.E, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, nullptr, 1, 0, sc.in_ws, st));
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws, (int)d.F, d.E, p->norm1_w, p->norm1_b, nullptr, 1, g->norm1_w, g->norm1_b, nullptr, nullptr, nullptr, nullptr};
     TRY(launch_reduce_jobs(jobs, st));
@@ -554,16 +557,18 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
         TRY(wviews(d, 4, src, dst, n, out, st, &prep));
         win_c = out[0]; wout_c = out[1]; w1_c = out[2]; w2_c = out[3];
     }
-    TRY(bf_in_stats(d.dtype, x, (int)d.F, (int)d.S, d.E, p->norm1_w, p->norm1_b, nullptr, 1, nullptr, sv.mean1, sv.rstd1, sv.sc1, sv.sh1, sc.in_ws, st));
-    TRY(qkv_gemm(d, x, sv.sc1, sv.sh1, win_c, p->input_head_b, sv.qkv, st));
+    TRY(bf_in_stats_apply(d.dtype, x, (int)d.F, (int)d.S, d.E, p->norm1_w, p->norm1_b, nullptr, 1, nullptr, sv.mean1, sv.rstd1, sv.sc1, sv.sh1, sc.in_ws,
+                          nullptr, sv.xn, st));
+    TRY(qkv_gemm(d, sv.xn, win_c, p->input_head_b, sv.qkv, st));
     // along w: one sequence per (frame, row): contiguous tokens
     TRY(bf_attn_fwd(d.dtype, sv.qkv, sv.o, d.F * d.h, d.w, 1, d.w, 0, 1, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
                     p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_x : nullptr, 0.5f, 0, st));
     // along h: one sequence per (frame, column): stride w
     TRY(bf_attn_fwd(d.dtype, sv.qkv, sv.o, d.F * d.w, d.h, d.w, d.S, 1, d.w, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
                     p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_y : nullptr, 0.5f, 1, st));
-    TRY(bf_in_stats(d.dtype, sv.o, (int)d.F, (int)d.S, d.E, p->norm2_w, p->norm2_b, nullptr, 1, nullptr, sv.mean2, sv.rstd2, sv.sc2, sv.sh2, sc.in_ws, st));
-    TRY(outproj_gemm(d, sv.o, sv.sc2, sv.sh2, wout_c, sv.alpha, sv.beta, x, sv.x1, drop_att, d.S, st));     // mask per frame
+    TRY(bf_in_stats_apply(d.dtype, sv.o, (int)d.F, (int)d.S, d.E, p->norm2_w, p->norm2_b, nullptr, 1, nullptr, sv.mean2, sv.rstd2, sv.sc2, sv.sh2, sc.in_ws,
+                          nullptr, sv.on, st));
+    TRY(outproj_gemm(d, sv.on, wout_c, sv.alpha, sv.beta, x, sv.x1, drop_att, d.S, st));     // mask per frame
     {   // pre = x1 @ W1^T + b1 ; hid = gelu(pre) (both kept: pre for gelu', hid as the fc2 operand -- no erf in any prologue)
         bf_operand A = op_plain(sv.x1, d.E, BF_LAY_KC);
         bf_operand Bo = op_plain(w1_c, d.E, BF_LAY_KC);
@@ -641,7 +646,7 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
         TRY(bf_frame_scale(d.dtype, dx1, drop_att, 1, sc.e5, d.N, (int)d.S, d.E, st));
         dbr = sc.e5;
     }
-    TRY(outproj_bwd(d, sc, dbr, sv.o, sv.sc2, sv.sh2, wout_c, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att,
+    TRY(outproj_bwd(d, sc, dbr, sv.on, wout_c, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att,
                     d.feat_scale ? p->low_freq_scalar : nullptr, d.feat_scale ? p->high_freq_scalar : nullptr, sv.alpha, sv.mc,
                     g->output_head_w, g->output_head_b, g->norm2_b, g->gamma_att, d.feat_scale ? g->low_freq_scalar : nullptr,
                     d.feat_scale ? g->high_freq_scalar : nullptr, don, st, fk));
@@ -663,7 +668,7 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
                                                d.attn_scale ? g->attn_scale_factor_y : nullptr};
     }
     void* dxn = sc.e6;      // don is dead (it was only read on this stream)
-    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, x, d.E, BF_PRO_AFFINE, sv.sc1, sv.sh1, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk));
+    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, sv.xn, d.E, BF_PRO_NONE, nullptr, nullptr, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk));
     TRY(bf_in_bwd_partials(d.dtype, dxn, x, dx1, dx, (int)d.F, (int)d.S, d.E, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, nullptr, 1, 0, sc.in_ws, st));
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws, (int)d.F, d.E, p->norm1_w, p->norm1_b, nullptr, 1, g->norm1_w, g->norm1_b, nullptr, nullptr, nullptr, nullptr};
     TRY(launch_reduce_jobs(jobs, st));
