@@ -136,11 +136,13 @@ struct Fork {
 
 // ------------------------------------------------------------------------------------------------ small param kernels
 // out-projection fold.  mc[n] = <W[n,:], nb> + bias[n]; alpha = gamma*(1+hi); beta = gamma*(bias*(1+hi) + mc*(lo-hi))
-struct PrepArgs { const float *W, *bias, *nb, *gamma, *lo, *hi; float *alpha, *beta, *mc; int E; };
+struct PrepArgs { const float *W, *bias, *nb, *gamma, *lo, *hi; float *alpha, *beta, *mc; int E; void* wscaled; int dtype; };      // wscaled[n][k] = alpha[n] * W[n][k] (compute dtype): the data-gradient GEMM's weight
 __device__ __forceinline__ void outproj_prep_row(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ nb,
                                                  const float* __restrict__ gamma, const float* __restrict__ lo, const float* __restrict__ hi,
-                                                 float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ mc, int E, int n) {
+                                                 float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ mc, int E, int n,
+                                                 void* __restrict__ wscaled, int dtype) {
     __shared__ float red[4];
+    __shared__ float s_alpha;
     float acc = 0.f;
     if (lo) for (int k = threadIdx.x; k < E; k += blockDim.x) acc += W[(long)n * E + k] * nb[k];
     acc = wave_sum(acc);
@@ -153,10 +155,20 @@ __device__ __forceinline__ void outproj_prep_row(const float* __restrict__ W, co
         alpha[n] = g * (1.f + h);
         beta[n] = g * (bias[n] * (1.f + h) + (lo ? m * (l - h) : 0.f));
         mc[n] = m;
+        s_alpha = g * (1.f + h);
+    }
+    if (wscaled) {
+        __syncthreads();
+        const float al = s_alpha;
+        for (int k = threadIdx.x; k < E; k += blockDim.x) {
+            const float v = al * W[(long)n * E + k];
+            if (dtype == BF_DTYPE_BF16) reinterpret_cast<bf16*>(wscaled)[(long)n * E + k] = (bf16)v;
+            else reinterpret_cast<float*>(wscaled)[(long)n * E + k] = v;
+        }
     }
 }
 __global__ void __launch_bounds__(256) outproj_prep_kernel(PrepArgs a) {
-    outproj_prep_row(a.W, a.bias, a.nb, a.gamma, a.lo, a.hi, a.alpha, a.beta, a.mc, a.E, blockIdx.x);
+    outproj_prep_row(a.W, a.bias, a.nb, a.gamma, a.lo, a.hi, a.alpha, a.beta, a.mc, a.E, blockIdx.x, a.wscaled, a.dtype);
 }
 // parameter gradients of the fold (see header comment).  grid = E rows.
 __global__ void outproj_finalize_kernel(const float* __restrict__ G, const float* __restrict__ csum, const float* __restrict__ W,
@@ -221,7 +233,7 @@ __global__ void __launch_bounds__(256) cast4_kernel(Cast4 j) {
 // the same casts plus the out-projection fold (grid row cnt, one workgroup per output channel): a stage's parameter-only work in ONE launch
 __global__ void __launch_bounds__(256) stage_prep_kernel(Cast4 j, int cnt, PrepArgs a) {
     if ((int)blockIdx.y == cnt) {
-        if ((int)blockIdx.x < a.E) outproj_prep_row(a.W, a.bias, a.nb, a.gamma, a.lo, a.hi, a.alpha, a.beta, a.mc, a.E, blockIdx.x);
+        if ((int)blockIdx.x < a.E) outproj_prep_row(a.W, a.bias, a.nb, a.gamma, a.lo, a.hi, a.alpha, a.beta, a.mc, a.E, blockIdx.x, a.wscaled, a.dtype);
         return;
     }
     const int w = blockIdx.y;
@@ -260,7 +272,7 @@ int wview(const D& d, int mode, const float* src, void* dst, int R, int K, int K
 // ------------------------------------------------------------------------------------------------ saved-record layouts
 struct TemporalSaved {
     float *mean1, *rstd1, *sc1, *sh1, *mean2, *rstd2, *sc2, *sh2, *alpha, *beta, *mc;
-    void *qkv, *o, *xn, *on, *win_c, *wout_c;      // xn / on: InstanceNorm'd block input / attention output (GEMM operands, fwd and dW)
+    void *qkv, *o, *xn, *on, *win_c, *wout_c, *wout_s;      // wout_s = diag(alpha) W_out (data-gradient operand); xn / on: InstanceNorm'd block input / attention output (GEMM operands, fwd and dW)
     size_t bytes;
     TemporalSaved(const D& d, void* base) {
         Arena a(base);
@@ -274,12 +286,13 @@ struct TemporalSaved {
         on = a.take((size_t)d.N * d.E * d.es);
         win_c = a.take((size_t)3 * d.E * d.E * d.es);
         wout_c = a.take((size_t)d.E * d.E * d.es);
+        wout_s = a.take((size_t)d.E * d.E * d.es);
         bytes = a.off;
     }
 };
 struct SpatialSaved {
     float *mean1, *rstd1, *sc1, *sh1, *mean2, *rstd2, *sc2, *sh2, *mean3, *rstd3, *sc3, *sh3, *alpha, *beta, *mc, *gtab;
-    void *qkv, *o, *xn, *on, *x1, *pre, *hid, *z, *win_c, *wout_c, *w1_c, *w2_c;
+    void *qkv, *o, *xn, *on, *x1, *pre, *hid, *z, *win_c, *wout_c, *wout_s, *w1_c, *w2_c;
     size_t bytes;
     SpatialSaved(const D& d, void* base) {
         Arena a(base);
@@ -298,6 +311,7 @@ struct SpatialSaved {
         z = a.take((size_t)d.N * d.E * d.es);
         win_c = a.take((size_t)3 * d.E * d.E * d.es);
         wout_c = a.take((size_t)d.E * d.E * d.es);
+        wout_s = a.take((size_t)d.E * d.E * d.es);
         w1_c = a.take((size_t)4 * d.E * d.E * d.es);
         w2_c = a.take((size_t)4 * d.E * d.E * d.es);
         bytes = a.off;
@@ -406,7 +420,7 @@ int outproj_gemm(const D& d, const void* on, const void* w_c, const float* alpha
     return bf_gemm(d.dtype, (int)d.N, d.E, d.E, &A, &Bo, &e, 1, st);
 }
 // backward of the folded out-projection: param grads + don = (dout * alpha) @ W
-int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on, const void* w_c,
+int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on, const void* w_s,
                 const float* W, const float* bias, const float* nb, const float* gamma, const float* lo, const float* hi,
                 const float* alpha, const float* mc, float* dW, float* dbias, float* dnb, float* dgamma, float* dlo, float* dhi,
                 void* don, hipStream_t st, Fork& fk) {
@@ -423,10 +437,9 @@ int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on,
     hipLaunchKernelGGL(outproj_finalize_kernel, dim3(d.E), dim3(256), 0, ss, sc.G, sc.csum, W, bias, nb, gamma, lo, hi, mc, dW, dbias, dnb,
                        dgamma, dlo, dhi, d.E);
     BF_CHECK_LAUNCH();
-    {   // don = (dout * alpha) @ W     (alpha per reduction column; frame independent)
+    {   // don = (dout * alpha) @ W = dout @ (diag(alpha) W): the scaled weight was written by the forward's parameter prep
         bf_operand A = op_plain(dout, d.E, BF_LAY_KC);
-        op_affine(A, BF_PRO_AFFINE, alpha, nullptr, d.N, d.E);
-        bf_operand Bo = op_plain(w_c, d.E, BF_LAY_XC);
+        bf_operand Bo = op_plain(w_s, d.E, BF_LAY_XC);
         bf_epilogue e = epi_store(don, d.E);
         TRY(bf_gemm(d.dtype, (int)d.N, d.E, d.E, &A, &Bo, &e, 1, st));
     }
@@ -482,7 +495,7 @@ extern "C" int bf_temporal_fwd(const bf_dims* dims, const bf_temporal_params* p,
         void* dst[2] = {sv.win_c, sv.wout_c};
         const long n[2] = {3L * d.E * d.E, (long)d.E * d.E};
         const void* out[4];
-        const PrepArgs prep{p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr, sv.alpha, sv.beta, sv.mc, d.E};
+        const PrepArgs prep{p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr, sv.alpha, sv.beta, sv.mc, d.E, sv.wout_s, d.dtype};
         TRY(wviews(d, 2, src, dst, n, out, st, &prep));
         win_c = out[0]; wout_c = out[1];
     }
@@ -516,7 +529,7 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
         TRY(bf_frame_scale(d.dtype, dout, drop, d.T, sc.t4, d.N, (int)d.S, d.E, st));
         dbr = sc.t4;
     }
-    TRY(outproj_bwd(d, sc, dbr, sv.on, wout_c, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr,
+    TRY(outproj_bwd(d, sc, dbr, sv.on, sv.wout_s, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr,
                     sv.alpha, sv.mc, g->output_head_w, g->output_head_b, nullptr, g->gamma, nullptr, nullptr, don, st, fk));
     ReduceJobs jobs;        // parameter-gradient reductions, all launched together at the end
     TRY(bf_in_bwd_partials(d.dtype, don, sv.o, nullptr, dO, (int)d.F, (int)d.S, d.E, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, nullptr, 1, 0, sc.in_ws2, st));
@@ -553,7 +566,7 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
         const long n[4] = {3L * d.E * d.E, (long)d.E * d.E, 4L * d.E * d.E, 4L * d.E * d.E};
         const void* out[4];
         const PrepArgs prep{p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att, d.feat_scale ? p->low_freq_scalar : nullptr,
-                            d.feat_scale ? p->high_freq_scalar : nullptr, sv.alpha, sv.beta, sv.mc, d.E};
+                            d.feat_scale ? p->high_freq_scalar : nullptr, sv.alpha, sv.beta, sv.mc, d.E, sv.wout_s, d.dtype};
         TRY(wviews(d, 4, src, dst, n, out, st, &prep));
         win_c = out[0]; wout_c = out[1]; w1_c = out[2]; w2_c = out[3];
     }
@@ -646,7 +659,7 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
         TRY(bf_frame_scale(d.dtype, dx1, drop_att, 1, sc.e5, d.N, (int)d.S, d.E, st));
         dbr = sc.e5;
     }
-    TRY(outproj_bwd(d, sc, dbr, sv.on, wout_c, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att,
+    TRY(outproj_bwd(d, sc, dbr, sv.on, sv.wout_s, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att,
                     d.feat_scale ? p->low_freq_scalar : nullptr, d.feat_scale ? p->high_freq_scalar : nullptr, sv.alpha, sv.mc,
                     g->output_head_w, g->output_head_b, g->norm2_b, g->gamma_att, d.feat_scale ? g->low_freq_scalar : nullptr,
                     d.feat_scale ? g->high_freq_scalar : nullptr, don, st, fk));
