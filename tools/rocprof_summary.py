@@ -38,7 +38,8 @@ def normalise(name: str) -> str:
         ax, bx, ap, bp, tm = m.groups()
         return "gemm_wide_kernel<bf16,%s,%s,pro%s,tm%s>" % ("xc" if ax == "true" else "kc", "xc" if bx == "true" else "kc",
                                                            "A" if ap == "true" else "B" if bp == "true" else "0", tm)
-    for key in ("in_bwd_slice_kernel", "in_stats_slice_kernel", "in_stats_merge_kernel", "in_slice_sum_kernel", "frame_table_kernel", "frame_wcolsum_kernel",
+    for key in ("frame_scale_kernel", "stage_param_reduce_kernel", "stage_prep_kernel", "clip_gather_kernel", "eikonal_kernel", "heatflux_kernel",
+                "lion_kernel", "in_bwd_slice_kernel", "in_stats_slice_kernel", "in_stats_merge_kernel", "in_slice_sum_kernel", "frame_table_kernel", "frame_wcolsum_kernel",
                 "cast4_kernel", "lploss_finalize_kernel", "fill_kernel"):
         if key in name:
             return key
