@@ -216,7 +216,6 @@ __global__ void frame_table_kernel(const float* __restrict__ m, int fdiv, const 
     const int f = (int)(i / C), c = (int)(i % C);
     out[i] = m[f / fdiv] * (v ? v[c] : 1.f);
 }
-__global__ void fill_kernel(float* p, float v, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
 
 // up to four plain fp32 -> bf16 weight casts in ONE launch (a stage's projection weights)
 struct Cast4 { const float* src[4]; bf16* dst[4]; long n[4]; };
@@ -262,12 +261,6 @@ int wviews(const D& d, int cnt, const float* const* src, void* const* dst, const
     return 0;
 }
 
-// compute-dtype view of an fp32 weight: cast in bf16 mode, alias in f32 mode
-int wview(const D& d, int mode, const float* src, void* dst, int R, int K, int Kp, const void** out, hipStream_t st) {
-    if (d.dtype == BF_DTYPE_F32 && mode == 0 && Kp == K) { *out = src; return 0; }
-    *out = dst;
-    return bf_wprep(d.dtype, mode, src, dst, R, K, Kp, st);
-}
 
 // ------------------------------------------------------------------------------------------------ saved-record layouts
 struct TemporalSaved {
@@ -393,11 +386,6 @@ int launch_reduce_jobs(ReduceJobs& J, hipStream_t st) {
     return 0;
 }
 
-int launch_fill(float* p, float v, int n, hipStream_t st) {
-    hipLaunchKernelGGL(fill_kernel, dim3(bf_cdiv(n, 256)), dim3(256), 0, st, p, v, n);
-    BF_CHECK_LAUNCH();
-    return 0;
-}
 
 // QKV projection + attention shared pieces -------------------------------------------------------
 // The InstanceNorm'd operand is materialised by the statistics kernel itself (bf_in_stats_apply: the frame is in registers there),
@@ -519,7 +507,6 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
     TemporalSaved sv(d, saved);
     Scratch sc(d, scratch);
     const void* win_c = d.dtype == BF_DTYPE_F32 ? (const void*)p->input_head_w : sv.win_c;
-    const void* wout_c = d.dtype == BF_DTYPE_F32 ? (const void*)p->output_head_w : sv.wout_c;
     Fork fk(st);            // weight-gradient GEMMs go to the side stream; nothing they read (dbr, t3, s1) is rewritten before the join
     void* don = sc.t1;      // [N][E]
     void* dO = sc.t1b;      // [N][E]
@@ -619,7 +606,6 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     Scratch sc(d, scratch);
     const bool f32 = d.dtype == BF_DTYPE_F32;
     const void* win_c = f32 ? (const void*)p->input_head_w : sv.win_c;
-    const void* wout_c = f32 ? (const void*)p->output_head_w : sv.wout_c;
     const void* w1_c = f32 ? (const void*)p->fc1_w : sv.w1_c;
     const void* w2_c = f32 ? (const void*)p->fc2_w : sv.w2_c;
     // weight-gradient GEMMs go to the side stream and are joined at the end; every buffer they read (dz = t1, dpre = t4,
