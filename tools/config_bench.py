@@ -16,9 +16,9 @@ CFG = dict(input_fields=4, output_fields=4, patch_size=16, embed_dim=384, num_he
 dev = torch.device("cuda")
 
 
-def train_rate(B, T, H, W, steps=10, warm=3):
+def train_rate(B, T, H, W, steps=10, warm=3, cfg=CFG):
     torch.manual_seed(0)
-    m = get_model("filmavit", time_window=T, drop_path=0.2, **CFG).to(dev).train()
+    m = get_model("filmavit", time_window=T, drop_path=0.2, **cfg).to(dev).train()
     step = TrainStep(m)
     x = torch.randn(B, T, 4, H, W, device=dev)
     y = torch.randn(B, T, 4, H, W, device=dev)
@@ -66,3 +66,6 @@ if __name__ == "__main__":
         r, ms = train_rate(B, 32, 384, 192)
         print(f"configs[3] train 32x384x192 bs {B}: {r:.1f} samples/s ({ms:.1f} ms/step)")
     print("configs[4] rollout 16x192x192 bs 1, ms/step:", rollout_ms())
+    big = dict(CFG, embed_dim=768, num_heads=12)        # config/model_cfg/film_avit_big.yaml
+    r, ms = train_rate(8, 16, 192, 192, cfg=big)
+    print(f"film_avit_big train 16x192x192 bs 8: {r:.1f} samples/s ({ms:.1f} ms/step)")
