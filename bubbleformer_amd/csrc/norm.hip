@@ -16,12 +16,52 @@ template <typename T, int CPB_ = CPB, int NT_ = NT> struct Geo {
     static constexpr int RG = NT_ / LC;    // row groups (a power of two: reduce_rows halves it)
 };
 
-// block-wide reduction of CH per-thread partials over the RG row groups; result valid in every thread
+// block-wide reduction of CH per-thread partials over the RG row groups; result valid in every thread.
+// When the chunk lanes tile a wavefront (LC a power of two <= 32) the row groups inside a wave are folded with lane permutes
+// (row rotate by 8, then the gfx950 row / half swaps for lanes ^16 and ^32 -- VALU only), and the waves meet once in LDS: two
+// barriers per reduction instead of two per tree level.
+__device__ __forceinline__ float lane_xor_add(float v, int o) {
+    if (o == 8) return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));   // row_ror:8
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const unsigned u = __float_as_uint(v);
+    const u2 r = o == 16 ? __builtin_amdgcn_permlane16_swap(u, u, false, false) : __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 template <typename T, int NV, int CPB_ = CPB, int NT_ = NT>
 __device__ __forceinline__ void reduce_rows(float (&v)[NV][Chunk<T>::N], float* sm) {
     constexpr int CH = Chunk<T>::N, LC = Geo<T, CPB_, NT_>::LC, RG = Geo<T, CPB_, NT_>::RG;
     static_assert((RG & (RG - 1)) == 0 && LC * RG == NT_, "row groups must be a power of two and fill the block");
     const int tid = threadIdx.x, lc = tid % LC, rg = tid / LC;
+    if constexpr ((LC == 8 || LC == 16 || LC == 32) && NT_ % 64 == 0) {
+        constexpr int NW = NT_ / 64;
+        const int wave = tid >> 6;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                float x = v[q][j];
+                if (LC <= 8) x = lane_xor_add(x, 8);
+                if (LC <= 16) x = lane_xor_add(x, 16);
+                x = lane_xor_add(x, 32);
+                v[q][j] = x;
+            }
+            __syncthreads();                       // previous use of sm is over
+            if ((tid & 63) < LC) {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) sm[(wave * LC + lc) * CH + j] = v[q][j];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) t += sm[(w * LC + lc) * CH + j];
+                v[q][j] = t;
+            }
+        }
+        __syncthreads();
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
         __syncthreads();

@@ -214,22 +214,23 @@ __global__ void film_net_bwd_kernel(const float* __restrict__ dgb_, const float*
     const int o0 = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = o0 < E2;                 // no early return: the wave reductions below need every lane
     const int o = valid ? o0 : 0;
-    float sb = 0.f;
-    for (int b = 0; b < B; ++b) sb += dgb_[(long)(o / E) * B * E + (long)b * E + (o % E)];
-    if (valid) dbias[o] += sb;
+    // fp64 accumulation: the LayerNorm(P) gradients are sums of 2E signed terms that largely cancel, and the kernel is tiny
+    double sb = 0.0;
+    for (int b = 0; b < B; ++b) sb += (double)dgb_[(long)(o / E) * B * E + (long)b * E + (o % E)];
+    if (valid) dbias[o] += (float)sb;
     for (int i = 0; i < P; ++i) {
-        float acc = 0.f, sw = 0.f, sbias = 0.f;
-        const float w = W[(long)o * P + i];
+        double acc = 0.0, sw = 0.0, sbias = 0.0;
+        const double w = W[(long)o * P + i];
         for (int b = 0; b < B; ++b) {
-            const float dg = valid ? dgb_[(long)(o / E) * B * E + (long)b * E + (o % E)] : 0.f;
-            acc += dg * (chat[b * P + i] * lnw[i] + lnb[i]);
+            const double dg = valid ? (double)dgb_[(long)(o / E) * B * E + (long)b * E + (o % E)] : 0.0;
+            acc += dg * ((double)chat[b * P + i] * lnw[i] + lnb[i]);
             sw += dg * w * chat[b * P + i];
             sbias += dg * w;
         }
-        if (valid) dW[(long)o * P + i] += acc;
-        sw = wave_sum(sw);
-        sbias = wave_sum(sbias);
-        if ((threadIdx.x & 63) == 0) { atomicAdd(dlnw + i, sw); atomicAdd(dlnb + i, sbias); }
+        if (valid) dW[(long)o * P + i] += (float)acc;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { sw += __shfl_xor(sw, off, 64); sbias += __shfl_xor(sbias, off, 64); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(dlnw + i, (float)sw); atomicAdd(dlnb + i, (float)sbias); }
     }
 }
 
