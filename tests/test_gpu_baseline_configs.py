@@ -36,11 +36,13 @@ def _weights(seed, cfg=None):
     return Wt.generate(Wt.param_shapes(**(cfg or SMALL)), seed=seed)
 
 
-def _oracle(B, T, H, W, seed, grads=True):
+def _oracle(B, T, H, W, seed, grads=True, dtype=torch.float32):
+    """dtype = float64 for the fp32-mode comparisons: the same fp32 values evaluated in double, so that the oracle's own rounding
+    (a few 1e-5 on cancellation-prone families such as FiLM's LayerNorm(9) at full depth) stays out of a 1e-4 tolerance."""
     from oracle import filmavit_ref as R
     torch.set_num_threads(16)
-    sd = {k: v.requires_grad_(grads) for k, v in _weights(seed).items()}
-    x, y, c = _inputs(B, T, H, W, seed)
+    sd = {k: v.to(dtype).requires_grad_(grads) for k, v in _weights(seed).items()}
+    x, y, c = (t.to(dtype) for t in _inputs(B, T, H, W, seed))
     x.requires_grad_(grads)
     with torch.set_grad_enabled(grads):
         pred = R.filmavit_forward(sd, x, c, patch_size=16, num_heads=6)
@@ -92,7 +94,7 @@ def _compare(prod, orac, dtype):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_config0_8x96x96_bs2(dtype):
     B, T, H, W, seed = 2, 8, 96, 96, 11
-    _compare(_product(B, T, H, W, seed, dtype), _oracle(B, T, H, W, seed), dtype)
+    _compare(_product(B, T, H, W, seed, dtype), _oracle(B, T, H, W, seed, dtype=torch.float64 if dtype == torch.float32 else torch.float32), dtype)
 
 
 def test_config1_full_resolution_sample_bf16():
@@ -103,7 +105,7 @@ def test_config1_full_resolution_sample_bf16():
 def test_config3_long_aspect_32x384x192_fp32():
     """24 x 12 tokens, T = 32: temporal and axial-H attention take the two-block (L > 16) paths at full model width."""
     B, T, H, W, seed = 1, 32, 384, 192, 13
-    _compare(_product(B, T, H, W, seed, torch.float32), _oracle(B, T, H, W, seed), torch.float32)
+    _compare(_product(B, T, H, W, seed, torch.float32), _oracle(B, T, H, W, seed, dtype=torch.float64), torch.float32)
 
 
 def test_config1_bench_size_properties():
