@@ -422,6 +422,9 @@ __global__ void __launch_bounds__(NT) in_bwd_kernel(const T* __restrict__ dy, co
 
 // Long frames, as for the statistics: phase 0 reduces {s1, s2} per slice into part[(f * nsl + sl) * C + c], in_slice_sum_kernel
 // adds the slices into ws[f][c], phase 1 applies over the same slices (grid = frames * slices x channel blocks).
+// A slice is BREP batches of RG * MAXR rows: the per-channel constants (mean, rstd, w, b, totals, scale: ~7 x CH loads per thread)
+// are fetched once per slice, which matters because a batch is only MAXR chunks of payload per thread.
+constexpr int BREP = 4;
 template <typename T, bool GELU, int PHASE, int CPB_, int NT_>
 __global__ void __launch_bounds__(NT_) in_bwd_slice_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ add,
                                                          T* __restrict__ dx, int S, int C, int nsl, const float* __restrict__ mean,
@@ -434,7 +437,7 @@ __global__ void __launch_bounds__(NT_) in_bwd_slice_kernel(const T* __restrict__
     const int tid = threadIdx.x, lc = tid % LC, rg = tid / LC;
     const int c = c0 + lc * CH;
     const bool cv = c < C;
-    const int s0 = sl * (RG * MAXR), n = min(S - s0, RG * MAXR);
+    const int s0 = sl * (RG * MAXR * BREP), n = min(S - s0, RG * MAXR * BREP);
     const long base = ((long)f * S + s0) * C + c;
     float mu[CH], rs[CH], ww[CH], bb[CH];
 #pragma unroll
@@ -444,50 +447,30 @@ __global__ void __launch_bounds__(NT_) in_bwd_slice_kernel(const T* __restrict__
         ww[j] = cv ? w[c + j] : 0.f;
         bb[j] = cv ? b[c + j] : 0.f;
     }
-    Chunk<T> kd[MAXR], kx[MAXR], ka[MAXR];
+    float acc[2][CH], t1[CH], t2[CH], gg[CH];
 #pragma unroll
-    for (int q = 0; q < MAXR; ++q) {            // all loads of the slice in flight before the first use
-        const int r = rg + RG * q;
-        if (cv && r < n) {
-            kd[q].load(dy + base + (long)r * C);
-            kx[q].load(x + base + (long)r * C);
-            if (PHASE == 1 && add) ka[q].load(add + base + (long)r * C);
-        } else { kd[q].zero(); kx[q].zero(); }
+    for (int j = 0; j < CH; ++j) {
+        acc[0][j] = acc[1][j] = 0.f;
+        t1[j] = (PHASE == 1 && cv) ? tot[((long)f * C + c + j) * 2] / (float)S : 0.f;
+        t2[j] = (PHASE == 1 && cv) ? tot[((long)f * C + c + j) * 2 + 1] / (float)S : 0.f;
+        gg[j] = (PHASE == 1 && cv && g) ? g[(long)(f / gdiv) * C + c + j] : 1.f;
     }
-    if constexpr (PHASE == 0) {
-        float acc[2][CH];
+    for (int it = 0; it < BREP; ++it) {
+        const int r0 = it * (RG * MAXR);
+        if (r0 >= n) break;
+        Chunk<T> kd[MAXR], kx[MAXR], ka[MAXR];
 #pragma unroll
-        for (int j = 0; j < CH; ++j) acc[0][j] = acc[1][j] = 0.f;
-#pragma unroll
-        for (int q = 0; q < MAXR; ++q) {
-            if (rg + RG * q < n) {
-#pragma unroll
-                for (int j = 0; j < CH; ++j) {
-                    const float xh = (kx[q].get(j) - mu[j]) * rs[j];
-                    float dd = kd[q].get(j);
-                    if (GELU) dd *= dgelu_f(xh * ww[j] + bb[j]);
-                    acc[0][j] += dd;
-                    acc[1][j] += dd * xh;
-                }
-            }
-        }
-        reduce_rows<T, 2, CPB_, NT_>(acc, sm);
-        if (cv && rg == 0) {
-            float* o = part + (((long)f * nsl + sl) * C + c) * 2;
-#pragma unroll
-            for (int j = 0; j < CH; ++j) { o[2 * j] = acc[0][j]; o[2 * j + 1] = acc[1][j]; }
-        }
-    } else {
-        float t1[CH], t2[CH], gg[CH];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            t1[j] = cv ? tot[((long)f * C + c + j) * 2] / (float)S : 0.f;
-            t2[j] = cv ? tot[((long)f * C + c + j) * 2 + 1] / (float)S : 0.f;
-            gg[j] = (cv && g) ? g[(long)(f / gdiv) * C + c + j] : 1.f;
+        for (int q = 0; q < MAXR; ++q) {            // all loads of the batch in flight before the first use
+            const int r = r0 + rg + RG * q;
+            if (cv && r < n) {
+                kd[q].load(dy + base + (long)r * C);
+                kx[q].load(x + base + (long)r * C);
+                if (PHASE == 1 && add) ka[q].load(add + base + (long)r * C);
+            } else { kd[q].zero(); kx[q].zero(); }
         }
 #pragma unroll
         for (int q = 0; q < MAXR; ++q) {
-            const int r = rg + RG * q;
+            const int r = r0 + rg + RG * q;
             if (cv && r < n) {
                 Chunk<T> o;
 #pragma unroll
@@ -495,12 +478,23 @@ __global__ void __launch_bounds__(NT_) in_bwd_slice_kernel(const T* __restrict__
                     const float xh = (kx[q].get(j) - mu[j]) * rs[j];
                     float dd = kd[q].get(j);
                     if (GELU) dd *= dgelu_f(xh * ww[j] + bb[j]);
-                    float t = rs[j] * ww[j] * gg[j] * (dd - t1[j] - xh * t2[j]);
-                    if (add) t += ka[q].get(j);
-                    o.set(j, t);
+                    if (PHASE == 0) { acc[0][j] += dd; acc[1][j] += dd * xh; }
+                    else {
+                        float t = rs[j] * ww[j] * gg[j] * (dd - t1[j] - xh * t2[j]);
+                        if (add) t += ka[q].get(j);
+                        o.set(j, t);
+                    }
                 }
-                o.store(dx + base + (long)r * C);
+                if (PHASE == 1) o.store(dx + base + (long)r * C);
             }
+        }
+    }
+    if constexpr (PHASE == 0) {
+        reduce_rows<T, 2, CPB_, NT_>(acc, sm);
+        if (cv && rg == 0) {
+            float* o = part + (((long)f * nsl + sl) * C + c) * 2;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) { o[2 * j] = acc[0][j]; o[2 * j + 1] = acc[1][j]; }
         }
     }
 }
@@ -688,7 +682,7 @@ static int in_bwd_impl(int dtype, const void* dy, const void* x, const void* add
     BfProfScope prof(st, "in_bwd", 0.0, (double)frames * S * C * bf_esize(dtype) * (add ? 4.0 : 3.0));
     const SliceCfg cfg = slice_cfg(dtype, S, C);
     if (ws && cfg.sliced) {                       // long frames: slice reduce -> sum -> slice apply
-        const int nsl = bf_cdiv(S, cfg.rows);
+        const int nsl = bf_cdiv(S, cfg.rows * BREP);
         BF_REQUIRE((long)frames * nsl < 2147483647L, "bf_in_bwd: grid too large");
         float* part = ws + (size_t)2 * frames * C;
 #define GOS(T, G, CP, TH)                                                                                                                \
