@@ -70,8 +70,11 @@ SIGNATURES = {
     "bf_abi_version": (C.c_int, []),
     "bf_prof_enable": (None, [C.c_int]),
     "bf_debug_force_generic_attn": (None, [C.c_int]),
+    "bf_side_defer": (None, [C.c_int]),
+    "bf_side_join": (C.c_int, [vp]),
     "bf_prof_report": (C.c_int, [C.c_char_p, C.c_int]),
     "bf_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, P(Operand), P(Operand), P(Epilogue), C.c_int, vp]),
+    "bf_gemm_inbwd_frames": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, vp, vp, vp, C.c_int, fp, fp, fp, fp, vp]),
     "bf_in_stats": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, fp, fp, fp, C.c_int, fp, fp, fp, fp, fp, fp, vp]),
     "bf_in_ws_floats": (i64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "bf_affine_apply": (C.c_int, [C.c_int, vp, vp, fp, fp, vp, i64, C.c_int, C.c_int, vp]),

@@ -93,7 +93,11 @@ int splitk_for(int M, int N, long K) {
 // still sees plain stream-ordered semantics on ITS stream (and the fork/join pattern is hipGraph-capturable).
 // BF_SIDE_STREAM=0 runs everything on the caller's stream.  The launch profiler times each kernel with events on the stream it was
 // launched on, so its per-kernel durations are the contended ones of the real schedule (they agree with a rocprofv3 trace).
-struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool failed = false; };
+struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr, tail = nullptr; bool failed = false; bool pending = false; };
+// bf_side_defer(1): a trunk stage's backward returns without waiting for its LAST weight-gradient GEMM (everything forked before it
+// is joined as usual); the wait is enqueued by the next stage right before it first overwrites what that GEMM reads (the dqkv
+// scratch), by every other stage entry point at its start, or by bf_side_join().  Off by default: plain stream-ordered semantics.
+bool g_side_defer = false;
 SideStream* side_stream() {
     static SideStream tab[64];
     static const bool enabled = []() { const char* v = getenv("BF_SIDE_STREAM"); return !(v && atoi(v) == 0); }();
@@ -107,13 +111,31 @@ SideStream* side_stream() {
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // lo = least urgent (numerically greatest)
         const int prio = prio_env == 1 ? lo : prio_env == 2 ? hi : 0;
         if (hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) { s.failed = true; s.st = nullptr; }
+            hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.tail, hipEventDisableTiming) != hipSuccess) { s.failed = true; s.st = nullptr; }
     }
     return s.st ? &s : nullptr;
 }
+// the previous stage's deferred tail (if any) is ordered before what `main` is given next
+int side_join_pending(hipStream_t main) {
+    SideStream* s = side_stream();
+    if (s && s->pending) {
+        HIP_TRY(hipStreamWaitEvent(main, s->tail, 0));
+        s->pending = false;
+    }
+    return 0;
+}
 struct Fork {
-    hipStream_t main; SideStream* s; bool used = false;
+    hipStream_t main; SideStream* s; bool used = false, marked = false;
     explicit Fork(hipStream_t m) : main(m), s(side_stream()) {}
+    // call before the stage's last begin(): what has been forked so far gets its own completion event, so that join() may leave
+    // only the last item outstanding (deferred mode)
+    int mark() {
+        if (!s || !used || !g_side_defer) return 0;
+        HIP_TRY(hipEventRecord(s->join, s->st));
+        marked = true;
+        return 0;
+    }
     // stream for work that depends only on what has been issued on `main` so far
     int begin(hipStream_t* out) {
         *out = main;
@@ -127,9 +149,15 @@ struct Fork {
     // everything forked so far is ordered before what `main` is given next
     int join() {
         if (!s || !used) return 0;
-        HIP_TRY(hipEventRecord(s->join, s->st));
-        HIP_TRY(hipStreamWaitEvent(main, s->join, 0));
-        used = false;
+        if (marked) {                                    // deferred: wait for all but the last item now, the last one later
+            HIP_TRY(hipStreamWaitEvent(main, s->join, 0));
+            HIP_TRY(hipEventRecord(s->tail, s->st));
+            s->pending = true;
+        } else {
+            HIP_TRY(hipEventRecord(s->join, s->st));
+            HIP_TRY(hipStreamWaitEvent(main, s->join, 0));
+        }
+        used = false; marked = false;
         return 0;
     }
 };
@@ -407,11 +435,23 @@ int outproj_gemm(const D& d, const void* on, const void* w_c, const float* alpha
     e.rowscale = drop; e.rows_per_group = (int)rows_per_group;
     return bf_gemm(d.dtype, (int)d.N, d.E, d.E, &A, &Bo, &e, 1, st);
 }
+// A data gradient dy @ W whose consumer is the backward of the InstanceNorm that fed the projection: when a frame is one
+// 144-row GEMM tile the two run as ONE kernel (gemm_frame.hip); otherwise GEMM into `tmp`, then the InstanceNorm backward.
+struct InFuse { const void* x; const void* add; void* dx; const float* mean; const float* rstd; const float* w; const float* b; float* ws; };
+int dgrad_inbwd(const D& d, const void* dy, int Kdim, const void* w_xc, int Nout, void* tmp, const InFuse& f, hipStream_t st) {
+    const int rc = bf_gemm_inbwd_frames(d.dtype, (int)d.N, Nout, Kdim, dy, Kdim, w_xc, Nout, f.x, f.add, f.dx, (int)d.S, f.mean, f.rstd, f.w, f.ws, st);
+    if (rc <= 0) return rc;
+    bf_operand A = op_plain(dy, Kdim, BF_LAY_KC);
+    bf_operand Bo = op_plain(w_xc, Nout, BF_LAY_XC);
+    bf_epilogue e = epi_store(tmp, Nout);
+    TRY(bf_gemm(d.dtype, (int)d.N, Nout, Kdim, &A, &Bo, &e, 1, st));
+    return bf_in_bwd_partials(d.dtype, tmp, f.x, f.add, f.dx, (int)d.F, (int)d.S, Nout, f.mean, f.rstd, f.w, f.b, nullptr, 1, 0, f.ws, st);
+}
 // backward of the folded out-projection: param grads + don = (dout * alpha) @ W
 int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on, const void* w_s,
                 const float* W, const float* bias, const float* nb, const float* gamma, const float* lo, const float* hi,
                 const float* alpha, const float* mc, float* dW, float* dbias, float* dnb, float* dgamma, float* dlo, float* dhi,
-                void* don, hipStream_t st, Fork& fk) {
+                void* don, hipStream_t st, Fork& fk, const InFuse* fu = nullptr) {
     hipStream_t ss;                                   // parameter-gradient side: memset, G GEMM, finalize
     TRY(fk.begin(&ss));
     ZERO_ON(ss, sc.G, (size_t)((char*)sc.csum - (char*)sc.G) + (size_t)d.E * 4);     // G and csum are adjacent in the arena: one memset
@@ -425,6 +465,7 @@ int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on,
     hipLaunchKernelGGL(outproj_finalize_kernel, dim3(d.E), dim3(256), 0, ss, sc.G, sc.csum, W, bias, nb, gamma, lo, hi, mc, dW, dbias, dnb,
                        dgamma, dlo, dhi, d.E);
     BF_CHECK_LAUNCH();
+    if (fu) return dgrad_inbwd(d, dout, d.E, w_s, d.E, don, *fu, st);      // ... followed by norm2's backward
     {   // don = (dout * alpha) @ W = dout @ (diag(alpha) W): the scaled weight was written by the forward's parameter prep
         bf_operand A = op_plain(dout, d.E, BF_LAY_KC);
         bf_operand Bo = op_plain(w_s, d.E, BF_LAY_XC);
@@ -435,7 +476,7 @@ int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on,
 }
 // backward of y = affine(x) @ W^T + b:  dW += dy^T affine(x), db += colsum(dy), dxn = dy @ W
 int linear_bwd(const D& d, const Scratch& sc, const void* dy, int Nout, const void* x, int Kin, int xpro, const float* xsc, const float* xsh,
-               const void* w_c, float* dW, float* db, void* dxn, const bf_epilogue* dx_epi, hipStream_t st, Fork& fk) {
+               const void* w_c, float* dW, float* db, void* dxn, const bf_epilogue* dx_epi, hipStream_t st, Fork& fk, const InFuse* fu = nullptr) {
     {
         hipStream_t ss;                          // weight gradient: side stream
         TRY(fk.begin(&ss));
@@ -452,6 +493,7 @@ int linear_bwd(const D& d, const Scratch& sc, const void* dy, int Nout, const vo
         e.colsum = db;                       // bias gradient = colsum(dy), fused into the same pass over dy
         TRY(bf_gemm(d.dtype, Nout, Kin, (int)d.N, &A, &Bo, &e, splitk_for(Nout, Kin, d.N), ss));
     }
+    if (fu) return dgrad_inbwd(d, dy, Nout, w_c, Kin, dxn, *fu, st);
     {
         bf_operand A = op_plain(dy, Nout, BF_LAY_KC);
         bf_operand Bo = op_plain(w_c, Kin, BF_LAY_XC);
@@ -469,12 +511,17 @@ extern "C" int64_t bf_temporal_saved_bytes(const bf_dims* s) { D d; if (get_dims
 extern "C" int64_t bf_spatial_saved_bytes(const bf_dims* s) { D d; if (get_dims(s, &d)) return -1; return (int64_t)SpatialSaved(d, nullptr).bytes; }
 extern "C" int64_t bf_scratch_bytes(const bf_dims* s) { D d; if (get_dims(s, &d)) return -1; return (int64_t)Scratch(d, nullptr).bytes; }
 
+// Deferred weight-gradient tails (see SideStream): opt-in for callers that join explicitly before they consume parameter gradients
+extern "C" void bf_side_defer(int on) { g_side_defer = on != 0; }
+extern "C" int bf_side_join(bf_stream_t s) { return side_join_pending((hipStream_t)s); }
+
 // ================================================================================================= temporal block
 extern "C" int bf_temporal_fwd(const bf_dims* dims, const bf_temporal_params* p, const void* x, void* out, void* saved, void* scratch,
                                const float* drop, bf_stream_t s) {
     D d; TRY(get_dims(dims, &d));
     BF_REQUIRE(p && x && out && saved && scratch, "bf_temporal_fwd: null pointer");
     hipStream_t st = (hipStream_t)s;
+    TRY(side_join_pending(st));
     TemporalSaved sv(d, saved);
     Scratch sc(d, scratch);
     const void *win_c, *wout_c;
@@ -516,11 +563,12 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
         TRY(bf_frame_scale(d.dtype, dout, drop, d.T, sc.t4, d.N, (int)d.S, d.E, st));
         dbr = sc.t4;
     }
+    const InFuse fu2{sv.o, nullptr, dO, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, sc.in_ws2};      // don @ ... then norm2's backward -> dO
     TRY(outproj_bwd(d, sc, dbr, sv.on, sv.wout_s, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr,
-                    sv.alpha, sv.mc, g->output_head_w, g->output_head_b, nullptr, g->gamma, nullptr, nullptr, don, st, fk));
+                    sv.alpha, sv.mc, g->output_head_w, g->output_head_b, nullptr, g->gamma, nullptr, nullptr, don, st, fk, &fu2));
     ReduceJobs jobs;        // parameter-gradient reductions, all launched together at the end
-    TRY(bf_in_bwd_partials(d.dtype, don, sv.o, nullptr, dO, (int)d.F, (int)d.S, d.E, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, nullptr, 1, 0, sc.in_ws2, st));
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws2, (int)d.F, d.E, p->norm2_w, p->norm2_b, nullptr, 1, g->norm2_w, g->norm2_b, nullptr, nullptr, nullptr, nullptr};
+    TRY(side_join_pending(st));     // the previous stage's last weight-gradient GEMM reads the dqkv scratch
     {
         int rows = 0;
         TRY(bf_attn_bwd_partials(d.dtype, sv.qkv, dO, dqkv, (long)d.B * d.S, d.T, d.S, (long)d.T * d.S, 1, d.S, d.heads, d.d, p->qnorm_w, p->qnorm_b,
@@ -531,8 +579,9 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
                                                d.attn_scale ? g->attn_scale_factor : nullptr};
     }
     void* dxn = sc.t1;      // don is dead
-    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, sv.xn, d.E, BF_PRO_NONE, nullptr, nullptr, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk));
-    TRY(bf_in_bwd_partials(d.dtype, dxn, x, dout, dx, (int)d.F, (int)d.S, d.E, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, nullptr, 1, 0, sc.in_ws, st));
+    const InFuse fu1{x, dout, dx, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, sc.in_ws};             // dqkv @ W_in, then norm1's backward + residual
+    TRY(fk.mark());
+    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, sv.xn, d.E, BF_PRO_NONE, nullptr, nullptr, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk, &fu1));
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws, (int)d.F, d.E, p->norm1_w, p->norm1_b, nullptr, 1, g->norm1_w, g->norm1_b, nullptr, nullptr, nullptr, nullptr};
     TRY(launch_reduce_jobs(jobs, st));
     return fk.join();
@@ -544,6 +593,7 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
     D d; TRY(get_dims(dims, &d));
     BF_REQUIRE(p && x && out && saved && scratch, "bf_spatial_fwd: null pointer");
     hipStream_t st = (hipStream_t)s;
+    TRY(side_join_pending(st));
     SpatialSaved sv(d, saved);
     Scratch sc(d, scratch);
     const void *win_c, *wout_c, *w1_c, *w2_c;
@@ -645,14 +695,15 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
         TRY(bf_frame_scale(d.dtype, dx1, drop_att, 1, sc.e5, d.N, (int)d.S, d.E, st));
         dbr = sc.e5;
     }
+    void* dO = sc.e7;       // [N][E]
+    const InFuse fu2{sv.o, nullptr, dO, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, sc.in_ws2};      // don @ ... then norm2's backward -> dO
     TRY(outproj_bwd(d, sc, dbr, sv.on, sv.wout_s, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att,
                     d.feat_scale ? p->low_freq_scalar : nullptr, d.feat_scale ? p->high_freq_scalar : nullptr, sv.alpha, sv.mc,
                     g->output_head_w, g->output_head_b, g->norm2_b, g->gamma_att, d.feat_scale ? g->low_freq_scalar : nullptr,
-                    d.feat_scale ? g->high_freq_scalar : nullptr, don, st, fk));
-    void* dO = sc.e7;       // [N][E]
-    TRY(bf_in_bwd_partials(d.dtype, don, sv.o, nullptr, dO, (int)d.F, (int)d.S, d.E, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, nullptr, 1, 0, sc.in_ws2, st));
+                    d.feat_scale ? g->high_freq_scalar : nullptr, don, st, fk, &fu2));
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws2, (int)d.F, d.E, p->norm2_w, p->norm2_b, nullptr, 1, g->norm2_w, g->norm2_b, nullptr, nullptr, nullptr, nullptr};
     void* dqkv = sc.t3;
+    TRY(side_join_pending(st));     // the previous stage's last weight-gradient GEMM reads the dqkv scratch
     {
         int rows = 0;
         TRY(bf_attn_bwd_partials(d.dtype, sv.qkv, dO, dqkv, d.F * d.h, d.w, 1, d.w, 0, 1, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
@@ -667,8 +718,9 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
                                                d.attn_scale ? g->attn_scale_factor_y : nullptr};
     }
     void* dxn = sc.e6;      // don is dead (it was only read on this stream)
-    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, sv.xn, d.E, BF_PRO_NONE, nullptr, nullptr, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk));
-    TRY(bf_in_bwd_partials(d.dtype, dxn, x, dx1, dx, (int)d.F, (int)d.S, d.E, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, nullptr, 1, 0, sc.in_ws, st));
+    const InFuse fu1{x, dx1, dx, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, sc.in_ws};              // dqkv @ W_in, then norm1's backward + residual
+    TRY(fk.mark());
+    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, sv.xn, d.E, BF_PRO_NONE, nullptr, nullptr, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk, &fu1));
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws, (int)d.F, d.E, p->norm1_w, p->norm1_b, nullptr, 1, g->norm1_w, g->norm1_b, nullptr, nullptr, nullptr, nullptr};
     TRY(launch_reduce_jobs(jobs, st));
     return fk.join();
@@ -745,6 +797,7 @@ extern "C" int bf_embed_fwd(const bf_dims* dims, const bf_embed_params* p, const
     BF_REQUIRE(p && x && out && saved && scratch && d.nst >= 1 && d.cin >= 1, "bf_embed_fwd: bad arguments");
     BF_REQUIRE((d.nfluid > 0) == (fluid != nullptr), "bf_embed_fwd: fluid parameters must be given exactly when nfluid > 0");
     hipStream_t st = (hipStream_t)s;
+    TRY(side_join_pending(st));
     EmbedSaved sv(d, saved);
     Scratch sc(d, scratch);
     const int n = d.nst, H = d.h * d.patch, W = d.w * d.patch;
@@ -784,6 +837,7 @@ extern "C" int bf_embed_bwd(const bf_dims* dims, const bf_embed_params* p, const
     D d; TRY(get_dims(dims, &d));
     BF_REQUIRE(p && g && dout && saved && scratch && d.nst >= 1, "bf_embed_bwd: bad arguments");
     hipStream_t st = (hipStream_t)s;
+    TRY(side_join_pending(st));
     EmbedSaved sv(d, saved);
     Scratch sc(d, scratch);
     const int n = d.nst, H = d.h * d.patch, W = d.w * d.patch;
@@ -858,6 +912,7 @@ extern "C" int bf_debed_fwd(const bf_dims* dims, const bf_debed_params* p, const
     BF_REQUIRE(p && x && pred && saved && scratch && d.nst >= 1 && d.cout >= 1, "bf_debed_fwd: bad arguments");
     BF_REQUIRE(!target || loss, "bf_debed_fwd: loss output missing");
     hipStream_t st = (hipStream_t)s;
+    TRY(side_join_pending(st));
     DebedSaved sv(d, saved);
     Scratch sc(d, scratch);
     const int n = d.nst;
@@ -896,6 +951,7 @@ extern "C" int bf_debed_bwd(const bf_dims* dims, const bf_debed_params* p, const
     BF_REQUIRE(p && g && x && dx && saved && scratch && d.nst >= 1, "bf_debed_bwd: bad arguments");
     BF_REQUIRE(dpred || (pred && target), "bf_debed_bwd: need dpred or (pred, target) of the fused loss");
     hipStream_t st = (hipStream_t)s;
+    TRY(side_join_pending(st));
     DebedSaved sv(d, saved);
     Scratch sc(d, scratch);
     const int n = d.nst;

@@ -43,6 +43,20 @@ def in_bwd(dy, x, frames, S, Cc, mean, rstd, w, b, add=None, g=None, gdiv=1, gel
     return dx, dw, db
 
 
+def gemm_inbwd_frames(A, B, x, S, mean, rstd, w, add=None):
+    """Fused data-gradient GEMM + InstanceNorm backward (whole-frame tiles): returns (dx, ws) or None when the shape is not covered."""
+    M, K = A.shape
+    N = B.shape[1]
+    out = torch.empty(M, N, dtype=x.dtype, device=x.device)
+    ws = torch.zeros((M // S) * N * 2, dtype=torch.float32, device=x.device)
+    rc = L.lib().bf_gemm_inbwd_frames(_dt(x.dtype), M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(x), _p(add), _p(out), S, _p(mean),
+                                      _p(rstd), _p(w), _p(ws), _stream())
+    if rc == 1:
+        return None
+    L.check(rc, "bf_gemm_inbwd_frames")
+    return out, ws
+
+
 def attn_fwd(qkv, out, nseq, Lq, inner, outer_stride, inner_stride, tok_stride, heads, d, qw, qb, kw, kb, emb, hscale, out_scale=1.0,
              accumulate=False):
     L.check(L.lib().bf_attn_fwd(_dt(qkv.dtype), _p(qkv), _p(out), nseq, Lq, inner, outer_stride, inner_stride, tok_stride, heads, d,

@@ -116,6 +116,8 @@ def _stage_grads(params: Sequence[Optional[torch.Tensor]]):
 
 
 def _stage_done(params, direct: bool) -> None:
+    if not direct:      # gradients go back through autograd on this stream: nothing of the stage may still be in flight on the side stream
+        L.check(L.lib().bf_side_join(_stream()), "bf_side_join")
     if direct and _DIRECT["on_ready"] is not None:
         _DIRECT["on_ready"]([p.data_ptr() for p in params if p is not None])
 

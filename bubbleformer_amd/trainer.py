@@ -56,6 +56,7 @@ class BucketReducer:
             self.count[b] += 1
         self.pending = [0] * nb
         self.handles = []
+        self.held = None          # direct-gradient mode: a complete bucket waits until the NEXT one is complete (see stage_ready)
         self.enabled = self.world > 1
         if self.enabled:
             for p, b in zip(flat.params, bucket_of):
@@ -63,13 +64,22 @@ class BucketReducer:
 
         self.bucket_of_ptr = {p.data_ptr(): b for p, b in zip(flat.params, bucket_of)}
 
-    def _arrived(self, b):
+    def _launch(self, b):
+        g = self.flat.grad[self.lo[b]:self.hi[b]]
+        self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _arrived(self, b, hold=False):
         self.pending[b] += 1
         if self.pending[b] == self.count[b]:
             self.pending[b] = 0
             if self.enabled:
-                g = self.flat.grad[self.lo[b]:self.hi[b]]
-                self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if self.held is not None:
+                    self._launch(self.held)
+                    self.held = None
+                if hold:
+                    self.held = b
+                else:
+                    self._launch(b)
 
     def _make_hook(self, b):
         def hook(_p):
@@ -77,12 +87,20 @@ class BucketReducer:
         return hook
 
     def stage_ready(self, ptrs):
-        """Direct-gradient mode: the stage's kernels (accumulating into the flat buffer) are enqueued on the current stream."""
+        """Direct-gradient mode: the stage's kernels (accumulating into the flat buffer) are enqueued on the current stream --
+        except possibly its last weight-gradient GEMM, which the library joins inside the next stage call (bf_side_defer).  A
+        complete bucket is therefore reduced when the next bucket completes, the last one in flush() after bf_side_join()."""
         for ptr in ptrs:
-            self._arrived(self.bucket_of_ptr[ptr])
+            self._arrived(self.bucket_of_ptr[ptr], hold=True)
+
+    def flush(self):
+        if self.held is not None:
+            self._launch(self.held)
+            self.held = None
 
     def wait(self) -> float:
         """Block the current stream on the outstanding buckets; returns the factor the optimizer must apply (1/world)."""
+        self.flush()
         for h in self.handles:
             h.wait()
         self.handles.clear()
@@ -127,12 +145,17 @@ class TrainStep:
         self.step_no = 0
 
     def __call__(self, x, fluid, target) -> torch.Tensor:
+        from . import _lib
+        h = _lib.lib()
         self.flat.zero_grad()
         self.ops.set_direct_grad_slots(self.slots, self.reducer.stage_ready)
+        h.bf_side_defer(1)          # a stage's last weight-gradient GEMM may run into the next stage; joined below
         try:
             loss = self._fwd_bwd(x, fluid, target)
         finally:
+            h.bf_side_defer(0)
             self.ops.set_direct_grad_slots(None)
+            _lib.check(h.bf_side_join(torch.cuda.current_stream().cuda_stream), "bf_side_join")
         gscale = self.reducer.wait()
         self.step_no += 1
         lr = self.scheduler.get_last_lr()[0] if self.scheduler is not None else self.lr

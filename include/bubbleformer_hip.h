@@ -94,6 +94,16 @@ typedef struct bf_epilogue {
 int bf_gemm(int dtype, int M, int N, int K, const bf_operand* A, const bf_operand* B, const bf_epilogue* E,
             int splitk, bf_stream_t stream);
 
+/* Data-gradient GEMM fused with the InstanceNorm backward that consumes it (whole-frame row tiles, gemm_frame.hip):
+ *   dy = A[M][K] @ B[K][N] (both row-major), frames of S consecutive rows; per (frame, column):
+ *   out = rstd*w*(dy - s1/S - xhat*s2/S) [+ add],  s1 = sum dy, s2 = sum dy*xhat, xhat = (x - mean)*rstd;  ws[(f*N+n)*2..] = {s1, s2}.
+ * Replaces the conv1x1 backward + InstanceNorm2d backward pair of layers/attention.py:77-78,120-121,208-210,298-299 (autograd).
+ * Returns 0 when done, 1 when the shape is not covered (bf16, S = 144, M % 144 = N % 128 = K % 64 = 0): the caller then runs
+ * bf_gemm + bf_in_bwd; < 0 on error. */
+int bf_gemm_inbwd_frames(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, const void* x,
+                         const void* add, void* out, int S, const float* mean, const float* rstd, const float* w, float* ws,
+                         bf_stream_t stream);
+
 /* ---------------------------------------------------------------- kernel-level entry points (unit-testable) */
 
 /* InstanceNorm statistics over the S tokens of each frame, per channel (two-pass, fp32):
@@ -131,6 +141,12 @@ int bf_attn_bwd(int dtype, const void* qkv, const void* dout, void* dqkv, int64_
                 bf_stream_t stream);
 
 /* test hook: route bf16 attention through the generic fp32-VALU kernel instead of the MFMA kernel */
+/* Weight-gradient GEMMs run on a library-owned side stream that every stage joins before it returns.  bf_side_defer(1) lets a
+ * temporal / spatial backward return with its LAST weight-gradient GEMM still in flight: the next stage call on the stream joins it
+ * (before it reuses what that GEMM reads), as does bf_side_join().  A caller that opts in must call bf_side_join(stream) before it
+ * reads parameter gradients outside the library (optimizer step, all-reduce of the stage's bucket).  Default: off. */
+void bf_side_defer(int on);
+int bf_side_join(bf_stream_t stream);
 void bf_debug_force_generic_attn(int on);
 
 int bf_im2col_nchw(int dtype, const float* x, void* out, int frames, int C, int H, int W, int Kp, bf_stream_t stream);

@@ -180,6 +180,43 @@ def test_in_bwd_matches_autograd(K, dtype, S, Cc, gelu):
     assert _rel(db.double(), br.grad) < tol
 
 
+@pytest.mark.parametrize("Kd,N,with_add", [(1152, 384, True), (384, 384, False), (64, 128, True), (1536, 256, False)])
+def test_gemm_inbwd_frames_matches_gemm_then_in_bwd(K, Kd, N, with_add):
+    """conv1x1 data gradient + InstanceNorm2d backward in one kernel (144-token frames) vs fp64 autograd and vs the two-kernel path."""
+    Fr, S = 5, 144
+    M = Fr * S
+    g = torch.Generator(device="cuda").manual_seed(21)
+    A = (torch.randn(M, Kd, device="cuda", generator=g) * 0.5).bfloat16()
+    W = (torch.randn(Kd, N, device="cuda", generator=g) / Kd ** 0.5).bfloat16()
+    x = (torch.randn(Fr, S, N, device="cuda", generator=g) * 1.5 + 0.3).bfloat16()
+    add = torch.randn(M, N, device="cuda", generator=g).bfloat16() if with_add else None
+    w = torch.randn(N, device="cuda", generator=g)
+    b = torch.randn(N, device="cuda", generator=g)
+    mean, rstd, _, _ = K.in_stats(x, Fr, S, N, w, b)
+    res = K.gemm_inbwd_frames(A, W, x.view(M, N), S, mean, rstd, w, add=add)
+    assert res is not None
+    dx, ws = res
+    torch.cuda.synchronize()
+    # fp64 autograd on the same (bf16-valued) operands
+    dy = A.double() @ W.double()
+    xr = x.double().requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    y = torch.nn.functional.instance_norm(xr.permute(0, 2, 1), weight=wr, bias=br, eps=1e-5).permute(0, 2, 1)
+    (y * dy.view(Fr, S, N)).sum().backward()
+    ref = xr.grad.view(M, N) + (add.double() if with_add else 0.0)
+    assert _rel(dx.double(), ref) < 6e-3                      # one bf16 rounding of the result
+    s = ws.view(Fr, N, 2).double()
+    assert _rel(s[..., 1].sum(0), wr.grad) < 2e-3 and _rel(s[..., 0].sum(0), br.grad) < 2e-3
+    # the two-kernel path rounds dy to bf16 in between: same answer to bf16 accuracy
+    dyb = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    K.gemm(torch.bfloat16, M, N, Kd, K.operand(A, Kd, K.L.BF_LAY_KC), K.operand(W, N, K.L.BF_LAY_XC), K.epilogue(dyb, N))
+    dx2, dw2, db2 = K.in_bwd(dyb.view(Fr, S, N), x, Fr, S, N, mean, rstd, w, b, add=add.view(Fr, S, N) if with_add else None)
+    assert _rel(dx.double(), dx2.view(M, N).double()) < 1.5e-2
+    # shapes outside the whole-frame form are refused, not mis-computed
+    assert K.gemm_inbwd_frames(A[:S * 2], W, x.view(M, N)[:S * 2], 72, mean, rstd, w) is None
+    assert K.gemm_inbwd_frames(A.float(), W.float(), x.view(M, N).float(), S, mean, rstd, w) is None
+
+
 def _attn_call(L_lib, qkv, dout, geo, heads, d, prm, generic):
     """Run attention fwd + bwd through the C ABI; returns (out, dqkv, param grads)."""
     import ctypes as C
