@@ -110,9 +110,12 @@ SideStream* side_stream() {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // lo = least urgent (numerically greatest)
         const int prio = prio_env == 1 ? lo : prio_env == 2 ? hi : 0;
-        if (hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s.tail, hipEventDisableTiming) != hipSuccess) { s.failed = true; s.st = nullptr; }
+        // the two streams are on one device: the events need no system-scope fence (an L2 write-back + invalidate at every fork / join;
+        // BF_EVENT_FENCE=1 restores it)
+        static const bool sysfence = []() { const char* v = getenv("BF_EVENT_FENCE"); return v && atoi(v) != 0; }();
+        const unsigned ef = hipEventDisableTiming | (sysfence ? 0u : hipEventDisableSystemFence);
+        if (hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&s.fork, ef) != hipSuccess ||
+            hipEventCreateWithFlags(&s.join, ef) != hipSuccess || hipEventCreateWithFlags(&s.tail, ef) != hipSuccess) { s.failed = true; s.st = nullptr; }
     }
     return s.st ? &s : nullptr;
 }
