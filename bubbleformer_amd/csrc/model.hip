@@ -12,6 +12,8 @@
 //    per-channel mean exactly norm2.bias, so mean_hw(y)[n] = W[n, :] . norm2.bias + bias[n]  =: mc[n].
 //  * parameter gradients of those folds come from G = dout^T @ on (one split-K GEMM) instead of a saved y:
 //       dW = alpha * G (+ dmc x norm2.bias), dalpha[n] = <W[n, :], G[n, :]>, dbeta = colsum(dout).
+#include <functional>
+#include <vector>
 #include "bf_common.h"
 #include "param_reduce.h"
 #include <stdlib.h>
@@ -93,10 +95,14 @@ int splitk_for(int M, int N, long K) {
 // still sees plain stream-ordered semantics on ITS stream (and the fork/join pattern is hipGraph-capturable).
 // BF_SIDE_STREAM=0 runs everything on the caller's stream.  The launch profiler times each kernel with events on the stream it was
 // launched on, so its per-kernel durations are the contended ones of the real schedule (they agree with a rocprofv3 trace).
-struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr, tail = nullptr; bool failed = false; bool pending = false; };
-// bf_side_defer(1): a trunk stage's backward returns without waiting for its LAST weight-gradient GEMM (everything forked before it
-// is joined as usual); the wait is enqueued by the next stage right before it first overwrites what that GEMM reads (the dqkv
-// scratch), by every other stage entry point at its start, or by bf_side_join().  Off by default: plain stream-ordered semantics.
+struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr, tail[2] = {nullptr, nullptr}; bool failed = false; bool pending[2] = {false, false}; };
+// bf_side_defer(1): a trunk stage's backward does not join its weight-gradient work before it returns (every fork / join is a
+// barrier packet that costs the caller's stream ~6 us, and the wait itself idles it when the side stream is behind).  Consecutive
+// stages alternate between two scratch sets and a stage first waits for the side work of the stage before the previous one (the
+// last user of its set), so nothing the side stream still reads is overwritten and the side stream may lag by a whole stage.
+// Every other stage entry point joins everything at its start, as does bf_side_join().  Off by default: plain stream-ordered
+// semantics (every stage joins before it returns).  BF_SIDE_LATE=1 additionally collects a stage's side work into ONE late fork
+// (measured: slower -- the work starts too late and the host enqueues it in a burst).
 bool g_side_defer = false;
 SideStream* side_stream() {
     static SideStream tab[64];
@@ -115,29 +121,27 @@ SideStream* side_stream() {
         static const bool sysfence = []() { const char* v = getenv("BF_EVENT_FENCE"); return v && atoi(v) != 0; }();
         const unsigned ef = hipEventDisableTiming | (sysfence ? 0u : hipEventDisableSystemFence);
         if (hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&s.fork, ef) != hipSuccess ||
-            hipEventCreateWithFlags(&s.join, ef) != hipSuccess || hipEventCreateWithFlags(&s.tail, ef) != hipSuccess) { s.failed = true; s.st = nullptr; }
+            hipEventCreateWithFlags(&s.join, ef) != hipSuccess || hipEventCreateWithFlags(&s.tail[0], ef) != hipSuccess ||
+            hipEventCreateWithFlags(&s.tail[1], ef) != hipSuccess) { s.failed = true; s.st = nullptr; }
     }
     return s.st ? &s : nullptr;
 }
 // the previous stage's deferred tail (if any) is ordered before what `main` is given next
-int side_join_pending(hipStream_t main) {
+int side_join_pending(hipStream_t main, int set = -1) {      // set: 0 / 1 = the work that reads that scratch set, -1 = everything
     SideStream* s = side_stream();
-    if (s && s->pending) {
-        HIP_TRY(hipStreamWaitEvent(main, s->tail, 0));
-        s->pending = false;
-    }
+    if (!s) return 0;
+    for (int i = 0; i < 2; ++i)
+        if ((set < 0 || set == i) && s->pending[i]) {
+            HIP_TRY(hipStreamWaitEvent(main, s->tail[i], 0));
+            s->pending[i] = false;
+        }
     return 0;
 }
 struct Fork {
-    hipStream_t main; SideStream* s; bool used = false, marked = false;
-    explicit Fork(hipStream_t m) : main(m), s(side_stream()) {}
-    // call before the stage's last begin(): what has been forked so far gets its own completion event, so that join() may leave
-    // only the last item outstanding (deferred mode)
-    int mark() {
-        if (!s || !used || !g_side_defer) return 0;
-        HIP_TRY(hipEventRecord(s->join, s->st));
-        marked = true;
-        return 0;
+    hipStream_t main; SideStream* s; bool used = false; bool deferred; int set;
+    std::vector<std::function<int(hipStream_t)>> jobs;          // deferred mode: the stage's side work, launched by flush()
+    explicit Fork(hipStream_t m, bool may_defer = false, int scratch_set = 0) : main(m), s(side_stream()), set(scratch_set) {
+        deferred = may_defer && g_side_defer && s != nullptr;
     }
     // stream for work that depends only on what has been issued on `main` so far
     int begin(hipStream_t* out) {
@@ -149,18 +153,36 @@ struct Fork {
         *out = s->st;
         return 0;
     }
-    // everything forked so far is ordered before what `main` is given next
+    // side work: job(stream) enqueues it.  Eager mode forks here; deferred mode keeps it for flush().
+    template <class F> int run(F&& job) {
+        static const bool late = []() { const char* v = getenv("BF_SIDE_LATE"); return v && atoi(v) != 0; }();
+        if (deferred && late) { jobs.emplace_back(std::forward<F>(job)); return 0; }
+        hipStream_t ss;
+        const int rc = begin(&ss);
+        return rc ? rc : job(ss);
+    }
+    // deferred mode: one fork for everything collected so far
+    int flush() {
+        if (!deferred || jobs.empty()) return 0;
+        int rc;
+        hipStream_t ss;
+        if ((rc = begin(&ss))) return rc;
+        for (auto& j : jobs) if ((rc = j(ss))) return rc;
+        jobs.clear();
+        return 0;
+    }
+    // everything forked so far is ordered before what `main` is given next (deferred mode: before the next stage's fork point)
     int join() {
-        if (!s || !used) return 0;
-        if (marked) {                                    // deferred: wait for all but the last item now, the last one later
-            HIP_TRY(hipStreamWaitEvent(main, s->join, 0));
-            HIP_TRY(hipEventRecord(s->tail, s->st));
-            s->pending = true;
-        } else {
-            HIP_TRY(hipEventRecord(s->join, s->st));
-            HIP_TRY(hipStreamWaitEvent(main, s->join, 0));
+        if (deferred) {
+            const int rc = flush();
+            if (rc) return rc;
+            if (used) { HIP_TRY(hipEventRecord(s->tail[set], s->st)); s->pending[set] = true; used = false; }
+            return 0;
         }
-        used = false; marked = false;
+        if (!s || !used) return 0;
+        HIP_TRY(hipEventRecord(s->join, s->st));
+        HIP_TRY(hipStreamWaitEvent(main, s->join, 0));
+        used = false;
         return 0;
     }
 };
@@ -438,6 +460,13 @@ int outproj_gemm(const D& d, const void* on, const void* w_c, const float* alpha
     e.rowscale = drop; e.rows_per_group = (int)rows_per_group;
     return bf_gemm(d.dtype, (int)d.N, d.E, d.E, &A, &Bo, &e, 1, st);
 }
+// scratch set of a trunk backward stage: deferred mode alternates, so that the side stream may still read the previous stage's set
+int g_scratch_parity = 0;
+void* bwd_scratch(const D& d, void* scratch) {
+    if (!g_side_defer || !side_stream()) return scratch;
+    g_scratch_parity ^= 1;
+    return (char*)scratch + (size_t)g_scratch_parity * Scratch(d, nullptr).bytes;
+}
 // A data gradient dy @ W whose consumer is the backward of the InstanceNorm that fed the projection: when a frame is one
 // 144-row GEMM tile the two run as ONE kernel (gemm_frame.hip); otherwise GEMM into `tmp`, then the InstanceNorm backward.
 struct InFuse { const void* x; const void* add; void* dx; const float* mean; const float* rstd; const float* w; const float* b; float* ws; };
@@ -455,19 +484,20 @@ int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on,
                 const float* W, const float* bias, const float* nb, const float* gamma, const float* lo, const float* hi,
                 const float* alpha, const float* mc, float* dW, float* dbias, float* dnb, float* dgamma, float* dlo, float* dhi,
                 void* don, hipStream_t st, Fork& fk, const InFuse* fu = nullptr) {
-    hipStream_t ss;                                   // parameter-gradient side: memset, G GEMM, finalize
-    TRY(fk.begin(&ss));
-    ZERO_ON(ss, sc.G, (size_t)((char*)sc.csum - (char*)sc.G) + (size_t)d.E * 4);     // G and csum are adjacent in the arena: one memset
-    {   // G[n][k] = sum_m dout[m][n] * on[m][k]; `on` is the normalised operand the forward saved
-        bf_operand A = op_plain(dout, d.E, BF_LAY_XC);
-        bf_operand Bo = op_plain(on, d.E, BF_LAY_XC);
-        bf_epilogue e = epi_atomic(sc.G, d.E);
-        e.colsum = sc.csum;                  // dbeta = colsum(dout), fused into the same pass over dout
-        TRY(bf_gemm(d.dtype, d.E, d.E, (int)d.N, &A, &Bo, &e, splitk_for(d.E, d.E, d.N), ss));
-    }
-    hipLaunchKernelGGL(outproj_finalize_kernel, dim3(d.E), dim3(256), 0, ss, sc.G, sc.csum, W, bias, nb, gamma, lo, hi, mc, dW, dbias, dnb,
-                       dgamma, dlo, dhi, d.E);
-    BF_CHECK_LAUNCH();
+    TRY(fk.run([=](hipStream_t ss) -> int {           // parameter-gradient side: memset, G GEMM, finalize
+        ZERO_ON(ss, sc.G, (size_t)((char*)sc.csum - (char*)sc.G) + (size_t)d.E * 4);     // G and csum are adjacent in the arena: one memset
+        {   // G[n][k] = sum_m dout[m][n] * on[m][k]; `on` is the normalised operand the forward saved
+            bf_operand A = op_plain(dout, d.E, BF_LAY_XC);
+            bf_operand Bo = op_plain(on, d.E, BF_LAY_XC);
+            bf_epilogue e = epi_atomic(sc.G, d.E);
+            e.colsum = sc.csum;                  // dbeta = colsum(dout), fused into the same pass over dout
+            TRY(bf_gemm(d.dtype, d.E, d.E, (int)d.N, &A, &Bo, &e, splitk_for(d.E, d.E, d.N), ss));
+        }
+        hipLaunchKernelGGL(outproj_finalize_kernel, dim3(d.E), dim3(256), 0, ss, sc.G, sc.csum, W, bias, nb, gamma, lo, hi, mc, dW, dbias, dnb,
+                           dgamma, dlo, dhi, d.E);
+        BF_CHECK_LAUNCH();
+        return 0;
+    }));
     if (fu) return dgrad_inbwd(d, dout, d.E, w_s, d.E, don, *fu, st);      // ... followed by norm2's backward
     {   // don = (dout * alpha) @ W = dout @ (diag(alpha) W): the scaled weight was written by the forward's parameter prep
         bf_operand A = op_plain(dout, d.E, BF_LAY_KC);
@@ -479,23 +509,24 @@ int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on,
 }
 // backward of y = affine(x) @ W^T + b:  dW += dy^T affine(x), db += colsum(dy), dxn = dy @ W
 int linear_bwd(const D& d, const Scratch& sc, const void* dy, int Nout, const void* x, int Kin, int xpro, const float* xsc, const float* xsh,
-               const void* w_c, float* dW, float* db, void* dxn, const bf_epilogue* dx_epi, hipStream_t st, Fork& fk, const InFuse* fu = nullptr) {
-    {
-        hipStream_t ss;                          // weight gradient: side stream
-        TRY(fk.begin(&ss));
-        void* tmp = sc.s1;
+               const void* w_c, float* dW, float* db, void* dxn, const bf_epilogue* dx_epi, hipStream_t st, Fork& fk, const InFuse* fu = nullptr,
+               bool last = false) {
+    TRY(fk.run([=](hipStream_t ss) -> int {      // weight gradient: side stream
+        const void* xo = x;
+        int pro = xpro;
         bf_operand A = op_plain(dy, Nout, BF_LAY_XC);
-        if (xpro == BF_PRO_AFFINE) {             // see outproj_bwd: materialise the normalised operand once
-            TRY(bf_affine_apply(d.dtype, x, nullptr, xsc, xsh, tmp, d.N, (int)d.S, Kin, ss));
-            x = tmp;
-            xpro = BF_PRO_NONE;
+        if (pro == BF_PRO_AFFINE) {              // see outproj_bwd: materialise the normalised operand once
+            TRY(bf_affine_apply(d.dtype, x, nullptr, xsc, xsh, sc.s1, d.N, (int)d.S, Kin, ss));
+            xo = sc.s1;
+            pro = BF_PRO_NONE;
         }
-        bf_operand Bo = op_plain(x, Kin, BF_LAY_XC);
-        if (xpro != BF_PRO_NONE) op_affine(Bo, xpro, xsc, xsh, d.S, Kin);
+        bf_operand Bo = op_plain(xo, Kin, BF_LAY_XC);
+        if (pro != BF_PRO_NONE) op_affine(Bo, pro, xsc, xsh, d.S, Kin);
         bf_epilogue e = epi_atomic(dW, Kin);
         e.colsum = db;                       // bias gradient = colsum(dy), fused into the same pass over dy
-        TRY(bf_gemm(d.dtype, Nout, Kin, (int)d.N, &A, &Bo, &e, splitk_for(Nout, Kin, d.N), ss));
-    }
+        return bf_gemm(d.dtype, Nout, Kin, (int)d.N, &A, &Bo, &e, splitk_for(Nout, Kin, d.N), ss);
+    }));
+    if (last) TRY(fk.flush());                   // deferred mode: the stage's one fork, ahead of its last kernel on the caller's stream
     if (fu) return dgrad_inbwd(d, dy, Nout, w_c, Kin, dxn, *fu, st);
     {
         bf_operand A = op_plain(dy, Nout, BF_LAY_KC);
@@ -512,7 +543,8 @@ int linear_bwd(const D& d, const Scratch& sc, const void* dy, int Nout, const vo
 // ================================================================================================= sizes
 extern "C" int64_t bf_temporal_saved_bytes(const bf_dims* s) { D d; if (get_dims(s, &d)) return -1; return (int64_t)TemporalSaved(d, nullptr).bytes; }
 extern "C" int64_t bf_spatial_saved_bytes(const bf_dims* s) { D d; if (get_dims(s, &d)) return -1; return (int64_t)SpatialSaved(d, nullptr).bytes; }
-extern "C" int64_t bf_scratch_bytes(const bf_dims* s) { D d; if (get_dims(s, &d)) return -1; return (int64_t)Scratch(d, nullptr).bytes; }
+// two scratch sets: consecutive trunk backward stages alternate between them in deferred mode (see SideStream)
+extern "C" int64_t bf_scratch_bytes(const bf_dims* s) { D d; if (get_dims(s, &d)) return -1; return 2 * (int64_t)Scratch(d, nullptr).bytes; }
 
 // Deferred weight-gradient tails (see SideStream): opt-in for callers that join explicitly before they consume parameter gradients
 extern "C" void bf_side_defer(int on) { g_side_defer = on != 0; }
@@ -555,9 +587,10 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
     BF_REQUIRE(p && g && x && dout && dx && saved && scratch, "bf_temporal_bwd: null pointer");
     hipStream_t st = (hipStream_t)s;
     TemporalSaved sv(d, saved);
-    Scratch sc(d, scratch);
+    Scratch sc(d, bwd_scratch(d, scratch));
     const void* win_c = d.dtype == BF_DTYPE_F32 ? (const void*)p->input_head_w : sv.win_c;
-    Fork fk(st);            // weight-gradient GEMMs go to the side stream; nothing they read (dbr, t3, s1) is rewritten before the join
+    Fork fk(st, true, g_scratch_parity);      // weight-gradient GEMMs go to the side stream; nothing they read (dbr, t3, s1) is rewritten before the join
+    if (fk.deferred) TRY(side_join_pending(st, fk.set));      // the stage before the previous one used this scratch set
     void* don = sc.t1;      // [N][E]
     void* dO = sc.t1b;      // [N][E]
     void* dqkv = sc.t3;     // [N][3E]
@@ -571,7 +604,6 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
                     sv.alpha, sv.mc, g->output_head_w, g->output_head_b, nullptr, g->gamma, nullptr, nullptr, don, st, fk, &fu2));
     ReduceJobs jobs;        // parameter-gradient reductions, all launched together at the end
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws2, (int)d.F, d.E, p->norm2_w, p->norm2_b, nullptr, 1, g->norm2_w, g->norm2_b, nullptr, nullptr, nullptr, nullptr};
-    TRY(side_join_pending(st));     // the previous stage's last weight-gradient GEMM reads the dqkv scratch
     {
         int rows = 0;
         TRY(bf_attn_bwd_partials(d.dtype, sv.qkv, dO, dqkv, (long)d.B * d.S, d.T, d.S, (long)d.T * d.S, 1, d.S, d.heads, d.d, p->qnorm_w, p->qnorm_b,
@@ -583,8 +615,7 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
     }
     void* dxn = sc.t1;      // don is dead
     const InFuse fu1{x, dout, dx, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, sc.in_ws};             // dqkv @ W_in, then norm1's backward + residual
-    TRY(fk.mark());
-    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, sv.xn, d.E, BF_PRO_NONE, nullptr, nullptr, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk, &fu1));
+    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, sv.xn, d.E, BF_PRO_NONE, nullptr, nullptr, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk, &fu1, true));
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws, (int)d.F, d.E, p->norm1_w, p->norm1_b, nullptr, 1, g->norm1_w, g->norm1_b, nullptr, nullptr, nullptr, nullptr};
     TRY(launch_reduce_jobs(jobs, st));
     return fk.join();
@@ -656,14 +687,15 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     BF_REQUIRE(p && g && x && dout && dx && saved && scratch, "bf_spatial_bwd: null pointer");
     hipStream_t st = (hipStream_t)s;
     SpatialSaved sv(d, saved);
-    Scratch sc(d, scratch);
+    Scratch sc(d, bwd_scratch(d, scratch));
     const bool f32 = d.dtype == BF_DTYPE_F32;
     const void* win_c = f32 ? (const void*)p->input_head_w : sv.win_c;
     const void* w1_c = f32 ? (const void*)p->fc1_w : sv.w1_c;
     const void* w2_c = f32 ? (const void*)p->fc2_w : sv.w2_c;
     // weight-gradient GEMMs go to the side stream and are joined at the end; every buffer they read (dz = t1, dpre = t4,
     // dx1 = t1b, dbr = e5, dqkv = t3, s1) is written once per call, so the critical path below never recycles one under them.
-    Fork fk(st);
+    Fork fk(st, true, g_scratch_parity);
+    if (fk.deferred) TRY(side_join_pending(st, fk.set));      // the stage before the previous one used this scratch set
     // out = x1 + gamma_mlp * IN(z)
     void* dz = sc.t1;
     ReduceJobs jobs;        // parameter-gradient reductions, all launched together at the end
@@ -706,7 +738,6 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
                     d.feat_scale ? g->high_freq_scalar : nullptr, don, st, fk, &fu2));
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws2, (int)d.F, d.E, p->norm2_w, p->norm2_b, nullptr, 1, g->norm2_w, g->norm2_b, nullptr, nullptr, nullptr, nullptr};
     void* dqkv = sc.t3;
-    TRY(side_join_pending(st));     // the previous stage's last weight-gradient GEMM reads the dqkv scratch
     {
         int rows = 0;
         TRY(bf_attn_bwd_partials(d.dtype, sv.qkv, dO, dqkv, d.F * d.h, d.w, 1, d.w, 0, 1, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
@@ -722,8 +753,7 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     }
     void* dxn = sc.e6;      // don is dead (it was only read on this stream)
     const InFuse fu1{x, dx1, dx, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, sc.in_ws};              // dqkv @ W_in, then norm1's backward + residual
-    TRY(fk.mark());
-    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, sv.xn, d.E, BF_PRO_NONE, nullptr, nullptr, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk, &fu1));
+    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, sv.xn, d.E, BF_PRO_NONE, nullptr, nullptr, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk, &fu1, true));
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws, (int)d.F, d.E, p->norm1_w, p->norm1_b, nullptr, 1, g->norm1_w, g->norm1_b, nullptr, nullptr, nullptr, nullptr};
     TRY(launch_reduce_jobs(jobs, st));
     return fk.join();

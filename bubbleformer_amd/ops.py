@@ -7,6 +7,7 @@ Activations between stages are token-major tensors of shape (B, T, h, w, E) (con
 Parameters stay ordinary fp32 ``nn.Parameter``s owned by the modules; every Function returns one gradient per
 parameter so autograd accumulation hooks (and therefore DDP bucket hooks) fire per stage during backward.
 """
+import collections
 import ctypes as C
 from typing import List, Optional, Sequence
 
@@ -104,6 +105,22 @@ def set_direct_grad_slots(slots, on_ready=None) -> None:
     _DIRECT["on_ready"] = on_ready
 
 
+# Deferred weight-gradient work (bf_side_defer): a trunk stage's side-stream GEMMs may still read its saved activations and its
+# incoming gradient while the NEXT stage runs, so those tensors are kept alive for two more stage calls (the library orders the
+# side work before the end of the next stage; the caching allocator knows nothing about the library's side stream).
+_DEFER = {"on": False, "keep": collections.deque(maxlen=2)}
+
+
+def set_side_defer(on: bool) -> None:
+    """on: opt in (TrainStep does, around forward + backward).  off: join the side stream on the current stream and drop the kept tensors."""
+    h = L.lib()
+    h.bf_side_defer(1 if on else 0)
+    _DEFER["on"] = bool(on)
+    if not on:
+        L.check(h.bf_side_join(_stream()), "bf_side_join")
+        _DEFER["keep"].clear()
+
+
 def _stage_grads(params: Sequence[Optional[torch.Tensor]]):
     """-> (gradient tensors the kernels accumulate into, what to hand back to autograd)"""
     slots = _DIRECT["slots"]
@@ -193,6 +210,8 @@ class _BlockFn(torch.autograd.Function):
             rc = bwd(C.byref(d), C.byref(st), C.byref(gs), _p(x), _p(dout), _p(dx), _p(saved), _p(scratch_for(d, x.device)), _p(drop_a),
                      _p(drop_b), _stream())
         L.check(rc, f"bf_{ctx.kind}_bwd")
+        if _DEFER["on"]:
+            _DEFER["keep"].append((saved, dout, x))
         _stage_done(params, direct)
         return (dx, None, None, None, None, None, None, *ret)
 

@@ -145,17 +145,14 @@ class TrainStep:
         self.step_no = 0
 
     def __call__(self, x, fluid, target) -> torch.Tensor:
-        from . import _lib
-        h = _lib.lib()
         self.flat.zero_grad()
         self.ops.set_direct_grad_slots(self.slots, self.reducer.stage_ready)
-        h.bf_side_defer(1)          # a stage's last weight-gradient GEMM may run into the next stage; joined below
+        self.ops.set_side_defer(True)       # a stage's weight-gradient GEMMs may run into the next stage; joined below
         try:
             loss = self._fwd_bwd(x, fluid, target)
         finally:
-            h.bf_side_defer(0)
+            self.ops.set_side_defer(False)
             self.ops.set_direct_grad_slots(None)
-            _lib.check(h.bf_side_join(torch.cuda.current_stream().cuda_stream), "bf_side_join")
         gscale = self.reducer.wait()
         self.step_no += 1
         lr = self.scheduler.get_last_lr()[0] if self.scheduler is not None else self.lr
