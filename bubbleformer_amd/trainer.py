@@ -43,7 +43,9 @@ class FlatParams:
 class BucketReducer:
     """Mean all-reduce of contiguous slices of a flat gradient buffer, launched from post-accumulate hooks."""
 
-    def __init__(self, flat: FlatParams, bucket_of: Sequence[int], group=None):
+    def __init__(self, flat: FlatParams, bucket_of: Sequence[int], group=None, use_hooks: bool = True):
+        """use_hooks=False: buckets are completed by stage_ready() only (TrainStep's direct-gradient mode -- autograd runs the
+        post-accumulate hooks even for the ``None`` gradients that mode returns, which would count every bucket twice)."""
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         nb = max(bucket_of) + 1
@@ -58,13 +60,15 @@ class BucketReducer:
         self.handles = []
         self.held = None          # direct-gradient mode: a complete bucket waits until the NEXT one is complete (see stage_ready)
         self.enabled = self.world > 1
-        if self.enabled:
+        self.done = set()         # buckets reduced in this step
+        if self.enabled and use_hooks:
             for p, b in zip(flat.params, bucket_of):
                 p.register_post_accumulate_grad_hook(self._make_hook(b))
 
         self.bucket_of_ptr = {p.data_ptr(): b for p, b in zip(flat.params, bucket_of)}
 
     def _launch(self, b):
+        self.done.add(b)
         g = self.flat.grad[self.lo[b]:self.hi[b]]
         self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -101,9 +105,15 @@ class BucketReducer:
     def wait(self) -> float:
         """Block the current stream on the outstanding buckets; returns the factor the optimizer must apply (1/world)."""
         self.flush()
+        if self.enabled:          # buckets nobody completed (a stage that fell back to autograd accumulation, unused parameters):
+            for b in range(len(self.count)):      # the backward is over, so they are final; same order on every rank
+                if b not in self.done and self.lo[b] is not None:
+                    self._launch(b)
         for h in self.handles:
             h.wait()
         self.handles.clear()
+        self.done.clear()
+        self.pending = [0] * len(self.pending)
         return 1.0 / self.world
 
 
@@ -133,7 +143,7 @@ class TrainStep:
         self.ops = ops
         self.model = model
         self.flat = FlatParams(model)
-        self.reducer = BucketReducer(self.flat, stage_buckets(model))
+        self.reducer = BucketReducer(self.flat, stage_buckets(model), use_hooks=False)
         self.slots = {p.data_ptr(): p.grad for p in self.flat.params}
         self.optimizer = optimizer
         self.m = torch.zeros_like(self.flat.flat)
