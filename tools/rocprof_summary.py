@@ -38,6 +38,8 @@ def normalise(name: str) -> str:
         ax, bx, ap, bp, tm = m.groups()
         return "gemm_wide_kernel<bf16,%s,%s,pro%s,tm%s>" % ("xc" if ax == "true" else "kc", "xc" if bx == "true" else "kc",
                                                            "A" if ap == "true" else "B" if bp == "true" else "0", tm)
+    if "gemm_inbwd_frames_kernel" in name:
+        return "gemm_inbwd_frames<bf16>"
     for key in ("frame_scale_kernel", "stage_param_reduce_kernel", "stage_prep_kernel", "clip_gather_kernel", "eikonal_kernel", "heatflux_kernel",
                 "lion_kernel", "in_bwd_slice_kernel", "in_stats_slice_kernel", "in_stats_merge_kernel", "in_slice_sum_kernel", "frame_table_kernel", "frame_wcolsum_kernel",
                 "cast4_kernel", "lploss_finalize_kernel", "fill_kernel"):
@@ -59,7 +61,7 @@ def main():
     ap.add_argument("--steps", type=int, required=True, help="total steps the profiled command ran (warm-up + timed + profiler leg)")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
-    stats = glob.glob(os.path.join(a.trace, "*", "*_kernel_stats.csv"))[0]
+    stats = glob.glob(os.path.join(a.trace, "**", "*kernel_stats.csv"), recursive=True)[0]
     agg = collections.OrderedDict()
     total = 0.0
     for r in csv.DictReader(open(stats)):
@@ -72,7 +74,7 @@ def main():
     traffic = {}
     if a.pmc_fetch and a.pmc_write:
         for d, ctr in ((a.pmc_fetch, "FETCH_SIZE"), (a.pmc_write, "WRITE_SIZE")):
-            f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
+            f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
             for r in csv.DictReader(open(f)):
                 if r["Counter_Name"] != ctr:
                     continue
