@@ -7,7 +7,14 @@ HPCForge/Bubbleformer ``bubbleformer.models`` / ``bubbleformer.layers`` nn.Modul
 The compute path is hand-written HIP (``csrc/``) behind a C ABI (``include/bubbleformer_hip.h``); there is no
 CPU or eager-PyTorch fallback -- importing works anywhere, running needs the built library and a ROCm GPU.
 """
-from . import _lib  # noqa: F401
+import os as _os
+
+# The stage backwards overlap weight-gradient GEMMs on a second HIP stream.  HIP deals streams onto GPU_MAX_HW_QUEUES hardware
+# queues round-robin; at the default of 4 the streams RCCL creates land that side stream on the main stream's queue and the overlap
+# is lost (DESIGN.md section 5).  Takes effect only if the HIP runtime has not been initialised yet; an explicit setting wins.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+from . import _lib  # noqa: F401,E402
 
 __version__ = "0.1.0"
 

@@ -13,6 +13,8 @@ only runs on the GPU.
 """
 from typing import List, Optional, Sequence
 
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -117,15 +119,18 @@ class BucketReducer:
         return 1.0 / self.world
 
 
-def stage_buckets(model: nn.Module) -> List[int]:
-    """Bucket index per parameter: one bucket per top-level stage / processor block (gradient-ready order is the
-    reverse of this list)."""
+def stage_buckets(model: nn.Module, blocks_per_bucket: Optional[int] = None) -> List[int]:
+    """Bucket index per parameter: one bucket per top-level stage and per group of `blocks_per_bucket` consecutive processor blocks
+    (gradient-ready order is the reverse of this list).  Each bucket is one collective: fewer, larger ones cost less host time
+    and fewer stream synchronisations, more of them start the exchange earlier (BF_BLOCKS_PER_BUCKET, default 4)."""
+    if blocks_per_bucket is None:
+        blocks_per_bucket = int(os.environ.get("BF_BLOCKS_PER_BUCKET", "4"))
     ids, names = [], {}
     for name, p in model.named_parameters():
         if not p.requires_grad:
             continue
         parts = name.split(".")
-        key = ".".join(parts[:2]) if parts[0] == "blocks" else parts[0]
+        key = "blocks.%d" % (int(parts[1]) // max(1, blocks_per_bucket)) if parts[0] == "blocks" else parts[0]
         ids.append(names.setdefault(key, len(names)))
     return ids
 

@@ -38,8 +38,9 @@ def _worker(rank, world, port, out):
     torch.manual_seed(0)
     model = Toy()
     flat = FlatParams(model)
-    buckets = stage_buckets(model)
+    buckets = stage_buckets(model, blocks_per_bucket=1)
     assert max(buckets) + 1 == 5          # embed, 3 blocks, debed
+    assert max(stage_buckets(model, blocks_per_bucket=2)) + 1 == 4      # embed, blocks {0,1}, block 2, debed
     red = BucketReducer(flat, buckets)
     g = torch.Generator().manual_seed(123)
     xs = torch.randn(world * 4, 6, generator=g)
