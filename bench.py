@@ -79,6 +79,33 @@ def cpu_baseline(threads):
             "sample": f"batch 1 clip 16x192x192x4ch fp32, 1 warm-up + {n} timed fwd+loss+bwd+AdamW steps of the oracle (torch CPU, {threads} threads)"}
 
 
+def eager_gpu_baseline(dev, autocast):
+    """the same restatement run eagerly on the MI355X through stock PyTorch-ROCm kernels -- the
+    un-accelerated GPU comparator (batch 8, the bench shape, AdamW; fp32 or bf16 autocast).  Checker code, timed, never shipped."""
+    from oracle import filmavit_ref as R, weights as Wt
+    shapes = Wt.param_shapes(**{k: v for k, v in CFG.items()})
+    sd = {k: v.to(dev).requires_grad_(True) for k, v in Wt.generate(shapes, seed=42).items()}
+    opt = torch.optim.AdamW(list(sd.values()), lr=2.5e-4, weight_decay=1e-2, fused=True)
+    x, c, y = synthetic_batch(42, dev)
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            pred = R.filmavit_forward(sd, x, c, patch_size=16, num_heads=6)
+        loss = R.lp_loss(pred.float(), y)
+        loss.backward()
+        opt.step()
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    n, t0 = 5, time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": BATCH * n / dt, "unit": "samples/s", "ms_per_step": dt / n * 1e3, "dtype": "bf16 autocast" if autocast else "f32",
+            "kind": "oracle restatement, eager PyTorch-ROCm on the same GPU", "sample": f"batch {BATCH}, 2 warm-up + {n} timed steps"}
+
+
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
@@ -95,6 +122,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager-gpu-baseline", action="store_true", help="also time the oracle eagerly on the GPU (fp32 and bf16 autocast)")
     args = ap.parse_args()
 
     # stdout carries exactly one JSON line: whatever libraries print there (RCCL's version banner under NCCL_DEBUG=VERSION) goes to stderr
@@ -213,6 +241,10 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         log("timing the CPU baseline (oracle) on", host_threads(), "threads")
         out["cpu_baseline"] = cpu_baseline(host_threads())
+    if world == 1 and args.eager_gpu_baseline:
+        del step, model
+        torch.cuda.empty_cache()
+        out["eager_gpu_baseline"] = [eager_gpu_baseline(dev, True), eager_gpu_baseline(dev, False)]
     sys.stdout.flush()
     os.dup2(real_stdout, 1)
     print(json.dumps(out), flush=True)
