@@ -97,6 +97,7 @@ SIGNATURES = {
     "bf_adamw": (C.c_int, [fp, fp, fp, fp, i64, C.c_int, f32, f32, f32, f32, f32, f32, vp]),
     "bf_lion": (C.c_int, [fp, fp, fp, i64, f32, f32, f32, f32, f32, vp]),
     "bf_eikonal_sum": (C.c_int, [fp, i64, C.c_int, C.c_int, f32, vp, vp]),
+    "bf_eikonal_l1_frames": (C.c_int, [fp, i64, C.c_int, C.c_int, f32, fp, vp]),
     "bf_heatflux_rows": (C.c_int, [fp, fp, i64, i64, C.c_int, f32, f32, f32, f32, fp, vp]),
     "bf_clip_gather": (C.c_int, [fp, i64, vp, vp, C.c_int, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "bf_temporal_saved_bytes": (i64, [P(Dims)]),

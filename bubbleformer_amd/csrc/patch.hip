@@ -384,6 +384,30 @@ __global__ void __launch_bounds__(NT) eikonal_kernel(const float* __restrict__ p
         atomicAdd(out, t);
     }
 }
+// The rollout notebook's Eikonal score (scripts/inference_autoregressive.ipynb, `get_eikonal_loss`): per frame, the mean of
+// | |grad phi| - 1 | with central differences at spacing dx in the interior and the border taking its neighbour's gradient
+// (replicate padding).  One workgroup per frame.
+__global__ void __launch_bounds__(NT) eikonal_l1_kernel(const float* __restrict__ phi, int H, int W, float inv_2dx, float* __restrict__ out) {
+    __shared__ double red[NT / 64];
+    const float* f = phi + (long)blockIdx.x * H * W;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < H * W; i += NT) {
+        const int x = i % W, y = i / W;
+        const int xi = min(max(x, 1), W - 2), yi = min(max(y, 1), H - 2);
+        const float gx = (f[y * W + xi + 1] - f[y * W + xi - 1]) * inv_2dx;
+        const float gy = (f[(yi + 1) * W + x] - f[(yi - 1) * W + x]) * inv_2dx;
+        acc += (double)fabsf(sqrtf(gx * gx + gy * gy) - 1.f);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < NT / 64; ++i) t += red[i];
+        out[blockIdx.x] = (float)(t / ((double)H * W));
+    }
+}
 // Heater heat flux of FC-72 pool boiling per frame (utils/heatflux.py:17-38): bottom row y = 0 of a W-column grid spanning
 // x in [x_min, x_min + W*dx); flux[t] = mean_x( [ |x| <= 5 and dfun < 0 ] * (heater_temp - temp) ) * 0.054 / (dx * lc)
 __global__ void __launch_bounds__(64) heatflux_kernel(const float* __restrict__ dfun, const float* __restrict__ temp, long frame_stride, int W,
@@ -403,6 +427,12 @@ __global__ void __launch_bounds__(64) heatflux_kernel(const float* __restrict__ 
 extern "C" int bf_eikonal_sum(const float* phi, int64_t frames, int H, int W, float dx, double* out, bf_stream_t stream) {
     BF_REQUIRE(phi && out && frames > 0 && H > 0 && W > 0 && dx > 0.f, "bf_eikonal_sum: bad arguments");
     hipLaunchKernelGGL(eikonal_kernel, dim3(grid_for(frames * H * W)), dim3(NT), 0, (hipStream_t)stream, phi, (long)frames, H, W, 1.f / dx, out);
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int bf_eikonal_l1_frames(const float* phi, int64_t frames, int H, int W, float dx, float* out, bf_stream_t stream) {
+    BF_REQUIRE(phi && out && frames > 0 && H >= 3 && W >= 3 && dx > 0.f, "bf_eikonal_l1_frames: bad arguments (central differences need >= 3 points per axis)");
+    hipLaunchKernelGGL(eikonal_l1_kernel, dim3((unsigned)frames), dim3(NT), 0, (hipStream_t)stream, phi, H, W, 0.5f / dx, out);
     BF_CHECK_LAUNCH();
     return 0;
 }

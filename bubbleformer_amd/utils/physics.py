@@ -18,6 +18,19 @@ def eikonal_loss(phi: torch.Tensor) -> torch.Tensor:
     return (acc / phi.numel()).float().squeeze(0)
 
 
+def eikonal_l1_per_frame(phi: torch.Tensor) -> torch.Tensor:
+    """phi (T, H, W) SDF frames -> (T,) scores of the rollout notebook (`get_eikonal_loss`, scripts/inference_autoregressive.ipynb):
+    mean | |grad phi| - 1 | per frame, central differences at dx = 1/32 with replicate-padded borders."""
+    _require_gpu(phi)
+    if phi.dim() != 3:
+        raise ValueError("eikonal_l1_per_frame expects (T, H, W)")
+    phi = phi.contiguous().float()
+    T, H, W = phi.shape
+    out = torch.empty(T, dtype=torch.float32, device=phi.device)
+    L.check(L.lib().bf_eikonal_l1_frames(_p(phi), T, H, W, 1.0 / 32, _p(out), _stream()), "bf_eikonal_l1_frames")
+    return out
+
+
 def heatflux(dfun: torch.Tensor, temp: torch.Tensor, heater_temp: float):
     """FC-72 heater heat flux (utils/heatflux.py:3-38): dfun, temp (T, 512, 512) device tensors -> (mean, max) over frames of the
     bottom-row flux.  The reference hard-codes the 16 x 16 domain at dx = 1/32 (512 x 512 cells); so does this."""

@@ -175,6 +175,9 @@ int bf_clip_gather(const float* src, int64_t field_stride, const int32_t* field,
  * bf_heatflux_rows: flux[t] = mean over the W bottom-row cells of [|x_c| <= 5 and dfun < 0] * (heater_temp - temp) * 0.054 / (dx * lc),
  * x_c = x_min + (i + 0.5) * dx; dfun / temp point at row 0 of frame 0, frames are frame_stride elements apart. */
 int bf_eikonal_sum(const float* phi, int64_t frames, int H, int W, float dx, double* out, bf_stream_t stream);
+/* out[frame] = mean over the frame of | |grad phi| - 1 |, central differences at spacing dx, borders replicate their neighbour's
+ * gradient: `get_eikonal_loss` of scripts/inference_autoregressive.ipynb (the rollout notebook's per-time-step SDF score). */
+int bf_eikonal_l1_frames(const float* phi, int64_t frames, int H, int W, float dx, float* out, bf_stream_t stream);
 int bf_heatflux_rows(const float* dfun, const float* temp, int64_t frames, int64_t frame_stride, int W, float x_min, float dx,
                      float heater_temp, float lc, float* flux, bf_stream_t stream);
 /* Lion: p *= 1 - lr*wd; p -= lr*sign(beta1*m + (1-beta1)*g); m = beta2*m + (1-beta2)*g   (g is multiplied by gscale first) */

@@ -315,6 +315,18 @@ def eikonal_loss(phi: Tensor) -> Tensor:
     return ((torch.sqrt(gy ** 2 + gx ** 2) - 1.0) ** 2).mean()
 
 
+def eikonal_l1_per_frame(phi: Tensor) -> Tensor:
+    """scripts/inference_autoregressive.ipynb cell 8 (`get_eikonal_loss`): phi (T, H, W) -> (T,) mean over the frame of
+    | |grad phi| - 1 |, central differences at dx = 1/32 in the interior, the border taking its neighbour's value (replicate pad)."""
+    dx = 1.0 / 32
+    H, W = phi.shape[-2:]
+    xi = torch.arange(W).clamp(1, W - 2)
+    yi = torch.arange(H).clamp(1, H - 2)
+    gx = (phi[:, :, xi + 1] - phi[:, :, xi - 1]) / (2 * dx)
+    gy = (phi[:, yi + 1, :] - phi[:, yi - 1, :]) / (2 * dx)
+    return (torch.sqrt(gx ** 2 + gy ** 2) - 1.0).abs().mean(dim=(1, 2))
+
+
 def heatflux(dfun, temp, heater_temp: float):
     """utils/heatflux.py:3-38 (numpy arrays (T, 512, 512)): bottom-row flux of the liquid cells over the heater |x| <= 5 on the
     16 x 16 domain at dx = 1/32, 0.054 * (T_heater - T) / (dx * lc) with lc = 0.0007; returns (mean, max) over frames."""

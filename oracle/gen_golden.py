@@ -163,8 +163,19 @@ def gen_physics(gold):
     eik32 = float(losses.eikonal_loss(torch.from_numpy(phi)))
     eik64 = float(losses.eikonal_loss(torch.from_numpy(phi).double()))
     mean, mx = hf.heatflux(dfun, temp, 1.0)
+    # the notebook's central-difference / replicate-pad L1 variant (scripts/inference_autoregressive.ipynb, the cell that defines
+    # get_eikonal_loss): that cell is executed as it stands and evaluated on the (T, H, W) view of the same field
+    import json
+    nb = json.load(open(os.path.join(REF, "scripts", "inference_autoregressive.ipynb")))
+    cell = next("".join(c["source"]) for c in nb["cells"] if c["cell_type"] == "code" and "def get_eikonal_loss" in "".join(c["source"]))
+    ns = {"torch": torch}
+    exec(cell, ns)
+    frames = torch.from_numpy(phi).reshape(-1, phi.shape[-2], phi.shape[-1])
+    nb32 = ns["get_eikonal_loss"](frames).numpy()
+    nb64 = ns["get_eikonal_loss"](frames.double()).numpy()
     np.savez(os.path.join(gold, "physics.npz"), eikonal_f32=np.array(eik32), eikonal_f64=np.array(eik64), heatflux_mean=np.array(mean),
-             heatflux_max=np.array(mx), seed=np.array(21), frames=np.array(3), heater_temp=np.array(1.0))
+             heatflux_max=np.array(mx), seed=np.array(21), frames=np.array(3), heater_temp=np.array(1.0), eikonal_nb_f32=nb32,
+             eikonal_nb_f64=nb64)
 
 
 def main():

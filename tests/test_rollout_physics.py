@@ -25,6 +25,9 @@ def test_oracle_physics_match_reference_values():
     assert float(R.eikonal_loss(torch.from_numpy(phi))) == pytest.approx(float(z["eikonal_f32"]), rel=2e-6)
     mean, mx = R.heatflux(dfun, temp, float(z["heater_temp"]))
     assert mean == pytest.approx(float(z["heatflux_mean"]), rel=1e-12) and mx == pytest.approx(float(z["heatflux_max"]), rel=1e-12)
+    frames = torch.from_numpy(phi).reshape(-1, *phi.shape[-2:])          # the notebook's central-difference / replicate-pad L1 variant
+    assert np.allclose(R.eikonal_l1_per_frame(frames.double()).numpy(), z["eikonal_nb_f64"], rtol=1e-12)
+    assert np.allclose(R.eikonal_l1_per_frame(frames).numpy(), z["eikonal_nb_f32"], rtol=2e-6)
 
 
 @pytest.mark.gpu
@@ -35,6 +38,10 @@ def test_physics_kernels_match_reference_values():
     assert float(physics.eikonal_loss(torch.from_numpy(phi).cuda())) == pytest.approx(float(z["eikonal_f64"]), rel=2e-6)
     mean, mx = physics.heatflux(torch.from_numpy(dfun).cuda(), torch.from_numpy(temp).cuda(), float(z["heater_temp"]))
     assert float(mean) == pytest.approx(float(z["heatflux_mean"]), rel=2e-6) and float(mx) == pytest.approx(float(z["heatflux_max"]), rel=2e-6)
+    frames = torch.from_numpy(phi).reshape(-1, *phi.shape[-2:]).cuda()
+    assert np.allclose(physics.eikonal_l1_per_frame(frames).cpu().numpy(), z["eikonal_nb_f64"], rtol=2e-6)
+    with pytest.raises(Exception):
+        physics.eikonal_l1_per_frame(frames[:, :2])                      # central differences need three points
     # degenerate axes behave like torch.gradient would not allow (needs >= 2 points): a 1-wide axis contributes a zero derivative
     one = torch.linspace(0, 1, 9, device="cuda").view(1, 9, 1) / 32
     assert float(physics.eikonal_loss(one)) == pytest.approx(float(((torch.full((9,), 1 / 8.0) - 1) ** 2).mean()), rel=1e-5)
