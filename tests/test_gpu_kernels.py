@@ -183,7 +183,16 @@ def test_in_bwd_matches_autograd(K, dtype, S, Cc, gelu):
 @pytest.mark.parametrize("Kd,N,with_add", [(1152, 384, True), (384, 384, False), (64, 128, True), (1536, 256, False)])
 def test_gemm_inbwd_frames_matches_gemm_then_in_bwd(K, Kd, N, with_add):
     """conv1x1 data gradient + InstanceNorm2d backward in one kernel (144-token frames) vs fp64 autograd and vs the two-kernel path."""
-    Fr, S = 5, 144
+    _check_gemm_inbwd_frames(K, 5, Kd, N, with_add)
+
+
+def test_gemm_inbwd_frames_at_the_bench_size(K):
+    """BASELINE configs[1]: 128 frames (batch 8 x 16), E = 384, the QKV projection's data gradient (K = 1152) with the residual."""
+    _check_gemm_inbwd_frames(K, 128, 1152, 384, True)
+
+
+def _check_gemm_inbwd_frames(K, Fr, Kd, N, with_add):
+    S = 144
     M = Fr * S
     g = torch.Generator(device="cuda").manual_seed(21)
     A = (torch.randn(M, Kd, device="cuda", generator=g) * 0.5).bfloat16()
