@@ -108,6 +108,13 @@ def test_config3_long_aspect_32x384x192_fp32():
     _compare(_product(B, T, H, W, seed, torch.float32), _oracle(B, T, H, W, seed, dtype=torch.float64), torch.float32)
 
 
+def test_config3_transposed_32x192x384_fp32():
+    """The wide variant SURVEY.md section 8(d) asks for beside configs[3] ("stresses axial-W"): 12 x 24 tokens, so the W pass is the
+    one with L = 24."""
+    B, T, H, W, seed = 1, 32, 192, 384, 16
+    _compare(_product(B, T, H, W, seed, torch.float32), _oracle(B, T, H, W, seed, dtype=torch.float64), torch.float32)
+
+
 def test_config1_bench_size_properties():
     """bs 8 x 16x192x192, bf16, eval: reruns are bit-identical; a sample's prediction does not depend on its batch mates
     (InstanceNorm is per frame, attention per sequence) beyond bf16 GEMM tiling noise."""

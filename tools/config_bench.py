@@ -65,6 +65,8 @@ if __name__ == "__main__":
     for B in (1, 2, 4):
         r, ms = train_rate(B, 32, 384, 192)
         print(f"configs[3] train 32x384x192 bs {B}: {r:.1f} samples/s ({ms:.1f} ms/step)")
+    r, ms = train_rate(4, 32, 192, 384)
+    print(f"configs[3] transposed train 32x192x384 bs 4: {r:.1f} samples/s ({ms:.1f} ms/step)")
     print("configs[4] rollout 16x192x192 bs 1, ms/step:", rollout_ms())
     big = dict(CFG, embed_dim=768, num_heads=12)        # config/model_cfg/film_avit_big.yaml
     r, ms = train_rate(8, 16, 192, 192, cfg=big)
