@@ -8,11 +8,14 @@ format specification (v1.x "old style" files, which is what ``samples/*.hdf5`` a
   -> object header v1 (incl. continuation blocks) -> dataspace / datatype / data-layout messages
   -> contiguous (or compact) data, returned as a zero-copy ``numpy.memmap``
 
-Little-endian IEEE floats and fixed-point integers, contiguous layout (what h5py writes unless chunking / compression is asked
-for, and what ``samples/*.hdf5`` contain).  Chunked or filtered datasets, new-style (v2) groups and object headers raise
+Little-endian IEEE floats and fixed-point integers.  Contiguous layout (what h5py writes unless chunking / compression is asked
+for, and what ``samples/*.hdf5`` contain) comes back as a zero-copy ``numpy.memmap``; chunked layout (data-layout message v3,
+B-tree v1 chunk index) with the deflate / shuffle / fletcher32 filters -- what ``compression="gzip"`` produces -- is assembled into
+an array on first access.  Other filters (szip, lzf, ...), new-style (v2) groups / object headers and layout message v4 raise
 ``Hdf5Error`` -- nothing is guessed.
 """
 import struct
+import zlib
 from typing import Dict, List, Tuple
 
 import numpy as np
@@ -42,9 +45,66 @@ class Dataset:
                     self._array = np.memmap(self._f.path, dtype=self.dtype, mode="r", offset=self._f.base + lay["addr"], shape=self.shape)
             elif lay["class"] == "compact":
                 self._array = np.frombuffer(lay["data"], dtype=self.dtype).reshape(self.shape)
+            elif lay["class"] == "chunked":
+                self._array = self._read_chunked()
             else:
-                raise Hdf5Error(f"dataset {self.name}: {lay['class']} layout is not supported (contiguous only)")
+                raise Hdf5Error(f"dataset {self.name}: {lay['class']} layout is not supported")
         return self._array
+
+    # ------------------------------------------------------------------ chunked storage
+    def _unfilter(self, raw: bytes, mask: int) -> bytes:
+        """Undo the filter pipeline of one chunk (filters were applied in list order when it was written)."""
+        for i in range(len(self._filters) - 1, -1, -1):
+            if (mask >> i) & 1:
+                continue                               # this filter was skipped for the chunk
+            fid, cd = self._filters[i]
+            if fid == 1:                               # deflate
+                raw = zlib.decompress(raw)
+            elif fid == 2:                             # shuffle: byte j of every element is stored together
+                es = cd[0] if cd else self.dtype.itemsize
+                n = len(raw) // es
+                body = np.frombuffer(raw, dtype=np.uint8, count=n * es).reshape(es, n).T.tobytes()
+                raw = body + raw[n * es:]
+            elif fid == 3:                             # fletcher32: 4 checksum bytes follow the data
+                raw = raw[:-4]
+            else:
+                raise Hdf5Error(f"dataset {self.name}: filter id {fid} is not supported (deflate, shuffle, fletcher32 only)")
+        return raw
+
+    def _read_chunked(self) -> np.ndarray:
+        lay, f = self._layout, self._f
+        cdims = lay["chunk"]
+        nd = len(self.shape)
+        if len(cdims) != nd:
+            raise Hdf5Error(f"dataset {self.name}: chunk rank {len(cdims)} != data rank {nd}")
+        out = np.zeros(self.shape, self.dtype)
+        if lay["btree"] == UNDEF:
+            return out                                 # nothing was ever written
+        nbytes = int(np.prod(cdims)) * self.dtype.itemsize
+
+        def walk(addr: int):
+            a = f.base + addr
+            if f._bytes(a, 4) != b"TREE" or f._u(a + 4, 1) != 1:
+                raise Hdf5Error(f"dataset {self.name}: chunk B-tree node expected")
+            level, used = f._u(a + 5, 1), f._u(a + 6, 2)
+            ksize = 8 + 8 * (nd + 1)
+            p = a + 8 + 16
+            for i in range(used):
+                k = p + i * (ksize + 8)
+                size, mask = f._u(k, 4), f._u(k + 4, 4)
+                offs = struct.unpack_from("<" + "Q" * nd, f._bytes(k + 8, 8 * nd), 0)
+                child = f._u(k + ksize, 8)
+                if level > 0:
+                    walk(child)
+                    continue
+                raw = self._unfilter(f._bytes(f.base + child, size), mask)
+                if len(raw) != nbytes:
+                    raise Hdf5Error(f"dataset {self.name}: chunk at {offs} has {len(raw)} bytes, expected {nbytes}")
+                chunk = np.frombuffer(raw, dtype=self.dtype).reshape(cdims)
+                take = tuple(slice(0, min(c, s - o)) for c, s, o in zip(cdims, self.shape, offs))     # edge chunks stick out
+                out[tuple(slice(o, o + t.stop) for o, t in zip(offs, take))] = chunk[take]
+        walk(lay["btree"])
+        return out
 
     def __getitem__(self, key):
         return self.array()[key]
@@ -199,7 +259,10 @@ class File:
                     if cls == 1:
                         layout = {"class": "contiguous", "addr": struct.unpack_from("<Q", d, 2)[0], "size": struct.unpack_from("<Q", d, 10)[0]}
                     elif cls == 2:
-                        layout = {"class": "chunked"}
+                        ndim1 = d[2]                          # rank + 1: the last "dimension" is the element size
+                        btree = struct.unpack_from("<Q", d, 3)[0]
+                        cd = struct.unpack_from("<" + "I" * ndim1, d, 11)
+                        layout = {"class": "chunked", "btree": btree, "chunk": tuple(cd[:-1]), "esize": cd[-1]}
                     elif cls == 0:
                         n = struct.unpack_from("<H", d, 2)[0]
                         layout = {"class": "compact", "data": bytes(d[4:4 + n])}
@@ -215,18 +278,52 @@ class File:
                     if cls == 1:
                         layout = {"class": "contiguous", "addr": addr, "size": 0}
                     elif cls == 2:
-                        layout = {"class": "chunked"}
+                        cd = struct.unpack_from("<" + "I" * nd, d, p)
+                        layout = {"class": "chunked", "btree": addr, "chunk": tuple(cd[:-1]), "esize": cd[-1]}
                     else:
                         raise Hdf5Error("compact layout (message version 1/2) is not supported")
                 else:
                     raise Hdf5Error(f"data layout message version {ver}")
             elif mtype == 0x000B:                         # filter pipeline
-                filters.append((d[1], ()))
+                filters = self._parse_filters(d)
         if shape is None or dtype is None or layout is None:
             raise Hdf5Error(f"dataset {name}: missing dataspace / datatype / layout message")
-        if filters:
-            raise Hdf5Error(f"dataset {name}: filtered (compressed) data is not supported")
+        if filters and layout["class"] != "chunked":
+            raise Hdf5Error(f"dataset {name}: a filter pipeline on {layout['class']} data")
+        for fid, _ in filters:
+            if fid not in (1, 2, 3):
+                raise Hdf5Error(f"dataset {name}: filter id {fid} is not supported (deflate, shuffle, fletcher32 only)")
         return Dataset(self, name, shape, dtype, layout, filters)
+
+    @staticmethod
+    def _parse_filters(d: bytes) -> List[Tuple[int, tuple]]:
+        ver, n = d[0], d[1]
+        out: List[Tuple[int, tuple]] = []
+        if ver == 1:
+            p = 8
+            for _ in range(n):
+                fid, nlen, _flags, ncd = struct.unpack_from("<HHHH", d, p)
+                p += 8 + ((nlen + 7) // 8) * 8
+                cd = struct.unpack_from("<" + "I" * ncd, d, p)
+                p += 4 * ncd + (4 if ncd % 2 else 0)
+                out.append((fid, tuple(cd)))
+        elif ver == 2:
+            p = 2
+            for _ in range(n):
+                fid = struct.unpack_from("<H", d, p)[0]
+                p += 2
+                nlen = 0
+                if fid >= 256:
+                    nlen = struct.unpack_from("<H", d, p)[0]
+                    p += 2
+                _flags, ncd = struct.unpack_from("<HH", d, p)
+                p += 4 + nlen
+                cd = struct.unpack_from("<" + "I" * ncd, d, p)
+                p += 4 * ncd
+                out.append((fid, tuple(cd)))
+        else:
+            raise Hdf5Error(f"filter pipeline message version {ver}")
+        return out
 
     # ------------------------------------------------------------------ mapping interface
     def keys(self):

@@ -42,6 +42,33 @@ def test_hdf5_reader_reads_the_sample_trajectories():
         hdf5_lite.File(os.path.abspath(__file__))            # not an HDF5 file
 
 
+def test_hdf5_reader_chunked_and_compressed_layouts(tmp_path):
+    """What h5py writes under `chunks=` / `compression="gzip"`: chunked layout (B-tree v1 index, edge chunks), deflate, shuffle,
+    fletcher32.  tests/golden/hdf5/chunked.hdf5 was written by libhdf5 1.10.6 (make_chunked_fixture.c beside it); values are exact."""
+    from bubbleformer_amd.data import BubbleForecast, hdf5_lite
+    path = os.path.join(os.path.dirname(SAMPLES), "hdf5", "chunked.hdf5")
+    f = hdf5_lite.File(path)
+    t, y, x = np.meshgrid(np.arange(7), np.arange(10), np.arange(12), indexing="ij")
+    for k, name in enumerate(ALL):
+        want = ((131 * t + 17 * y + 3 * x + 1000 * k) * 0.25).astype(np.float32)
+        assert f[name].shape == (7, 10, 12) and np.array_equal(f[name][...], want) and np.array_equal(f[name][2:5], want[2:5])
+    yy, xx = np.meshgrid(np.arange(5), np.arange(6), indexing="ij")
+    assert f["counts"].dtype == np.int16 and np.array_equal(f["counts"][...], (100 * yy - 7 * xx).astype(np.int16))
+    d = BubbleForecast([path], norm="none", time_window=2, start_time=1)            # the dataset class reads such files unchanged
+    d.normalize()
+    a, b = d[0]
+    assert tuple(a.shape) == (2, 4, 10, 12) and float(a[0, 0, 0, 0]) == 131 * 1 * 0.25
+    # many small chunks: a multi-level chunk B-tree.  Made on the fly where the HDF5 tools exist (they do in the build container).
+    repack = shutil.which("h5repack") or ("/opt/conda/bin/h5repack" if os.path.exists("/opt/conda/bin/h5repack") else None)
+    if repack:
+        import subprocess
+        out = str(tmp_path / "s1_chunked.hdf5")
+        subprocess.run([repack, "-l", "CHUNK=1x8x8", "-f", "SHUF", "-f", "GZIP=3", FILES[0], out], check=True)
+        g, h = hdf5_lite.File(FILES[0]), hdf5_lite.File(out)
+        for k in ALL:
+            assert np.array_equal(g[k][...], h[k][...])
+
+
 @pytest.mark.parametrize("input_fields", [["dfun"], ["temperature", "velx", "vely"], ALL])
 @pytest.mark.parametrize("output_fields", [["temperature"], ["temperature", "velx", "vely"], ALL])
 @pytest.mark.parametrize("norm", ["none", "std", "minmax", "tanh"])
