@@ -96,13 +96,15 @@ def _grad_views(params: Sequence[Optional[torch.Tensor]]):
 # per-parameter temporaries, no 500 tiny accumulate kernels per step.  `on_ready` tells the bucket reducer that a
 # stage's gradients are enqueued on the current stream.  Outside this mode gradients are returned to autograd as usual
 # (so DDP / optimizer hooks of an unmodified training script still fire).
-_DIRECT = {"slots": None, "on_ready": None}
+_DIRECT = {"slots": None, "on_ready": None, "on_join": None}
 
 
-def set_direct_grad_slots(slots, on_ready=None) -> None:
-    """slots: {param.data_ptr(): fp32 gradient view} or None to switch the mode off."""
+def set_direct_grad_slots(slots, on_ready=None, on_join=None) -> None:
+    """slots: {param.data_ptr(): fp32 gradient view} or None to switch the mode off.  on_join(): called when everything the stages so
+    far put on the library's side stream has been ordered on the current stream (see _joined)."""
     _DIRECT["slots"] = slots
     _DIRECT["on_ready"] = on_ready
+    _DIRECT["on_join"] = on_join
 
 
 # Deferred weight-gradient work (bf_side_defer): a trunk stage's side-stream GEMMs may still read its saved activations and its
@@ -119,6 +121,16 @@ def set_side_defer(on: bool) -> None:
     if not on:
         L.check(h.bf_side_join(_stream()), "bf_side_join")
         _DEFER["keep"].clear()
+
+
+def _joined() -> None:
+    """Deferred mode, before the patch-embedding backward (the last, long stage of a backward pass): join the side stream here, on
+    the Python side, so that the gradient buckets of the processor blocks can be handed to the all-reduce BEFORE that stage's kernels
+    are enqueued and travel under them, instead of after."""
+    if _DEFER["on"]:
+        L.check(L.lib().bf_side_join(_stream()), "bf_side_join")
+        if _DIRECT["on_join"] is not None:
+            _DIRECT["on_join"]()
 
 
 def _stage_grads(params: Sequence[Optional[torch.Tensor]]):
@@ -286,6 +298,7 @@ class _EmbedFn(torch.autograd.Function):
         gs = L.EmbedParams(gcw, giw, gib, *([_p(t) for t in gv[3 * nst:]] if film else [None] * 4))
         dout = dout.contiguous()
         dx = torch.empty(xshape, dtype=torch.float32, device=dout.device) if ctx.needs_input_grad[0] else None
+        _joined()
         L.check(lib.bf_embed_bwd(C.byref(d), C.byref(st), C.byref(gs), _p(dout), _p(dx), _p(saved), _p(scratch_for(d, dout.device)),
                                  _stream()), "bf_embed_bwd")
         _stage_done(params, direct)

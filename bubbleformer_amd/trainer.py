@@ -161,7 +161,7 @@ class TrainStep:
 
     def __call__(self, x, fluid, target) -> torch.Tensor:
         self.flat.zero_grad()
-        self.ops.set_direct_grad_slots(self.slots, self.reducer.stage_ready)
+        self.ops.set_direct_grad_slots(self.slots, self.reducer.stage_ready, self.reducer.flush)
         self.ops.set_side_defer(True)       # a stage's weight-gradient GEMMs may run into the next stage; joined below
         try:
             loss = self._fwd_bwd(x, fluid, target)
