@@ -122,9 +122,11 @@ class BucketReducer:
 def stage_buckets(model: nn.Module, blocks_per_bucket: Optional[int] = None) -> List[int]:
     """Bucket index per parameter: one bucket per top-level stage and per group of `blocks_per_bucket` consecutive processor blocks
     (gradient-ready order is the reverse of this list).  Each bucket is one collective: fewer, larger ones cost less host time
-    and fewer stream synchronisations, more of them start the exchange earlier (BF_BLOCKS_PER_BUCKET, default 4)."""
+    and fewer stream synchronisations, more of them start the exchange earlier: a bucket is launched one bucket late (see
+    BucketReducer.stage_ready), so at the end of the backward two buckets are still travelling.  BF_BLOCKS_PER_BUCKET, default 2
+    (19 MB of fp32 gradients per collective for FiLMAViT-small)."""
     if blocks_per_bucket is None:
-        blocks_per_bucket = int(os.environ.get("BF_BLOCKS_PER_BUCKET", "4"))
+        blocks_per_bucket = int(os.environ.get("BF_BLOCKS_PER_BUCKET", "2"))
     ids, names = [], {}
     for name, p in model.named_parameters():
         if not p.requires_grad:
