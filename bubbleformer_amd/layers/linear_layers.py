@@ -2,6 +2,7 @@
 
 ``GeluMLP`` and ``FiLMMLP`` are consumed by the fused stages (the axial block's MLP GEMM pair, and the patch
 embed whose last InstanceNorm absorbs the FiLM scale/shift); they hold the parameters under the reference's names.
+Both also run on their own (``ops.gelu_mlp`` / ``ops.film``: native kernels, forward and backward).
 """
 import torch
 import torch.nn as nn
@@ -15,7 +16,10 @@ class GeluMLP(nn.Module):
         self.act = nn.GELU()
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError("GeluMLP runs fused inside AxialAttentionBlock (csrc/model.hip: bf_spatial_fwd)")
+        """fc2(GELU(fc1(x))) on the last dimension (linear_layers.py:18-25), as native GEMMs with the bias / GELU / gelu' epilogues.
+        Inside AxialAttentionBlock the pair runs as part of the fused stage (csrc/model.hip: bf_spatial_fwd) instead."""
+        from .. import ops
+        return ops.gelu_mlp(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
 
 
 class SirenMLP(nn.Module):
@@ -42,4 +46,7 @@ class FiLMMLP(nn.Module):
         return (self.film_net[0].weight, self.film_net[0].bias, self.film_net[1].weight, self.film_net[1].bias)
 
     def forward(self, x: torch.Tensor, cond) -> torch.Tensor:
-        raise NotImplementedError("FiLMMLP runs fused with the patch embed (csrc/model.hip: bf_embed_fwd)")
+        """gamma * x + beta with (gamma, beta) = film_net(cond).chunk(2), x (B, T, C, h, w) (linear_layers.py:63-77), on native kernels.
+        In the model the modulation rides inside the fused patch embed (csrc/model.hip: bf_embed_fwd) instead."""
+        from .. import ops
+        return ops.film(x, cond, *self.film_params())

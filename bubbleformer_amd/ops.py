@@ -379,6 +379,111 @@ def debed_with_loss(x, target, patch, cout, conv_w, in_w, in_b):
 
 
 # ------------------------------------------------------------------------------------------------ optimizer
+class _GeluMlpFn(torch.autograd.Function):
+    """fc2(gelu(fc1(x))) on the last dimension as four (forward: two) native GEMMs -- `GeluMLP.forward` used on its own
+    (bubbleformer/layers/linear_layers.py:18-25); inside the axial block the same GEMMs run as part of bf_spatial_fwd / bwd."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        _require_gpu(x)
+        from . import kernels as K
+        dt = x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        D, Hd = w1.shape[1], w1.shape[0]
+        x2 = x.reshape(-1, D).to(dt).contiguous()
+        M = x2.shape[0]
+        w1c, w2c = w1.to(dt).contiguous(), w2.to(dt).contiguous()
+        pre = torch.empty(M, Hd, dtype=dt, device=x.device)
+        hid = torch.empty(M, Hd, dtype=dt, device=x.device)
+        out = torch.empty(M, D, dtype=dt, device=x.device)
+        K.gemm(dt, M, Hd, D, K.operand(x2, D), K.operand(w1c, D), K.epilogue(pre, Hd, bias=_f32c(b1), gelu_out=hid))
+        K.gemm(dt, M, D, Hd, K.operand(hid, Hd), K.operand(w2c, Hd), K.epilogue(out, D, bias=_f32c(b2)))
+        ctx.save_for_backward(x2, pre, hid, w1c, w2c)
+        ctx.shape, ctx.in_dtype = x.shape, x.dtype
+        return out.reshape(x.shape).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import kernels as K
+        x2, pre, hid, w1c, w2c = ctx.saved_tensors
+        dt = x2.dtype
+        M, D = x2.shape
+        Hd = pre.shape[1]
+        dev = x2.device
+        dy = dout.reshape(M, D).to(dt).contiguous()
+        dw1 = torch.zeros(Hd, D, dtype=torch.float32, device=dev)
+        db1 = torch.zeros(Hd, dtype=torch.float32, device=dev)
+        dw2 = torch.zeros(D, Hd, dtype=torch.float32, device=dev)
+        db2 = torch.zeros(D, dtype=torch.float32, device=dev)
+        dpre = torch.empty(M, Hd, dtype=dt, device=dev)
+        dx = torch.empty(M, D, dtype=dt, device=dev)
+        sk = max(1, min(64, M // 512))
+        XC, AT = L.BF_LAY_XC, L.BF_OUT_ATOMIC_F32
+        K.gemm(dt, D, Hd, M, K.operand(dy, D, layout=XC), K.operand(hid, Hd, layout=XC), K.epilogue(dw2, Hd, out_mode=AT, colsum=db2), splitk=sk)
+        K.gemm(dt, M, Hd, D, K.operand(dy, D), K.operand(w2c, Hd, layout=XC), K.epilogue(dpre, Hd, aux_mode=L.BF_AUX_DGELU, aux=pre, ld_aux=Hd))
+        K.gemm(dt, Hd, D, M, K.operand(dpre, Hd, layout=XC), K.operand(x2, D, layout=XC), K.epilogue(dw1, D, out_mode=AT, colsum=db1), splitk=sk)
+        K.gemm(dt, M, D, Hd, K.operand(dpre, Hd), K.operand(w1c, D, layout=XC), K.epilogue(dx, D))
+        return dx.reshape(ctx.shape).to(ctx.in_dtype), dw1, db1, dw2, db2
+
+
+def gelu_mlp(x: torch.Tensor, w1, b1, w2, b2) -> torch.Tensor:
+    return _GeluMlpFn.apply(x, w1, b1, w2, b2)
+
+
+class _FilmFn(torch.autograd.Function):
+    """`FiLMMLP.forward` used on its own (bubbleformer/layers/linear_layers.py:63-77): gamma, beta = Linear(LayerNorm(cond)).chunk(2);
+    out = gamma * x + beta over x (B, T, C, h, w).  Native pieces: bf_film_net_fwd / bwd for the conditioning network,
+    bf_affine_apply for the modulation and its data gradient, and the InstanceNorm-backward reduction (mean 0, rstd 1: its
+    per-frame partials are exactly sum(dout) and sum(dout * x)) for d gamma / d beta.  In the model FiLM rides inside bf_embed_fwd."""
+
+    @staticmethod
+    def forward(ctx, x, cond, lnw, lnb, W, bias):
+        _require_gpu(x)
+        lib = L.lib()
+        B, T, Cc, h, w = x.shape
+        dt = x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        tok = as_tokens(x.to(dt))                                     # (B, T, h, w, C)
+        cond = cond.contiguous().float()
+        P = cond.shape[1]
+        prm = [_f32c(t) for t in (lnw, lnb, W, bias)]
+        gb = torch.empty(2, B, Cc, dtype=torch.float32, device=x.device)          # the kernel's layout: [gamma | beta][B][C]
+        chat = torch.empty(B, P, dtype=torch.float32, device=x.device)
+        crstd = torch.empty(B, dtype=torch.float32, device=x.device)
+        L.check(lib.bf_film_net_fwd(_p(cond), *[_p(t) for t in prm], _p(gb), _p(chat), _p(crstd), B, P, 2 * Cc, _stream()), "bf_film_net_fwd")
+        gamma, beta = gb[0], gb[1]
+        out = torch.empty_like(tok)
+        S = T * h * w
+        L.check(lib.bf_affine_apply(_dt(dt), _p(tok), None, _p(gamma), _p(beta), _p(out), B * S, S, Cc, _stream()), "bf_affine_apply")
+        ctx.save_for_backward(tok, gamma, chat, *prm)
+        ctx.dims = (B, T, Cc, h, w, P, x.dtype)
+        return as_reference_layout(out).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = L.lib()
+        tok, gamma, chat, lnw, lnb, W, bias = ctx.saved_tensors
+        B, T, Cc, h, w, P, in_dtype = ctx.dims
+        dt, dev, S = tok.dtype, tok.device, T * h * w
+        dtok = as_tokens(dout.to(dt))
+        dx = torch.empty_like(tok)
+        L.check(lib.bf_affine_apply(_dt(dt), _p(dtok), None, _p(gamma), None, _p(dx), B * S, S, Cc, _stream()), "bf_affine_apply")
+        zero = torch.zeros(B, Cc, dtype=torch.float32, device=dev)
+        one = torch.ones(B, Cc, dtype=torch.float32, device=dev)
+        ws = torch.zeros(lib.bf_in_ws_floats(_dt(dt), B, S, Cc), dtype=torch.float32, device=dev)
+        junk = torch.empty_like(tok)
+        L.check(lib.bf_in_bwd(_dt(dt), _p(dtok), _p(tok), None, _p(junk), B, S, Cc, _p(zero), _p(one), _p(one[0].contiguous()), _p(zero[0].contiguous()),
+                              None, 1, 0, None, None, None, None, _p(ws), _stream()), "bf_in_bwd")
+        part = ws[:B * Cc * 2].view(B, Cc, 2)                         # {sum dout, sum dout * x} per (batch element, channel)
+        dgb = torch.stack([part[..., 1], part[..., 0]]).contiguous()          # [d gamma | d beta][B][C]
+        gr = [torch.zeros_like(t) for t in (W, bias, lnw, lnb)]
+        L.check(lib.bf_film_net_bwd(_p(dgb), _p(chat), _p(lnw), _p(lnb), _p(W), *[_p(t) for t in gr], B, P, 2 * Cc, _stream()), "bf_film_net_bwd")
+        dW, dbias, dlnw, dlnb = gr
+        return as_reference_layout(dx).to(in_dtype), None, dlnw, dlnb, dW, dbias
+
+
+def film(x: torch.Tensor, cond: torch.Tensor, lnw, lnb, W, bias) -> torch.Tensor:
+    return _FilmFn.apply(x, cond, lnw, lnb, W, bias)
+
+
 def clip_gather(frames: torch.Tensor, first: torch.Tensor, t0: int, T: int, table, Ho: int, Wo: int) -> torch.Tensor:
     """frames [fields][total_frames][H][W] fp32 (device), first [B] int64 absolute first input frame per sample, table =
     (field ids int32 [C], diff fp32 [C], div fp32 [C]) -> (B, T, C, Ho, Wo) fp32 normalised clips (data/dataset.py)."""

@@ -283,3 +283,50 @@ def test_attention_mfma_matches_generic_and_fp32(L, d, heads, axis):
             assert float((a - b).norm()) < 1e-2 * float(g_f[0].norm()), (name, float((a - b).norm()), float(g_f[0].norm()))
         else:
             assert float((a - b).norm()) / float(b.norm()) < (1e-1 if name == "dhscale" else 5e-2), (name, float((a - b).norm()) / float(b.norm()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gelu_mlp_layer_standalone(dtype):
+    """layers.GeluMLP used on its own (linear_layers.py:5-25): forward and every gradient vs torch in fp64."""
+    from bubbleformer_amd.layers import GeluMLP
+    torch.manual_seed(4)
+    m = GeluMLP(96).cuda()
+    x = torch.randn(3, 7, 11, 96, device="cuda").to(dtype).requires_grad_(True)
+    y = m(x)
+    g = torch.randn_like(y)
+    y.backward(g)
+    xr = x.detach().double().requires_grad_(True)
+    w1, b1, w2, b2 = (p.detach().double().requires_grad_(True) for p in (m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias))
+    if dtype == torch.bfloat16:                      # the GEMMs see bf16 weights
+        w1, w2 = (w.detach().bfloat16().double().requires_grad_(True) for w in (w1, w2))
+    yr = torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(xr, w1, b1)), w2, b2)
+    yr.backward(g.double())
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert y.shape == x.shape and y.dtype == dtype
+    assert _rel(y.detach().double(), yr.detach()) < tol and _rel(x.grad.double(), xr.grad) < tol
+    for got, want in ((m.fc1.weight.grad, w1.grad), (m.fc1.bias.grad, b1.grad), (m.fc2.weight.grad, w2.grad), (m.fc2.bias.grad, b2.grad)):
+        assert _rel(got.double(), want) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_film_layer_standalone(dtype):
+    """layers.FiLMMLP used on its own (linear_layers.py:49-77): gamma * x + beta and every gradient vs torch in fp64."""
+    from bubbleformer_amd.layers import FiLMMLP
+    torch.manual_seed(6)
+    B, T, Cc, h, w, P = 3, 4, 64, 5, 6, 9
+    m = FiLMMLP(P, Cc).cuda()
+    x = torch.randn(B, T, Cc, h, w, device="cuda").to(dtype).requires_grad_(True)
+    cond = torch.randn(B, P, device="cuda")
+    y = m(x, cond)
+    g = torch.randn_like(y)
+    y.backward(g)
+    ref = torch.nn.Sequential(torch.nn.LayerNorm(P), torch.nn.Linear(P, 2 * Cc)).cuda().double()
+    ref.load_state_dict({k: v.double() for k, v in m.film_net.state_dict().items()})
+    xr = x.detach().double().requires_grad_(True)
+    gamma, beta = ref(cond.double()).chunk(2, dim=1)
+    yr = gamma.view(-1, 1, Cc, 1, 1) * xr + beta.view(-1, 1, Cc, 1, 1)
+    yr.backward(g.double())
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-2
+    assert y.shape == x.shape and _rel(y.detach().double(), yr.detach()) < tol and _rel(x.grad.double(), xr.grad) < tol
+    for a, b in zip(m.film_net.parameters(), ref.parameters()):
+        assert _rel(a.grad.double(), b.grad) < tol
