@@ -75,7 +75,8 @@ int splitk_for(int M, int N, long K) {
     // sweep (tools/dw_sweep.py) prefers ~64/sqrt(tiles) slices, but inside the full step that loses 5% (A/B on the bench: 351 vs
     // 369 samples/s) to the rule below.
     const long tiles = (long)bf_cdiv(M, 128) * bf_cdiv(N, 128);
-    long s = (256 + tiles / 2) / tiles;   // ~one wave of tiles over 256 CUs; more slices lose to atomic traffic in the full step
+    static const long target = []() { const char* v = getenv("BF_SPLITK_TARGET"); return v ? atol(v) : 256L; }();
+    long s = (target + tiles / 2) / tiles;   // ~one wave of tiles over 256 CUs; more slices lose to atomic traffic in the full step
     const long kt = (K + 63) / 64;
     if (s > kt / 4) s = kt / 4;                         // at least 4 K-steps per slice
     if (s < 1) s = 1;
