@@ -24,8 +24,7 @@ vp, fp, i32, i64, f32 = C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 class Operand(C.Structure):
     _fields_ = [("p", vp), ("ld", i64), ("layout", i32), ("seglen", i32), ("segstride", i64), ("gw", i32), ("gh", i32),
-                ("gc", i32), ("pro", i32), ("sc", fp), ("sh", fp), ("rows_per_frame", i32), ("nch", i32), ("rowscale", fp),
-                ("rows_per_group", i32)]
+                ("gc", i32), ("pro", i32), ("sc", fp), ("sh", fp), ("rows_per_frame", i32), ("nch", i32)]
 
 
 class Epilogue(C.Structure):
@@ -75,9 +74,7 @@ SIGNATURES = {
     "bf_side_join": (C.c_int, [vp]),
     "bf_prof_report": (C.c_int, [C.c_char_p, C.c_int]),
     "bf_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, P(Operand), P(Operand), P(Epilogue), C.c_int, vp]),
-    "bf_gemm_inbwd_frames": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, vp, vp, vp, C.c_int, fp, fp, fp, fp, fp,
-                                       C.c_int, vp]),
-    "bf_gemm_inbwd_frames_ok": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, i64, i64, C.c_int]),
+    "bf_gemm_inbwd_frames": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, vp, vp, vp, C.c_int, fp, fp, fp, fp, vp]),
     "bf_in_stats": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, fp, fp, fp, C.c_int, fp, fp, fp, fp, fp, fp, vp]),
     "bf_in_ws_floats": (i64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "bf_affine_apply": (C.c_int, [C.c_int, vp, vp, fp, fp, vp, i64, C.c_int, C.c_int, vp]),

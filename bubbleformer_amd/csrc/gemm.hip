@@ -48,7 +48,6 @@ struct Stager {
     static constexpr int NCH = TR * TC / CH / NT;   // chunks per thread; chunk i sits at tile row r0 + (NT / CPR) * i, tile col cc
     static constexpr int RSTEP = NT / CPR;
     Chunk<T> data[NCH];
-    float fac[XC ? NCH : 1];   // row factors of an outer-contiguous operand (fetched together with the rows)
     unsigned valid;
     int k0;
 };
@@ -114,10 +113,6 @@ struct StagerFixed {
             }
         } else {
             const int left = kend - k0 - r0;                                             // rows of this thread still in range
-            if (op.rs != nullptr) {
-#pragma unroll
-                for (int i = 0; i < NCH; ++i) s.fac[i] = (ok && RSTEP * i < left) ? op.rs[(unsigned)(k0 + r0 + RSTEP * i) / (unsigned)op.rpg] : 0.f;
-            }
             if (!gather) {
                 const T* tile = reinterpret_cast<const T*>(op.p) + (long)k0 * op.ld;    // wave-uniform
 #pragma unroll
@@ -134,19 +129,6 @@ struct StagerFixed {
                         s.data[i].load(base + row_base(k0 + r0 + RSTEP * i, op.ld, op.gw, op.gh, op.gc));
                     } else s.data[i].zero();
                 }
-            }
-        }
-    }
-    // outer-contiguous operands: memory row k (a token) times op.rs[k / op.rpg] -- the stochastic-depth factor of a branch gradient,
-    // applied to the staged registers (before the fused bias-gradient column sums read them)
-    __device__ __forceinline__ void rowscale(Stager<T, TR, TC, LDT, XC, NT>& s, const OpDev& op) const {
-        if constexpr (XC) {
-            if (op.rs == nullptr) return;
-#pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                if (!((s.valid >> i) & 1u)) continue;
-#pragma unroll
-                for (int j = 0; j < CH; ++j) s.data[i].set(j, s.data[i].get(j) * s.fac[i]);
             }
         }
     }
@@ -261,7 +243,6 @@ __global__ void __launch_bounds__(NT) gemm_kernel(int M, int N, int K, OpDev A, 
             }
         };
         if (k0 < kend) {      // tile 0 -> buffer 0, tile 1 in flight
-            if constexpr (AXC) fa_.rowscale(sa[0], A);
             colsum_acc();
             fa_.template commit<APRO>(sa[0], A, ta, lA, m0);
             fb_.template commit<BPRO>(sb[0], B, tb, lB, n0);
@@ -286,7 +267,6 @@ __global__ void __launch_bounds__(NT) gemm_kernel(int M, int N, int K, OpDev A, 
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
             }
             if (k0 + BK < kend) {      // next tile into the other buffer (nobody reads it until the barrier below)
-                if constexpr (AXC) fa_.rowscale(sa[0], A);
                 colsum_acc();
                 fa_.template commit<APRO>(sa[0], A, ta, lA + (cur ^ 1) * BUF, m0);
                 fb_.template commit<BPRO>(sb[0], B, tb, lB + (cur ^ 1) * BUF, n0);
@@ -302,7 +282,6 @@ __global__ void __launch_bounds__(NT) gemm_kernel(int M, int N, int K, OpDev A, 
             if (k0 < kend) {
                 __syncthreads();
                 if (!(dbg & 4) || k0 == kbeg) {
-                    if constexpr (AXC) fa_.rowscale(sa[s], A);
                     if constexpr (AXC) {            // fused bias gradient: column sums of the raw A operand (d output)
                     if (do_colsum) {
 #pragma unroll
@@ -373,7 +352,6 @@ OpDev to_dev(const bf_operand* o) {
     d.p = o->p; d.ld = o->ld; d.layout = o->layout; d.seglen = o->seglen; d.segstride = o->segstride;
     d.gw = o->gw; d.gh = o->gh; d.gc = o->gc; d.pro = o->pro; d.sc = o->sc; d.sh = o->sh;
     d.rpf = o->rows_per_frame > 0 ? o->rows_per_frame : 1; d.nch = o->nch > 0 ? o->nch : 1;
-    d.rs = o->rowscale; d.rpg = o->rows_per_group > 0 ? o->rows_per_group : 1;
     return d;
 }
 
@@ -464,8 +442,6 @@ extern "C" int bf_gemm(int dtype, int M, int N, int K, const bf_operand* A, cons
                "bf_gemm: the token-reduction form (A outer-contiguous) accumulates with fp32 atomics, the other forms store");
     BF_REQUIRE((long)M < (1L << 31) && (long)N < (1L << 31) && (long)K < (1L << 31), "bf_gemm: extents must fit 31 bits");
     if (E->aux_mode != BF_AUX_NONE) BF_REQUIRE(E->aux != nullptr, "bf_gemm: aux pointer missing");
-    BF_REQUIRE(!B->rowscale && (!A->rowscale || (A->layout == BF_LAY_XC && A->gw == 0 && A->pro == BF_PRO_NONE)),
-               "bf_gemm: rowscale is implemented for a plain outer-contiguous A operand (the token-reduction form)");
     BF_REQUIRE(!E->colsum || A->layout == BF_LAY_XC, "bf_gemm: colsum is defined for the token-reduction form only");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == BF_DTYPE_BF16 && !g_no_wide) {

@@ -9,7 +9,6 @@ constexpr int TAB = 2048;   // floats per prologue-table array (sc, sh): 16 KiB 
 struct OpDev {
     const void* p; long ld; int layout; int seglen; long segstride; int gw, gh, gc;
     int pro; const float* sc; const float* sh; int rpf; int nch;
-    const float* rs; int rpg;       // row scale of an outer-contiguous operand: memory row k times rs[k / rpg]
 };
 struct EpiDev {
     const float* bias; const float* colscale; const float* colshift; int aux_mode; const void* aux; long ld_aux;

@@ -223,7 +223,7 @@ int launch_wide(Kern kern, int tm, int M, int N, int K, const OpDev& a, const Op
 int bf_gemm_wide_try(int M, int N, int K, const bf_operand* A, const bf_operand* B, const bf_epilogue* E, int splitk, hipStream_t st) {
     const bool ax = A->layout == BF_LAY_XC, bx = B->layout == BF_LAY_XC;
     if (ax && !bx) return 1;
-    if (E->colsum || A->rowscale) return 1;
+    if (E->colsum) return 1;
     if (A->gw > 0 || B->gw > 0 || A->seglen > 0 || B->seglen > 0 || E->gw > 0 || E->seglen > 0) return 1;
     if (N % 8 || N < 192) return 1;                        // narrow outputs waste the 384-wide tile
     if ((long)(ax ? K : M) * A->ld >= (1L << 31) || (long)(bx ? K : N) * B->ld >= (1L << 31)) return 1;   // 32-bit tile offsets
@@ -237,7 +237,7 @@ int bf_gemm_wide_try(int M, int N, int K, const bf_operand* A, const bf_operand*
     OpDev a, b;
     auto cv = [](const bf_operand* o, OpDev& d) {
         d.p = o->p; d.ld = o->ld; d.layout = o->layout; d.seglen = 0; d.segstride = 0; d.gw = d.gh = d.gc = 0; d.pro = o->pro; d.sc = o->sc;
-        d.sh = o->sh; d.rpf = o->rows_per_frame > 0 ? o->rows_per_frame : 1; d.nch = o->nch > 0 ? o->nch : 1; d.rs = nullptr; d.rpg = 1;
+        d.sh = o->sh; d.rpf = o->rows_per_frame > 0 ? o->rows_per_frame : 1; d.nch = o->nch > 0 ? o->nch : 1;
     };
     cv(A, a); cv(B, b);
     EpiDev e;

@@ -473,19 +473,9 @@ void* bwd_scratch(const D& d, void* scratch) {
 // A data gradient dy @ W whose consumer is the backward of the InstanceNorm that fed the projection: when a frame is one
 // 144-row GEMM tile the two run as ONE kernel (gemm_frame.hip); otherwise GEMM into `tmp`, then the InstanceNorm backward.
 struct InFuse { const void* x; const void* add; void* dx; const float* mean; const float* rstd; const float* w; const float* b; float* ws; };
-bool inbwd_fusable(const D& d, int Kdim, int Nout) { return bf_gemm_inbwd_frames_ok(d.dtype, (int)d.N, Nout, Kdim, Kdim, Nout, (int)d.S) != 0; }
-// the stochastic-depth factor of a branch gradient applied inside the consumers (BF_FUSE_DROP=0: a separate pass writes m * dout)
-bool drop_fusable(const D& d) {
-    static const bool off = []() { const char* v = getenv("BF_FUSE_DROP"); return v && atoi(v) == 0; }();
-    return !off && inbwd_fusable(d, d.E, d.E);
-}
-// fscale / fdiv: optional per-frame-group factor of dy (only honoured by the one-kernel form: callers check inbwd_fusable() first)
-int dgrad_inbwd(const D& d, const void* dy, int Kdim, const void* w_xc, int Nout, void* tmp, const InFuse& f, hipStream_t st,
-                const float* fscale = nullptr, int fdiv = 1) {
-    const int rc = bf_gemm_inbwd_frames(d.dtype, (int)d.N, Nout, Kdim, dy, Kdim, w_xc, Nout, f.x, f.add, f.dx, (int)d.S, f.mean, f.rstd, f.w, f.ws,
-                                        fscale, fdiv, st);
+int dgrad_inbwd(const D& d, const void* dy, int Kdim, const void* w_xc, int Nout, void* tmp, const InFuse& f, hipStream_t st) {
+    const int rc = bf_gemm_inbwd_frames(d.dtype, (int)d.N, Nout, Kdim, dy, Kdim, w_xc, Nout, f.x, f.add, f.dx, (int)d.S, f.mean, f.rstd, f.w, f.ws, st);
     if (rc <= 0) return rc;
-    BF_REQUIRE(fscale == nullptr, "dgrad_inbwd: a frame factor needs the one-kernel form");
     bf_operand A = op_plain(dy, Kdim, BF_LAY_KC);
     bf_operand Bo = op_plain(w_xc, Nout, BF_LAY_XC);
     bf_epilogue e = epi_store(tmp, Nout);
@@ -496,14 +486,11 @@ int dgrad_inbwd(const D& d, const void* dy, int Kdim, const void* w_xc, int Nout
 int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on, const void* w_s,
                 const float* W, const float* bias, const float* nb, const float* gamma, const float* lo, const float* hi,
                 const float* alpha, const float* mc, float* dW, float* dbias, float* dnb, float* dgamma, float* dlo, float* dhi,
-                void* don, hipStream_t st, Fork& fk, const InFuse* fu = nullptr, const float* rowscale = nullptr, long rows_per_group = 1) {
-    // rowscale: dout is the UNSCALED incoming gradient and the branch's stochastic-depth factor is applied on the fly -- to the staged
-    // rows of the G GEMM's operand and to the accumulators of the whole-frame data-gradient kernel (no pass that materialises m * dout)
+                void* don, hipStream_t st, Fork& fk, const InFuse* fu = nullptr) {
     TRY(fk.run([=](hipStream_t ss) -> int {           // parameter-gradient side: memset, G GEMM, finalize
         ZERO_ON(ss, sc.G, (size_t)((char*)sc.csum - (char*)sc.G) + (size_t)d.E * 4);     // G and csum are adjacent in the arena: one memset
         {   // G[n][k] = sum_m dout[m][n] * on[m][k]; `on` is the normalised operand the forward saved
             bf_operand A = op_plain(dout, d.E, BF_LAY_XC);
-            A.rowscale = rowscale; A.rows_per_group = (int)rows_per_group;
             bf_operand Bo = op_plain(on, d.E, BF_LAY_XC);
             bf_epilogue e = epi_atomic(sc.G, d.E);
             e.colsum = sc.csum;                  // dbeta = colsum(dout), fused into the same pass over dout
@@ -514,8 +501,7 @@ int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on,
         BF_CHECK_LAUNCH();
         return 0;
     }));
-    if (fu) return dgrad_inbwd(d, dout, d.E, w_s, d.E, don, *fu, st, rowscale, (int)(rows_per_group / d.S));      // ... followed by norm2's backward
-    BF_REQUIRE(rowscale == nullptr, "outproj_bwd: a row factor needs the fused form");
+    if (fu) return dgrad_inbwd(d, dout, d.E, w_s, d.E, don, *fu, st);      // ... followed by norm2's backward
     {   // don = (dout * alpha) @ W = dout @ (diag(alpha) W): the scaled weight was written by the forward's parameter prep
         bf_operand A = op_plain(dout, d.E, BF_LAY_KC);
         bf_operand Bo = op_plain(w_s, d.E, BF_LAY_XC);
@@ -612,16 +598,13 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
     void* dO = sc.t1b;      // [N][E]
     void* dqkv = sc.t3;     // [N][3E]
     const void* dbr = dout; // gradient entering the attention branch
-    const bool fuse2 = drop_fusable(d);      // whole-frame kernel available: the factor rides in it and in the G GEMM's staging
-    if (drop && !fuse2) {   // branch = drop[b] * (...): scale the incoming gradient once (2U pass), the rest is unchanged
+    if (drop) {             // branch = drop[b] * (...): scale the incoming gradient once (2U pass), the rest is unchanged
         TRY(bf_frame_scale(d.dtype, dout, drop, d.T, sc.t4, d.N, (int)d.S, d.E, st));
         dbr = sc.t4;
     }
-    const float* rsc = (drop && fuse2) ? drop : nullptr;
     const InFuse fu2{sv.o, nullptr, dO, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, sc.in_ws2};      // don @ ... then norm2's backward -> dO
     TRY(outproj_bwd(d, sc, dbr, sv.on, sv.wout_s, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr,
-                    sv.alpha, sv.mc, g->output_head_w, g->output_head_b, nullptr, g->gamma, nullptr, nullptr, don, st, fk, &fu2, rsc,
-                    (long)d.T * d.S));
+                    sv.alpha, sv.mc, g->output_head_w, g->output_head_b, nullptr, g->gamma, nullptr, nullptr, don, st, fk, &fu2));
     ReduceJobs jobs;        // parameter-gradient reductions, all launched together at the end
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws2, (int)d.F, d.E, p->norm2_w, p->norm2_b, nullptr, 1, g->norm2_w, g->norm2_b, nullptr, nullptr, nullptr, nullptr};
     {
@@ -746,18 +729,16 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     // folded out-projection
     void* don = sc.e6;
     const void* dbr = dx1;  // gradient entering the attention branch (dx1 itself continues down the residual)
-    const bool fuse2 = drop_fusable(d);
-    if (drop_att && !fuse2) {
+    if (drop_att) {
         TRY(bf_frame_scale(d.dtype, dx1, drop_att, 1, sc.e5, d.N, (int)d.S, d.E, st));
         dbr = sc.e5;
     }
-    const float* rsc = (drop_att && fuse2) ? drop_att : nullptr;
     void* dO = sc.e7;       // [N][E]
     const InFuse fu2{sv.o, nullptr, dO, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, sc.in_ws2};      // don @ ... then norm2's backward -> dO
     TRY(outproj_bwd(d, sc, dbr, sv.on, sv.wout_s, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att,
                     d.feat_scale ? p->low_freq_scalar : nullptr, d.feat_scale ? p->high_freq_scalar : nullptr, sv.alpha, sv.mc,
                     g->output_head_w, g->output_head_b, g->norm2_b, g->gamma_att, d.feat_scale ? g->low_freq_scalar : nullptr,
-                    d.feat_scale ? g->high_freq_scalar : nullptr, don, st, fk, &fu2, rsc, (long)d.S));
+                    d.feat_scale ? g->high_freq_scalar : nullptr, don, st, fk, &fu2));
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws2, (int)d.F, d.E, p->norm2_w, p->norm2_b, nullptr, 1, g->norm2_w, g->norm2_b, nullptr, nullptr, nullptr, nullptr};
     void* dqkv = sc.t3;
     {

@@ -9,8 +9,8 @@ from .ops import _dt, _p, _stream
 
 
 def operand(t=None, ld=0, layout=L.BF_LAY_KC, seglen=0, segstride=0, gw=0, gh=0, gc=0, pro=L.BF_PRO_NONE, sc=None, sh=None,
-            rows_per_frame=0, nch=0, rowscale=None, rows_per_group=0) -> L.Operand:
-    return L.Operand(_p(t), ld, layout, seglen, segstride, gw, gh, gc, pro, _p(sc), _p(sh), rows_per_frame, nch, _p(rowscale), rows_per_group)
+            rows_per_frame=0, nch=0) -> L.Operand:
+    return L.Operand(_p(t), ld, layout, seglen, segstride, gw, gh, gc, pro, _p(sc), _p(sh), rows_per_frame, nch)
 
 
 def epilogue(c, ldc, bias=None, colscale=None, colshift=None, aux_mode=L.BF_AUX_NONE, aux=None, ld_aux=0, out_mode=L.BF_OUT_STORE,
@@ -43,14 +43,14 @@ def in_bwd(dy, x, frames, S, Cc, mean, rstd, w, b, add=None, g=None, gdiv=1, gel
     return dx, dw, db
 
 
-def gemm_inbwd_frames(A, B, x, S, mean, rstd, w, add=None, framescale=None, frames_per_group=1):
+def gemm_inbwd_frames(A, B, x, S, mean, rstd, w, add=None):
     """Fused data-gradient GEMM + InstanceNorm backward (whole-frame tiles): returns (dx, ws) or None when the shape is not covered."""
     M, K = A.shape
     N = B.shape[1]
     out = torch.empty(M, N, dtype=x.dtype, device=x.device)
     ws = torch.zeros((M // S) * N * 2, dtype=torch.float32, device=x.device)
     rc = L.lib().bf_gemm_inbwd_frames(_dt(x.dtype), M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(x), _p(add), _p(out), S, _p(mean),
-                                      _p(rstd), _p(w), _p(ws), _p(framescale), frames_per_group, _stream())
+                                      _p(rstd), _p(w), _p(ws), _stream())
     if rc == 1:
         return None
     L.check(rc, "bf_gemm_inbwd_frames")

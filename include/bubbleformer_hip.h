@@ -69,9 +69,6 @@ typedef struct bf_operand {
     const float* sh;        /* [frames][nch] shift (NULL = 0) */
     int32_t rows_per_frame; /* frame = row / rows_per_frame   */
     int32_t nch;            /* channel = col % nch            */
-    const float* rowscale;  /* optional, outer-contiguous operands only: memory row k is multiplied by rowscale[k / rows_per_group]
-                               (the per-sample / per-frame stochastic-depth factor of a branch gradient, applied while staging) */
-    int32_t rows_per_group;
 } bf_operand;
 
 typedef struct bf_epilogue {
@@ -105,10 +102,7 @@ int bf_gemm(int dtype, int M, int N, int K, const bf_operand* A, const bf_operan
  * bf_gemm + bf_in_bwd; < 0 on error. */
 int bf_gemm_inbwd_frames(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, const void* x,
                          const void* add, void* out, int S, const float* mean, const float* rstd, const float* w, float* ws,
-                         const float* framescale /* optional: dy of frame f is multiplied by framescale[f / frames_per_group] */,
-                         int frames_per_group, bf_stream_t stream);
-/* 1 if bf_gemm_inbwd_frames covers the problem (it would not return 1), else 0 */
-int bf_gemm_inbwd_frames_ok(int dtype, int M, int N, int K, int64_t lda, int64_t ldb, int S);
+                         bf_stream_t stream);
 
 /* ---------------------------------------------------------------- kernel-level entry points (unit-testable) */
 

@@ -191,29 +191,7 @@ def test_gemm_inbwd_frames_at_the_bench_size(K):
     _check_gemm_inbwd_frames(K, 128, 1152, 384, True)
 
 
-def test_gemm_token_reduction_with_row_factor(K):
-    """dW = (m * dC)^T x and its fused bias gradient with the per-group row factor m applied while the operand is staged
-    (stochastic-depth factor of a branch gradient), split-K, vs scaling dC first."""
-    from bubbleformer_amd import _lib as L
-    Mtok, N, K_, rpg = 10 * 144, 384, 128, 288
-    g = torch.Generator(device="cuda").manual_seed(12)
-    dc = torch.randn(Mtok, N, device="cuda", generator=g).bfloat16()
-    x = torch.randn(Mtok, K_, device="cuda", generator=g).bfloat16()
-    m = torch.tensor([0.0, 1.25, 1.25, 0.0, 1.25], device="cuda")
-    out = torch.zeros(N, K_, device="cuda")
-    cs = torch.zeros(N, device="cuda")
-    K.gemm(torch.bfloat16, N, K_, Mtok, K.operand(dc, N, layout=L.BF_LAY_XC, rowscale=m, rows_per_group=rpg), K.operand(x, K_, layout=L.BF_LAY_XC),
-           K.epilogue(out, K_, out_mode=L.BF_OUT_ATOMIC_F32, colsum=cs), splitk=5)
-    scaled = (dc.float() * m.repeat_interleave(rpg)[:, None]).bfloat16().double()       # the staged rows are rounded to bf16 after scaling
-    assert _rel(out.double(), scaled.t() @ x.double()) < TOL[torch.bfloat16]
-    assert _rel(cs.double(), scaled.sum(0)) < TOL[torch.bfloat16]
-
-
-def test_gemm_inbwd_frames_with_frame_factor(K):
-    _check_gemm_inbwd_frames(K, 6, 384, 384, True, fdiv=2)
-
-
-def _check_gemm_inbwd_frames(K, Fr, Kd, N, with_add, fdiv=0):
+def _check_gemm_inbwd_frames(K, Fr, Kd, N, with_add):
     S = 144
     M = Fr * S
     g = torch.Generator(device="cuda").manual_seed(21)
@@ -224,17 +202,12 @@ def _check_gemm_inbwd_frames(K, Fr, Kd, N, with_add, fdiv=0):
     w = torch.randn(N, device="cuda", generator=g)
     b = torch.randn(N, device="cuda", generator=g)
     mean, rstd, _, _ = K.in_stats(x, Fr, S, N, w, b)
-    fs = None
-    if fdiv:
-        fs = torch.tensor([0.0, 1.0 / 0.8, 1.0 / 0.8][:Fr // fdiv], device="cuda")
-    res = K.gemm_inbwd_frames(A, W, x.view(M, N), S, mean, rstd, w, add=add, framescale=fs, frames_per_group=max(fdiv, 1))
+    res = K.gemm_inbwd_frames(A, W, x.view(M, N), S, mean, rstd, w, add=add)
     assert res is not None
     dx, ws = res
     torch.cuda.synchronize()
     # fp64 autograd on the same (bf16-valued) operands
     dy = A.double() @ W.double()
-    if fdiv:
-        dy = dy * fs.double().repeat_interleave(fdiv * S)[:, None]
     xr = x.double().requires_grad_(True)
     wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
     y = torch.nn.functional.instance_norm(xr.permute(0, 2, 1), weight=wr, bias=br, eps=1e-5).permute(0, 2, 1)
@@ -246,8 +219,6 @@ def _check_gemm_inbwd_frames(K, Fr, Kd, N, with_add, fdiv=0):
     # the two-kernel path rounds dy to bf16 in between: same answer to bf16 accuracy
     dyb = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     K.gemm(torch.bfloat16, M, N, Kd, K.operand(A, Kd, K.L.BF_LAY_KC), K.operand(W, N, K.L.BF_LAY_XC), K.epilogue(dyb, N))
-    if fdiv:
-        dyb = (dyb.float() * fs.repeat_interleave(fdiv * S)[:, None]).bfloat16()
     dx2, dw2, db2 = K.in_bwd(dyb.view(Fr, S, N), x, Fr, S, N, mean, rstd, w, b, add=add.view(Fr, S, N) if with_add else None)
     assert _rel(dx.double(), dx2.view(M, N).double()) < 1.5e-2
     # shapes outside the whole-frame form are refused, not mis-computed
