@@ -9,7 +9,8 @@
 //   k2s2 conv / conv-transpose  patch gather on an operand, patch scatter on the store
 // Operands are staged global -> registers (prologue: InstanceNorm affine and/or GELU, fp32) -> LDS;
 // the next K-tile's loads are in flight while the current tile is multiplied (issue-early / write-late).
-// 128x128 block tile, 4 waves (2x2), 64x64 per wave as 4x4 MFMA 16x16 tiles:
+// 128x128 block tile; bf16: 8 waves (2x4), 64x32 per wave as 4x2 MFMA 16x16 tiles, two workgroups per CU, two LDS tile buffers in
+// the prologue-free variants; f32 (and BF_GEMM_WAVES=4): 4 waves (2x2), 64x64 per wave.
 //   bf16: v_mfma_f32_16x16x32_bf16, BK = 64;   f32: v_mfma_f32_16x16x4_f32 (exact fp32), BK = 32.
 // The MFMA is issued "swapped" (B fragment as the first operand) so each lane ends up with 4
 // consecutive output COLUMNS of one row: 8-/16-byte epilogue stores and vector bias loads.
