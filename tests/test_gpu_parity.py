@@ -164,6 +164,53 @@ def test_train_step_reduces_loss():
     assert losses[-1] < losses[0] and all(l == l for l in losses), losses
 
 
+@pytest.mark.parametrize("optimizer", ["adamw", "lion"])
+def test_training_trajectory_matches_the_oracle_trained_with_torch(optimizer):
+    """Eight optimizer steps end to end -- forward, fused loss, backward, fused AdamW / Lion, per-batch cosine warm-up -- in fp32
+    against the oracle restatement in fp64 driven by torch.optim.AdamW / the restated Lion rule and the reference's scheduler
+    formula, fresh input every step: the loss sequence agrees to 2e-4 and the parameters after the last step to 5e-3 (relative L2
+    per tensor).  Adam and sign() turn the rounding noise of a structurally zero gradient into full-size steps, so the two all-zero
+    families are skipped and the bound leaves room for the partly-zero ones (the value third of `input_head.bias`: a per-channel
+    constant that the InstanceNorm after the attention removes) -- a wrong update direction in a tenth of a tensor would be 3e-2."""
+    from bubbleformer_amd.trainer import TrainStep
+    from bubbleformer_amd.utils.lr_schedulers import CosineWarmupLR
+    from oracle import filmavit_ref as R, weights as W
+    spec, z, model = build_product_model("tiny_d64", torch.float32)
+    cfg = spec["cfg"]
+    steps, base_lr, wd = 8, (2e-3 if optimizer == "adamw" else 2e-4), 1e-2
+    sched = CosineWarmupLR(base_lr, 3, steps, 1e-6)
+    step = TrainStep(model, lr=base_lr, weight_decay=wd, optimizer=optimizer, scheduler=sched)
+    sd = {k: v.double().requires_grad_(True) for k, v in W.generate(W.param_shapes(**cfg), seed=spec["seed"]).items()}
+    opt = torch.optim.AdamW(list(sd.values()), lr=base_lr, weight_decay=wd) if optimizer == "adamw" else None
+    mom = {k: torch.zeros_like(v) for k, v in sd.items()}
+    kw = dict(patch_size=cfg["patch_size"], num_heads=cfg["num_heads"])
+    got, want = [], []
+    for i in range(steps):
+        x = W.synthetic_clip(spec["B"], spec["T"], cfg["input_fields"], spec["H"], spec["W"], 400 + i)
+        y = W.synthetic_clip(spec["B"], spec["T"], cfg["output_fields"], spec["H"], spec["W"], 500 + i)
+        c = W.synthetic_fluid_params(spec["B"], cfg["num_fluid_params"], 600 + i)
+        got.append(float(step(x.cuda(), c.cuda(), y.cuda())))
+        lr = R.cosine_warmup_lr(i, base_lr, 3, steps, 1e-6)
+        for v in sd.values():
+            v.grad = None
+        loss = R.lp_loss(R.filmavit_forward(sd, x.double(), c.double(), **kw), y.double())
+        loss.backward()
+        want.append(float(loss.detach()))
+        with torch.no_grad():
+            if optimizer == "adamw":
+                for gp in opt.param_groups:
+                    gp["lr"] = lr
+                opt.step()
+            else:
+                for k, v in sd.items():
+                    R.lion_step(v, v.grad, mom[k], lr, 0.9, 0.99, wd)
+    assert np.allclose(got, want, rtol=2e-4), (got, want)
+    torch.cuda.synchronize()
+    for k, p_ in model.named_parameters():
+        if not structurally_zero(k):
+            assert rel_l2(p_.detach().cpu(), sd[k].detach()) < 5e-3, k
+
+
 def test_long_axes_two_block_attention_paths():
     """T = 18, w = 20, h = 3: sequence lengths in (16, 32] take the two-block MFMA attention path in bf16 mode and ragged
     masking in both modes.  fp32 mode vs the oracle run here (1e-4); bf16 mode vs fp32 mode (bf16 bounds)."""
