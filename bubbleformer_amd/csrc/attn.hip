@@ -365,6 +365,8 @@ int bf_attn_bwd_mfma(const void* qkv, const void* dout, void* dqkv, long nseq, i
                      long tok_stride, int heads, int d, const float* qw, const float* qb, const float* kw, const float* kb, const float* emb,
                      const float* hscale, float* dqw, float* dqb, float* dkw, float* dkb, float* demb, float* dhscale, float out_scale,
                      int accumulate, float* ws, long ws_floats, int* rows_out, hipStream_t st);
+int bf_attn_axial_fwd_mfma(const void* qkv, void* out, int frames, int h, int w, int heads, int d, const float* qw, const float* qb, const float* kw,
+                           const float* kb, const float* emb, const float* hscale_x, const float* hscale_y, hipStream_t st);
 static bool use_mfma(int dtype, int d) { return !g_force_generic && dtype == BF_DTYPE_BF16 && d % 32 == 0 && d <= 128; }
 
 extern "C" void bf_debug_force_generic_attn(int on) { g_force_generic = on != 0; }
@@ -394,6 +396,23 @@ extern "C" int bf_attn_fwd(int dtype, const void* qkv, void* out, int64_t nseq, 
         hipLaunchKernelGGL(attn_fwd_kernel<float>, dim3(grid), dim3(WPB * 64), shm, (hipStream_t)stream, (const float*)qkv, (float*)out, g, heads, d, p, out_scale, accumulate);
     BF_CHECK_LAUNCH();
     return 0;
+}
+
+// Both axial passes of AxialAttentionBlock (along W, then along H, averaged: layers/attention.py:212-297) on QKV [frames*h*w][3E].
+// One launch where the fused kernel covers the shape, otherwise the two bf_attn_fwd calls it is bit-identical to.
+extern "C" int bf_attn_axial_fwd(int dtype, const void* qkv, void* out, int64_t frames, int h, int w, int heads, int d, const float* qw,
+                                 const float* qb, const float* kw, const float* kb, const float* emb, const float* hscale_x,
+                                 const float* hscale_y, bf_stream_t stream) {
+    BF_REQUIRE(qkv && out && qw && qb && kw && kb && frames > 0 && h > 0 && w > 0, "bf_attn_axial_fwd: bad arguments");
+    if (use_mfma(dtype, d) && frames < (1L << 24)) {
+        BfProfScope prof((hipStream_t)stream, "attn_fwd", 4.0 * frames * heads * h * w * (h + w) * d, (double)frames * h * w * heads * d * 2.0 * 4.0);
+        const int rc = bf_attn_axial_fwd_mfma(qkv, out, (int)frames, h, w, heads, d, qw, qb, kw, kb, emb, hscale_x, hscale_y, (hipStream_t)stream);
+        if (rc <= 0) return rc;
+    }
+    const long S = (long)h * w;
+    int rc = bf_attn_fwd(dtype, qkv, out, frames * h, w, 1, w, 0, 1, heads, d, qw, qb, kw, kb, emb, hscale_x, 0.5f, 0, stream);
+    if (rc) return rc;
+    return bf_attn_fwd(dtype, qkv, out, frames * w, h, w, S, 1, w, heads, d, qw, qb, kw, kb, emb, hscale_y, 0.5f, 1, stream);
 }
 
 static int attn_bwd_impl(int dtype, const void* qkv, const void* dout, void* dqkv, int64_t nseq, int L, int64_t inner,

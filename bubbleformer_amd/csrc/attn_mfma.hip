@@ -345,6 +345,107 @@ __global__ void __launch_bounds__(256) attn_fwd_mfma(const bf16* __restrict__ qk
     }
 }
 
+// Axial attention forward, both passes in one launch (layers/attention.py:212-297: along W, then along H, (xx + xy) / 2).  A workgroup
+// owns one (frame, head): its waves first run the h row sequences and leave 0.5 * result in an LDS tile [h*w][D] (rounded to bf16
+// exactly as the two-launch form rounds its intermediate), then the w column sequences, which add their half and write the output
+// once.  QKV is read from HBM once (the second pass hits L2), the output is never read back: the two-launch form re-reads QKV and
+// read-modify-writes `out`.  Results are bit-identical to bf_attn_fwd(W, out_scale 0.5) + bf_attn_fwd(H, 0.5, accumulate).
+template <int KS>
+__global__ void __launch_bounds__(256) attn_fwd_axial_mfma(const bf16* __restrict__ qkv, bf16* __restrict__ out, int frames, int h, int w, int heads, Par p,
+                                                           const float* __restrict__ hscale_y) {
+    constexpr int NB = 1, D = 32 * KS, LD = D + 16, NT16 = D / 16, DP = D + 8;
+    extern __shared__ __attribute__((aligned(16))) bf16 smem_ax[];
+    __shared__ __attribute__((aligned(16))) float s_par[4 * 32 * KS];   // qw | qb | kw | kb
+    __shared__ float s_emb[32 * 16];
+    __shared__ float s_hsx[16], s_hsy[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    bf16* vt = smem_ax + wave * (16 * LD);
+    bf16* ot = smem_ax + wpb * (16 * LD);                                 // [h * w][DP]
+    for (int i = threadIdx.x; i < 32 * 16; i += blockDim.x) {
+        const int t = i >> 4, hd = i & 15;
+        s_emb[i] = (p.emb && hd < heads) ? p.emb[t * heads + hd] : 0.f;
+    }
+    if (threadIdx.x < 16) {
+        s_hsx[threadIdx.x] = (p.hscale && (int)threadIdx.x < heads) ? p.hscale[threadIdx.x] : 1.f;
+        s_hsy[threadIdx.x] = (hscale_y && (int)threadIdx.x < heads) ? hscale_y[threadIdx.x] : 1.f;
+    }
+    for (int i = threadIdx.x; i < 4 * D; i += blockDim.x) {
+        const int q = i / D, e = i % D;
+        s_par[i] = (q == 0 ? p.qw : q == 1 ? p.qb : q == 2 ? p.kw : p.kb)[e];
+    }
+    __syncthreads();
+    const int E = heads * D, S = h * w;
+    const float scale = rsqrtf((float)D);
+    const int gq = lane >> 4, i16 = lane & 15;
+    const Geo gW{(long)frames * h, w, 1, w, 0, 1}, gH{(long)frames * w, h, w, S, 1, w};
+    const int RW = (h + wpb - 1) / wpb, RH = (w + wpb - 1) / wpb;         // rounds per phase (uniform over the waves: barriers)
+    const long ntile = (long)frames * heads;
+    for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int frame = (int)(tile / heads), head = (int)(tile % heads);
+        for (int k = 0; k < RW + RH; ++k) {
+            const bool isH = k >= RW;
+            const int idx = wave + (isH ? k - RW : k) * wpb;
+            const int L = isH ? h : w;
+            if (k == RW) __syncthreads();                                   // every row sequence has left its half in the tile
+            if (idx < (isH ? w : h)) {
+                const Geo& g = isH ? gH : gW;
+                const long seq = (long)frame * (isH ? w : h) + idx;
+                FwdRows<NB, KS> cur;
+                load_fwd_rows<NB, KS>(cur, qkv, g, heads, seq * heads + head, lane);
+                bf16x8 qf[NB][KS], kf[NB][KS];
+                {
+                    float x[KS][8];
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) x[ks][j] = (float)cur.q[0][ks][j];
+                    ln_quad<KS>(x, D);
+                    affine_frag<KS>(x, s_par, s_par + D, scale, lane, qf[0]);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) x[ks][j] = (float)cur.k[0][ks][j];
+                    ln_quad<KS>(x, D);
+                    affine_frag<KS>(x, s_par + 2 * D, s_par + 3 * D, 1.f, lane, kf[0]);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {      // V tile for the transposing read; rows >= L are zeros
+                        bf16x8 zv = cur.v[0][ks];
+                        if (i16 >= L) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) zv[j] = (bf16)0.f;
+                        }
+                        *reinterpret_cast<bf16x8*>(vt + i16 * LD + 32 * ks + 8 * gq) = zv;
+                    }
+                }
+                float P[NB][NB][4], A[NB][NB][4];
+                scores_softmax<NB, KS>(kf, qf, p.emb ? s_emb : nullptr, 16, isH ? (hscale_y ? s_hsy : nullptr) : (p.hscale ? s_hsx : nullptr), head, L, lane, P, A);
+                wsync();   // V tile visible to the wave
+                const bf16x8 pa = pack_keys<NB>(A, 0);
+#pragma unroll
+                for (int t = 0; t < NT16; ++t) {
+                    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                    o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_keys<NB>(vt, LD, t, lane), pa, o, 0, 0, 0);
+                    if (i16 < L) {
+                        const int tok = isH ? i16 * w + idx : idx * w + i16;                 // token inside the frame
+                        bf16* cell = ot + tok * DP + 16 * t + 4 * gq;
+                        float v[4] = {o[0] * 0.5f, o[1] * 0.5f, o[2] * 0.5f, o[3] * 0.5f};
+                        if (isH) {
+                            const bf16x4 old = *reinterpret_cast<const bf16x4*>(cell);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += (float)old[r];
+                        }
+                        const bf16x4 w4 = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                        if (isH) *reinterpret_cast<bf16x4*>(out + ((long)frame * S + tok) * E + head * D + 16 * t + 4 * gq) = w4;
+                        else *reinterpret_cast<bf16x4*>(cell) = w4;
+                    }
+                }
+                wsync();   // before the next problem overwrites the V tile
+            }
+        }
+        __syncthreads();                                                   // the tile is free for the next (frame, head)
+    }
+}
+
 // The q / k / v / dO rows of one problem exactly as the MFMA operand layout wants them: lane (i = l & 15, g = l >> 4) holds
 // channels 32*s + 8*g .. +7 of row i.  The backward loads the NEXT problem's rows while it works on the current one: a wave runs
 // ~20 dependent phases per problem, and with only two waves per SIMD every exposed global round trip is paid in full.
@@ -770,6 +871,23 @@ int bf_attn_fwd_mfma(const void* qkv, void* out, long nseq, int L, long inner, l
     GO(1, 1); GO(1, 2); GO(1, 3); GO(1, 4); GO(2, 1); GO(2, 2); GO(2, 3); GO(2, 4);
 #undef GO
     return bf_fail_msg("bf_attn_fwd_mfma: unsupported shape", __FILE__, __LINE__);
+}
+// both axial passes in one launch (see attn_fwd_axial_mfma); 1 = shape not covered (the caller runs the two passes)
+int bf_attn_axial_fwd_mfma(const void* qkv, void* out, int frames, int h, int w, int heads, int d, const float* qw, const float* qb, const float* kw,
+                           const float* kb, const float* emb, const float* hscale_x, const float* hscale_y, hipStream_t st) {
+    static const bool off = []() { const char* v = getenv("BF_ATTN_AXIAL_FUSED"); return v && atoi(v) == 0; }();
+    if (off || h > 16 || w > 16 || h < 1 || w < 1 || d % 32 || d > 128 || heads > 16) return 1;
+    Par p{qw, qb, kw, kb, emb, hscale_x};
+    const int ks = d / 32, wpb = 4;
+    const size_t shm = ((size_t)wpb * 16 * (d + 16) + (size_t)h * w * (d + 8)) * sizeof(bf16);
+    const long ntile = (long)frames * heads;
+    const int grid = (int)std::min<long>(ntile, 256L * 3);
+#define GO(KS) if (ks == KS) { if (int rc = set_lds(attn_fwd_axial_mfma<KS>, shm)) return rc; \
+        hipLaunchKernelGGL((attn_fwd_axial_mfma<KS>), dim3(grid), dim3(wpb * 64), shm, st, (const bf16*)qkv, (bf16*)out, frames, h, w, heads, p, hscale_y); }
+    GO(1) GO(2) GO(3) GO(4)
+#undef GO
+    BF_CHECK_LAUNCH();
+    return 0;
 }
 int bf_attn_bwd_mfma(const void* qkv, const void* dout, void* dqkv, long nseq, int L, long inner, long outer_stride, long inner_stride,
                      long tok_stride, int heads, int d, const float* qw, const float* qb, const float* kw, const float* kb, const float* emb,

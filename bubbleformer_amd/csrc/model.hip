@@ -647,12 +647,9 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
     TRY(bf_in_stats_apply(d.dtype, x, (int)d.F, (int)d.S, d.E, p->norm1_w, p->norm1_b, nullptr, 1, nullptr, sv.mean1, sv.rstd1, sv.sc1, sv.sh1, sc.in_ws,
                           nullptr, sv.xn, st));
     TRY(qkv_gemm(d, sv.xn, win_c, p->input_head_b, sv.qkv, st));
-    // along w: one sequence per (frame, row): contiguous tokens
-    TRY(bf_attn_fwd(d.dtype, sv.qkv, sv.o, d.F * d.h, d.w, 1, d.w, 0, 1, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
-                    p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_x : nullptr, 0.5f, 0, st));
-    // along h: one sequence per (frame, column): stride w
-    TRY(bf_attn_fwd(d.dtype, sv.qkv, sv.o, d.F * d.w, d.h, d.w, d.S, 1, d.w, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
-                    p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_y : nullptr, 0.5f, 1, st));
+    // along w (one sequence per (frame, row): contiguous tokens), then along h (per (frame, column): stride w), averaged
+    TRY(bf_attn_axial_fwd(d.dtype, sv.qkv, sv.o, d.F, (int)d.h, (int)d.w, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b, p->rel_pos_emb,
+                          d.attn_scale ? p->attn_scale_factor_x : nullptr, d.attn_scale ? p->attn_scale_factor_y : nullptr, st));
     TRY(bf_in_stats_apply(d.dtype, sv.o, (int)d.F, (int)d.S, d.E, p->norm2_w, p->norm2_b, nullptr, 1, nullptr, sv.mean2, sv.rstd2, sv.sc2, sv.sh2, sc.in_ws,
                           nullptr, sv.on, st));
     TRY(outproj_gemm(d, sv.on, wout_c, sv.alpha, sv.beta, x, sv.x1, drop_att, d.S, st));     // mask per frame

@@ -133,6 +133,12 @@ int bf_colsum(int dtype, const void* x, int64_t nrows, int C, const float* scale
 int bf_attn_fwd(int dtype, const void* qkv, void* out, int64_t nseq, int L, int64_t inner, int64_t outer_stride,
                 int64_t inner_stride, int64_t tok_stride, int heads, int d, const float* qw, const float* qb, const float* kw,
                 const float* kb, const float* emb, const float* hscale, float out_scale, int accumulate, bf_stream_t stream);
+/* AxialAttentionBlock's attention core (layers/attention.py:212-297): attention along W with hscale_x, along H with hscale_y, both on
+ * the shared q/k LayerNorm and T5 table, out = (xx + xy) / 2.  qkv [frames*h*w][3E] token-major, out [frames*h*w][E].  One launch
+ * where h, w <= 16 (bf16), otherwise the two bf_attn_fwd passes; the results are bit-identical either way. */
+int bf_attn_axial_fwd(int dtype, const void* qkv, void* out, int64_t frames, int h, int w, int heads, int d, const float* qw,
+                      const float* qb, const float* kw, const float* kb, const float* emb, const float* hscale_x,
+                      const float* hscale_y, bf_stream_t stream);
 int bf_attn_bwd(int dtype, const void* qkv, const void* dout, void* dqkv, int64_t nseq, int L, int64_t inner,
                 int64_t outer_stride, int64_t inner_stride, int64_t tok_stride, int heads, int d, const float* qw,
                 const float* qb, const float* kw, const float* kb, const float* emb, const float* hscale, float* dqw,

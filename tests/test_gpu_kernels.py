@@ -330,3 +330,31 @@ def test_film_layer_standalone(dtype):
     assert y.shape == x.shape and _rel(y.detach().double(), yr.detach()) < tol and _rel(x.grad.double(), xr.grad) < tol
     for a, b in zip(m.film_net.parameters(), ref.parameters()):
         assert _rel(a.grad.double(), b.grad) < tol
+
+
+@pytest.mark.parametrize("h,w,heads,d", [(12, 12, 6, 64), (5, 9, 3, 32), (16, 3, 2, 128), (1, 7, 2, 96)])
+def test_axial_attention_forward_one_launch_equals_two_passes(h, w, heads, d):
+    """bf_attn_axial_fwd (W then H in one launch, intermediate in LDS) vs the two bf_attn_fwd passes it replaces: bit-identical,
+    and both agree with the fp32 generic kernels."""
+    import ctypes as C
+    from bubbleformer_amd import _lib as L
+    from bubbleformer_amd.ops import _p, _stream
+    lib = L.lib()
+    Fr, E = 7, heads * d
+    N = Fr * h * w
+    g = torch.Generator(device="cuda").manual_seed(17)
+    qkv = torch.randn(N, 3 * E, device="cuda", generator=g).bfloat16()
+    prm = [1 + 0.1 * torch.randn(d, device="cuda", generator=g), 0.1 * torch.randn(d, device="cuda", generator=g),
+           1 + 0.1 * torch.randn(d, device="cuda", generator=g), 0.1 * torch.randn(d, device="cuda", generator=g),
+           0.3 * torch.randn(32, heads, device="cuda", generator=g)]
+    hx = 1 + 0.3 * torch.randn(heads, device="cuda", generator=g)
+    hy = 1 + 0.3 * torch.randn(heads, device="cuda", generator=g)
+    one = torch.zeros(N, E, device="cuda", dtype=torch.bfloat16)
+    L.check(lib.bf_attn_axial_fwd(1, _p(qkv), _p(one), Fr, h, w, heads, d, *[_p(t) for t in prm], _p(hx), _p(hy), _stream()), "axial")
+    two = torch.zeros_like(one)
+    L.check(lib.bf_attn_fwd(1, _p(qkv), _p(two), Fr * h, w, 1, w, 0, 1, heads, d, *[_p(t) for t in prm], _p(hx), 0.5, 0, _stream()), "w")
+    L.check(lib.bf_attn_fwd(1, _p(qkv), _p(two), Fr * w, h, w, h * w, 1, w, heads, d, *[_p(t) for t in prm], _p(hy), 0.5, 1, _stream()), "h")
+    assert torch.equal(one, two)
+    ref = torch.zeros(N, E, device="cuda")                        # fp32 generic kernels through the same entry point
+    L.check(lib.bf_attn_axial_fwd(0, _p(qkv.float()), _p(ref), Fr, h, w, heads, d, *[_p(t) for t in prm], _p(hx), _p(hy), _stream()), "axial f32")
+    assert _rel(one.double(), ref.double()) < 2e-2
