@@ -82,6 +82,8 @@ SIGNATURES = {
                             fp, fp, fp, vp]),
     "bf_colsum": (C.c_int, [C.c_int, vp, i64, C.c_int, fp, fp, vp]),
     "bf_attn_axial_fwd": (C.c_int, [C.c_int, vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp, fp, vp]),
+    "bf_attn_axial_norm_fwd": (C.c_int, [C.c_int, vp, vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp,
+                                         fp, vp]),
     "bf_attn_fwd": (C.c_int, [C.c_int, vp, vp, i64, C.c_int, i64, i64, i64, i64, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp, f32,
                               C.c_int, vp]),
     "bf_attn_bwd": (C.c_int, [C.c_int, vp, vp, vp, i64, C.c_int, i64, i64, i64, i64, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp,

@@ -366,7 +366,8 @@ int bf_attn_bwd_mfma(const void* qkv, const void* dout, void* dqkv, long nseq, i
                      const float* hscale, float* dqw, float* dqb, float* dkw, float* dkb, float* demb, float* dhscale, float out_scale,
                      int accumulate, float* ws, long ws_floats, int* rows_out, hipStream_t st);
 int bf_attn_axial_fwd_mfma(const void* qkv, void* out, int frames, int h, int w, int heads, int d, const float* qw, const float* qb, const float* kw,
-                           const float* kb, const float* emb, const float* hscale_x, const float* hscale_y, hipStream_t st);
+                           const float* kb, const float* emb, const float* hscale_x, const float* hscale_y, const float* nw, const float* nb,
+                           void* out_n, float* mean, float* rstd, float* sc, float* sh, hipStream_t st);
 static bool use_mfma(int dtype, int d) { return !g_force_generic && dtype == BF_DTYPE_BF16 && d % 32 == 0 && d <= 128; }
 
 extern "C" void bf_debug_force_generic_attn(int on) { g_force_generic = on != 0; }
@@ -406,13 +407,30 @@ extern "C" int bf_attn_axial_fwd(int dtype, const void* qkv, void* out, int64_t 
     BF_REQUIRE(qkv && out && qw && qb && kw && kb && frames > 0 && h > 0 && w > 0, "bf_attn_axial_fwd: bad arguments");
     if (use_mfma(dtype, d) && frames < (1L << 24)) {
         BfProfScope prof((hipStream_t)stream, "attn_fwd", 4.0 * frames * heads * h * w * (h + w) * d, (double)frames * h * w * heads * d * 2.0 * 4.0);
-        const int rc = bf_attn_axial_fwd_mfma(qkv, out, (int)frames, h, w, heads, d, qw, qb, kw, kb, emb, hscale_x, hscale_y, (hipStream_t)stream);
+        const int rc = bf_attn_axial_fwd_mfma(qkv, out, (int)frames, h, w, heads, d, qw, qb, kw, kb, emb, hscale_x, hscale_y, nullptr, nullptr, nullptr,
+                                              nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream);
         if (rc <= 0) return rc;
     }
     const long S = (long)h * w;
     int rc = bf_attn_fwd(dtype, qkv, out, frames * h, w, 1, w, 0, 1, heads, d, qw, qb, kw, kb, emb, hscale_x, 0.5f, 0, stream);
     if (rc) return rc;
     return bf_attn_fwd(dtype, qkv, out, frames * w, h, w, S, 1, w, heads, d, qw, qb, kw, kb, emb, hscale_y, 0.5f, 1, stream);
+}
+
+// bf_attn_axial_fwd followed by the InstanceNorm2d of AxialAttentionBlock.norm2 (layers/attention.py:298) in the same launch: also
+// writes out_n = (out - mean) * rstd * w + b and mean / rstd / sc / sh [frames][E] as bf_in_stats does.  Returns 1 when the one-launch
+// form does not cover the shape (the caller then runs bf_attn_axial_fwd and bf_in_stats / bf_affine_apply).
+extern "C" int bf_attn_axial_norm_fwd(int dtype, const void* qkv, void* out, void* out_n, int64_t frames, int h, int w, int heads, int d,
+                                      const float* qw, const float* qb, const float* kw, const float* kb, const float* emb,
+                                      const float* hscale_x, const float* hscale_y, const float* norm_w, const float* norm_b, float* mean,
+                                      float* rstd, float* sc, float* sh, bf_stream_t stream) {
+    BF_REQUIRE(qkv && out && out_n && qw && qb && kw && kb && norm_w && norm_b && mean && rstd && sc && sh && frames > 0 && h > 0 && w > 0,
+               "bf_attn_axial_norm_fwd: bad arguments");
+    static const bool off = []() { const char* v = getenv("BF_ATTN_AXIAL_NORM"); return v && atoi(v) == 0; }();
+    if (off || !use_mfma(dtype, d) || frames >= (1L << 24)) return 1;
+    BfProfScope prof((hipStream_t)stream, "attn_fwd", 4.0 * frames * heads * h * w * (h + w) * d, (double)frames * h * w * heads * d * 2.0 * 5.0);
+    return bf_attn_axial_fwd_mfma(qkv, out, (int)frames, h, w, heads, d, qw, qb, kw, kb, emb, hscale_x, hscale_y, norm_w, norm_b, out_n, mean, rstd, sc,
+                                  sh, (hipStream_t)stream);
 }
 
 static int attn_bwd_impl(int dtype, const void* qkv, const void* dout, void* dqkv, int64_t nseq, int L, int64_t inner,

@@ -350,9 +350,13 @@ __global__ void __launch_bounds__(256) attn_fwd_mfma(const bf16* __restrict__ qk
 // exactly as the two-launch form rounds its intermediate), then the w column sequences, which add their half and write the output
 // once.  QKV is read from HBM once (the second pass hits L2), the output is never read back: the two-launch form re-reads QKV and
 // read-modify-writes `out`.  Results are bit-identical to bf_attn_fwd(W, out_scale 0.5) + bf_attn_fwd(H, 0.5, accumulate).
-template <int KS>
+// NORM: the InstanceNorm that follows the attention (norm2, layers/attention.py:298) runs here as well -- a (frame, head) tile holds
+// all h*w tokens of its d channels, i.e. everything a per-(frame, channel) statistic needs: two-pass mean / variance over the LDS tile,
+// then `out` and the normalised `out_n` (the out-projection's operand) are written together; the separate statistics launch is gone.
+struct AxNorm { const float* w; const float* b; bf16* out_n; float* mean; float* rstd; float* sc; float* sh; };
+template <int KS, bool NORM>
 __global__ void __launch_bounds__(256) attn_fwd_axial_mfma(const bf16* __restrict__ qkv, bf16* __restrict__ out, int frames, int h, int w, int heads, Par p,
-                                                           const float* __restrict__ hscale_y) {
+                                                           const float* __restrict__ hscale_y, AxNorm nrm) {
     constexpr int NB = 1, D = 32 * KS, LD = D + 16, NT16 = D / 16, DP = D + 8;
     extern __shared__ __attribute__((aligned(16))) bf16 smem_ax[];
     __shared__ __attribute__((aligned(16))) float s_par[4 * 32 * KS];   // qw | qb | kw | kb
@@ -435,14 +439,85 @@ __global__ void __launch_bounds__(256) attn_fwd_axial_mfma(const bf16* __restric
                             for (int r = 0; r < 4; ++r) v[r] += (float)old[r];
                         }
                         const bf16x4 w4 = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                        if (isH) *reinterpret_cast<bf16x4*>(out + ((long)frame * S + tok) * E + head * D + 16 * t + 4 * gq) = w4;
+                        if (isH && !NORM) *reinterpret_cast<bf16x4*>(out + ((long)frame * S + tok) * E + head * D + 16 * t + 4 * gq) = w4;
                         else *reinterpret_cast<bf16x4*>(cell) = w4;
                     }
                 }
                 wsync();   // before the next problem overwrites the V tile
             }
         }
-        __syncthreads();                                                   // the tile is free for the next (frame, head)
+        __syncthreads();                                                   // NORM: the tile holds the frame's output; else: it is free again
+        if constexpr (NORM) {
+            constexpr int CPR = D / 8, RGN = 256 / CPR;                     // 16-byte chunks per token row, row groups
+            float* red = reinterpret_cast<float*>(ot + ((S * DP + 7) & ~7)); // [RGN][D] partial sums, then [2][D] mean | rstd
+            float* stat = red + RGN * D;
+            const int cg = threadIdx.x % CPR, rg = threadIdx.x / CPR;
+            const bool act = rg < RGN;
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+            if (act)
+                for (int r = rg; r < S; r += RGN) {
+                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(ot + r * DP + cg * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+                }
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) red[rg * D + cg * 8 + j] = acc[j];
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < D) {
+                float t = 0.f;
+                for (int g2 = 0; g2 < RGN; ++g2) t += red[g2 * D + threadIdx.x];
+                stat[threadIdx.x] = t / (float)S;
+            }
+            __syncthreads();
+            float mu[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { mu[j] = stat[cg * 8 + j]; acc[j] = 0.f; }
+            if (act)
+                for (int r = rg; r < S; r += RGN) {
+                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(ot + r * DP + cg * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float dlt = (float)v[j] - mu[j]; acc[j] += dlt * dlt; }
+                }
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) red[rg * D + cg * 8 + j] = acc[j];
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < D) {
+                float t = 0.f;
+                for (int g2 = 0; g2 < RGN; ++g2) t += red[g2 * D + threadIdx.x];
+                const float r = rsqrtf(t / (float)S + BF_IN_EPS);
+                const int c = head * D + threadIdx.x;
+                const long o = (long)frame * E + c;
+                const float a = r * nrm.w[c], m = stat[threadIdx.x];
+                stat[D + threadIdx.x] = r;
+                nrm.mean[o] = m; nrm.rstd[o] = r; nrm.sc[o] = a; nrm.sh[o] = nrm.b[c] - m * a;
+            }
+            __syncthreads();
+            if (act) {
+                float aa[8], ss[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = head * D + cg * 8 + j;
+                    aa[j] = stat[D + cg * 8 + j] * nrm.w[c];
+                    ss[j] = nrm.b[c] - mu[j] * aa[j];
+                }
+                for (int r = rg; r < S; r += RGN) {
+                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(ot + r * DP + cg * 8);
+                    bf16x8 nv;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) nv[j] = (bf16)((float)v[j] * aa[j] + ss[j]);
+                    const long go = ((long)frame * S + r) * E + head * D + cg * 8;
+                    *reinterpret_cast<bf16x8*>(out + go) = v;
+                    *reinterpret_cast<bf16x8*>(nrm.out_n + go) = nv;
+                }
+            }
+            __syncthreads();                                               // the tile is free for the next (frame, head)
+        }
     }
 }
 
@@ -874,16 +949,23 @@ int bf_attn_fwd_mfma(const void* qkv, void* out, long nseq, int L, long inner, l
 }
 // both axial passes in one launch (see attn_fwd_axial_mfma); 1 = shape not covered (the caller runs the two passes)
 int bf_attn_axial_fwd_mfma(const void* qkv, void* out, int frames, int h, int w, int heads, int d, const float* qw, const float* qb, const float* kw,
-                           const float* kb, const float* emb, const float* hscale_x, const float* hscale_y, hipStream_t st) {
+                           const float* kb, const float* emb, const float* hscale_x, const float* hscale_y, const float* nw, const float* nb,
+                           void* out_n, float* mean, float* rstd, float* sc, float* sh, hipStream_t st) {
     static const bool off = []() { const char* v = getenv("BF_ATTN_AXIAL_FUSED"); return v && atoi(v) == 0; }();
     if (off || h > 16 || w > 16 || h < 1 || w < 1 || d % 32 || d > 128 || heads > 16) return 1;
     Par p{qw, qb, kw, kb, emb, hscale_x};
     const int ks = d / 32, wpb = 4;
-    const size_t shm = ((size_t)wpb * 16 * (d + 16) + (size_t)h * w * (d + 8)) * sizeof(bf16);
+    const bool norm = nw != nullptr;
+    const size_t tile = ((size_t)h * w * (d + 8) + 7) & ~(size_t)7;
+    const size_t shm = ((size_t)wpb * 16 * (d + 16) + tile) * sizeof(bf16) + (norm ? ((size_t)(256 / (d / 8)) + 2) * d * sizeof(float) : 0);
     const long ntile = (long)frames * heads;
     const int grid = (int)std::min<long>(ntile, 256L * 3);
-#define GO(KS) if (ks == KS) { if (int rc = set_lds(attn_fwd_axial_mfma<KS>, shm)) return rc; \
-        hipLaunchKernelGGL((attn_fwd_axial_mfma<KS>), dim3(grid), dim3(wpb * 64), shm, st, (const bf16*)qkv, (bf16*)out, frames, h, w, heads, p, hscale_y); }
+    const AxNorm nrm{nw, nb, (bf16*)out_n, mean, rstd, sc, sh};
+#define GO(KS) if (ks == KS) { \
+        if (norm) { if (int rc = set_lds(attn_fwd_axial_mfma<KS, true>, shm)) return rc; \
+            hipLaunchKernelGGL((attn_fwd_axial_mfma<KS, true>), dim3(grid), dim3(wpb * 64), shm, st, (const bf16*)qkv, (bf16*)out, frames, h, w, heads, p, hscale_y, nrm); } \
+        else { if (int rc = set_lds(attn_fwd_axial_mfma<KS, false>, shm)) return rc; \
+            hipLaunchKernelGGL((attn_fwd_axial_mfma<KS, false>), dim3(grid), dim3(wpb * 64), shm, st, (const bf16*)qkv, (bf16*)out, frames, h, w, heads, p, hscale_y, nrm); } }
     GO(1) GO(2) GO(3) GO(4)
 #undef GO
     BF_CHECK_LAUNCH();

@@ -648,10 +648,19 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
                           nullptr, sv.xn, st));
     TRY(qkv_gemm(d, sv.xn, win_c, p->input_head_b, sv.qkv, st));
     // along w (one sequence per (frame, row): contiguous tokens), then along h (per (frame, column): stride w), averaged
-    TRY(bf_attn_axial_fwd(d.dtype, sv.qkv, sv.o, d.F, (int)d.h, (int)d.w, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b, p->rel_pos_emb,
-                          d.attn_scale ? p->attn_scale_factor_x : nullptr, d.attn_scale ? p->attn_scale_factor_y : nullptr, st));
-    TRY(bf_in_stats_apply(d.dtype, sv.o, (int)d.F, (int)d.S, d.E, p->norm2_w, p->norm2_b, nullptr, 1, nullptr, sv.mean2, sv.rstd2, sv.sc2, sv.sh2, sc.in_ws,
-                          nullptr, sv.on, st));
+    {   // ... and norm2 in the same launch where the one-launch form applies
+        const int rc = bf_attn_axial_norm_fwd(d.dtype, sv.qkv, sv.o, sv.on, d.F, (int)d.h, (int)d.w, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w,
+                                              p->knorm_b, p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_x : nullptr,
+                                              d.attn_scale ? p->attn_scale_factor_y : nullptr, p->norm2_w, p->norm2_b, sv.mean2, sv.rstd2, sv.sc2,
+                                              sv.sh2, st);
+        if (rc < 0) return rc;
+        if (rc == 1) {
+            TRY(bf_attn_axial_fwd(d.dtype, sv.qkv, sv.o, d.F, (int)d.h, (int)d.w, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
+                                  p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_x : nullptr, d.attn_scale ? p->attn_scale_factor_y : nullptr, st));
+            TRY(bf_in_stats_apply(d.dtype, sv.o, (int)d.F, (int)d.S, d.E, p->norm2_w, p->norm2_b, nullptr, 1, nullptr, sv.mean2, sv.rstd2, sv.sc2, sv.sh2,
+                                  sc.in_ws, nullptr, sv.on, st));
+        }
+    }
     TRY(outproj_gemm(d, sv.on, wout_c, sv.alpha, sv.beta, x, sv.x1, drop_att, d.S, st));     // mask per frame
     {   // pre = x1 @ W1^T + b1 ; hid = gelu(pre) (both kept: pre for gelu', hid as the fc2 operand -- no erf in any prologue)
         bf_operand A = op_plain(sv.x1, d.E, BF_LAY_KC);

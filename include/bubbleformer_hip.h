@@ -139,6 +139,14 @@ int bf_attn_fwd(int dtype, const void* qkv, void* out, int64_t nseq, int L, int6
 int bf_attn_axial_fwd(int dtype, const void* qkv, void* out, int64_t frames, int h, int w, int heads, int d, const float* qw,
                       const float* qb, const float* kw, const float* kb, const float* emb, const float* hscale_x,
                       const float* hscale_y, bf_stream_t stream);
+/* The same followed, in the same launch, by AxialAttentionBlock.norm2 (InstanceNorm2d over the frame, layers/attention.py:298): also
+ * writes out_n = (out - mean) * rstd * norm_w + norm_b and mean / rstd / sc / sh [frames][E] exactly as bf_in_stats lays them out.
+ * Returns 0 when done, 1 when the one-launch form does not cover the shape (h, w <= 16, bf16): the caller then runs bf_attn_axial_fwd
+ * and bf_in_stats + bf_affine_apply. */
+int bf_attn_axial_norm_fwd(int dtype, const void* qkv, void* out, void* out_n, int64_t frames, int h, int w, int heads, int d,
+                           const float* qw, const float* qb, const float* kw, const float* kb, const float* emb, const float* hscale_x,
+                           const float* hscale_y, const float* norm_w, const float* norm_b, float* mean, float* rstd, float* sc,
+                           float* sh, bf_stream_t stream);
 int bf_attn_bwd(int dtype, const void* qkv, const void* dout, void* dqkv, int64_t nseq, int L, int64_t inner,
                 int64_t outer_stride, int64_t inner_stride, int64_t tok_stride, int heads, int d, const float* qw,
                 const float* qb, const float* kw, const float* kb, const float* emb, const float* hscale, float* dqw,

@@ -358,3 +358,40 @@ def test_axial_attention_forward_one_launch_equals_two_passes(h, w, heads, d):
     ref = torch.zeros(N, E, device="cuda")                        # fp32 generic kernels through the same entry point
     L.check(lib.bf_attn_axial_fwd(0, _p(qkv.float()), _p(ref), Fr, h, w, heads, d, *[_p(t) for t in prm], _p(hx), _p(hy), _stream()), "axial f32")
     assert _rel(one.double(), ref.double()) < 2e-2
+
+
+@pytest.mark.parametrize("h,w,heads,d", [(12, 12, 6, 64), (5, 9, 3, 32), (16, 3, 2, 128), (4, 7, 2, 96)])
+def test_axial_attention_forward_with_instance_norm(K, h, w, heads, d):
+    """bf_attn_axial_norm_fwd: the attention output is bit-identical to bf_attn_axial_fwd, and out_n / mean / rstd / sc / sh equal what
+    bf_in_stats + the affine apply give on that output (fp32 summation order aside)."""
+    from bubbleformer_amd import _lib as L
+    from bubbleformer_amd.ops import _p, _stream
+    lib = L.lib()
+    Fr, E = 5, heads * d
+    S = h * w
+    N = Fr * S
+    g = torch.Generator(device="cuda").manual_seed(23)
+    qkv = torch.randn(N, 3 * E, device="cuda", generator=g).bfloat16()
+    prm = [1 + 0.1 * torch.randn(d, device="cuda", generator=g), 0.1 * torch.randn(d, device="cuda", generator=g),
+           1 + 0.1 * torch.randn(d, device="cuda", generator=g), 0.1 * torch.randn(d, device="cuda", generator=g),
+           0.3 * torch.randn(32, heads, device="cuda", generator=g)]
+    hx = 1 + 0.3 * torch.randn(heads, device="cuda", generator=g)
+    hy = 1 + 0.3 * torch.randn(heads, device="cuda", generator=g)
+    nw = 1 + 0.2 * torch.randn(E, device="cuda", generator=g)
+    nb = 0.2 * torch.randn(E, device="cuda", generator=g)
+    o = torch.zeros(N, E, device="cuda", dtype=torch.bfloat16)
+    on = torch.zeros_like(o)
+    mean, rstd, sc, sh = (torch.zeros(Fr, E, device="cuda") for _ in range(4))
+    rc = lib.bf_attn_axial_norm_fwd(1, _p(qkv), _p(o), _p(on), Fr, h, w, heads, d, *[_p(t) for t in prm], _p(hx), _p(hy), _p(nw), _p(nb),
+                                    _p(mean), _p(rstd), _p(sc), _p(sh), _stream())
+    assert rc == 0
+    ref = torch.zeros_like(o)
+    L.check(lib.bf_attn_axial_fwd(1, _p(qkv), _p(ref), Fr, h, w, heads, d, *[_p(t) for t in prm], _p(hx), _p(hy), _stream()), "axial")
+    assert torch.equal(o, ref)
+    m2, r2, sc2, sh2 = K.in_stats(ref.view(Fr, S, E), Fr, S, E, nw, nb)
+    assert _rel(mean, m2) < 1e-5 and _rel(rstd, r2) < 1e-5 and _rel(sc, sc2) < 1e-5 and torch.allclose(sh, sh2, rtol=1e-4, atol=1e-5)
+    want = (ref.view(Fr, S, E).float() * sc2[:, None] + sh2[:, None]).view(N, E)
+    assert _rel(on.float(), want) < 6e-3
+    # a shape the one-launch form does not cover is refused, the caller then takes the two-step path
+    assert lib.bf_attn_axial_norm_fwd(1, _p(qkv), _p(o), _p(on), 1, 20, 2, heads, d, *[_p(t) for t in prm], _p(hx), _p(hy), _p(nw), _p(nb),
+                                      _p(mean), _p(rstd), _p(sc), _p(sh), _stream()) == 1
