@@ -178,17 +178,83 @@ def gen_physics(gold):
              eikonal_nb_f64=nb64)
 
 
+ROLLOUT = dict(model="avit", T=2, steps=20, start_time=5, seed=31,
+               cfg=dict(input_fields=4, output_fields=4, patch_size=8, embed_dim=64, num_heads=2, processor_blocks=2))
+
+
+def rollout_clips(T, steps, start_time):
+    """The (input, target) clips scripts/inference.py:239-241 takes from `test_dataset[itr]`, itr = 0, T, 2T, ...: frames
+    [start + itr, start + itr + T) and the T after them of the reference's own sample trajectory, fields sorted by name, each normalised
+    with the trajectory's mean / std (BubbleForecast norm="std").  Read with the in-tree HDF5 reader (data loading is not what this
+    fixture pins); returns float32 arrays (steps, T, C, H, W) x 2."""
+    from bubbleformer_amd.data import hdf5_lite
+    f = hdf5_lite.File(os.path.join(REPO, "tests", "golden", "samples", "sample_1.hdf5"))
+    fields = sorted(f.keys())
+    data = np.stack([np.array(f[k][...], dtype=np.float64) for k in fields], axis=1)          # (frames, C, H, W)
+    mean = data.mean(axis=(0, 2, 3), keepdims=True)
+    std = data.std(axis=(0, 2, 3), keepdims=True)
+    data = ((data - mean) / std).astype(np.float32)
+    inp = np.stack([data[start_time + i * T:start_time + (i + 1) * T] for i in range(steps)])
+    tgt = np.stack([data[start_time + (i + 1) * T:start_time + (i + 2) * T] for i in range(steps)])
+    return inp, tgt
+
+
+def gen_rollout(gold, ref_models, LpLoss):
+    """Autoregressive rollout of the REFERENCE model (generator weights) exactly as scripts/inference.py:231-252 runs it: eval mode,
+    each prediction fed back as the next input, criterion LpLoss(d=2, p=2, reduce_dims=[0, 1], reductions=["mean", "mean"]) against the
+    dataset target; plus the reference's eikonal_loss and the notebook's per-frame score of the predicted dfun channel."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("ref_losses_r", os.path.join(REF, "bubbleformer", "utils", "losses.py"))
+    losses = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(losses)
+    nb = json.load(open(os.path.join(REF, "scripts", "inference_autoregressive.ipynb")))
+    ns = {"torch": torch}
+    exec(next("".join(c["source"]) for c in nb["cells"] if c["cell_type"] == "code" and "def get_eikonal_loss" in "".join(c["source"])), ns)
+    R_ = ROLLOUT
+    inp, tgt = rollout_clips(R_["T"], R_["steps"], R_["start_time"])
+    out = {}
+    for dtype, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+        model = ref_models.get_model(R_["model"], time_window=R_["T"], drop_path=0.0, **R_["cfg"]).to(dtype)
+        model.load_state_dict({k: v.to(dtype) for k, v in W.generate(W.param_shapes(**R_["cfg"]), seed=R_["seed"]).items()})
+        model.eval()
+        criterion = LpLoss(d=2, p=2, reduce_dims=[0, 1], reductions=["mean", "mean"])
+        preds, crit, eik, eik_nb = [], [], [], []
+        with torch.no_grad():
+            for i in range(R_["steps"]):
+                x = torch.from_numpy(inp[i]).to(dtype) if not preds else preds[-1]
+                pred = model(x.unsqueeze(0)).squeeze(0)
+                preds.append(pred)
+                crit.append(float(criterion(pred, torch.from_numpy(tgt[i]).to(dtype))))
+                eik.append(float(losses.eikonal_loss(pred[:, 0])))
+                eik_nb.append(ns["get_eikonal_loss"](pred[:, 0]).numpy())
+        out["criterion_" + tag] = np.array(crit)
+        out["eikonal_" + tag] = np.array(eik)
+        out["eikonal_nb_" + tag] = np.stack(eik_nb)
+        out["preds_" + tag] = torch.stack(preds)
+    # fields: the fp64 prediction of step 5 and of the last step; the reference's OWN fp32 run measured against its fp64 run per step
+    # (random weights amplify rounding from step to step: this drift is the yardstick for any fp32 implementation)
+    p64, p32 = out.pop("preds_f64"), out.pop("preds_f32").double()
+    out["field_drift_f32"] = ((p32 - p64).flatten(1).norm(dim=1) / p64.flatten(1).norm(dim=1)).numpy()
+    out["pred4_f64"] = p64[4].numpy()
+    out["last_pred_f64"] = p64[-1].numpy()
+    np.savez(os.path.join(gold, "rollout.npz"), **out)
+
+
 def main():
     gold = os.path.join(REPO, "tests", "golden")
     os.makedirs(gold, exist_ok=True)
     if "--only-scheduler" in sys.argv or "--only-small" in sys.argv:
         gen_scheduler(gold)
         gen_physics(gold)
-        print("wrote cosine_warmup_lr.npz, physics.npz")
+        ref_models, _, LpLoss = _import_reference()
+        gen_rollout(gold, ref_models, LpLoss)
+        print("wrote cosine_warmup_lr.npz, physics.npz, rollout.npz")
         return
     gen_scheduler(gold)
     gen_physics(gold)
     ref_models, ref_layers, LpLoss = _import_reference()
+    gen_rollout(gold, ref_models, LpLoss)
     for name, spec in VARIANTS.items():
         np.savez(os.path.join(gold, f"model_{name}.npz"), **run_variant(name, spec, ref_models, LpLoss))
 
