@@ -4,6 +4,8 @@ ORACLE -- TEST INFRASTRUCTURE ONLY.  Generates tests/golden/*.npz by IMPORTING
 the real reference from /root/reference (CPU, fp64 and fp32) in the build
 container.  The reference never travels: only the data this script writes is
 committed.  Run:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+(`--only-small`: scheduler / physics / rollout fixtures only; `--fullsize [names]`: the full-width statistics
+fixtures fullsize_*.npz, a few minutes of CPU time, not part of the default run).
 
 ``timm`` (the reference's only missing dependency on this path: one symbol,
 ``timm.layers.DropPath``, layers/attention.py:6) is satisfied by an inert module
@@ -241,9 +243,70 @@ def gen_rollout(gold, ref_models, LpLoss):
     np.savez(os.path.join(gold, "rollout.npz"), **out)
 
 
+FULLSIZE = OrderedDict(      # BASELINE.json configs at full `film_avit_small` width and depth; seeds = tests/test_gpu_baseline_configs.py
+    config0_8x96x96_bs2=dict(B=2, T=8, H=96, W=96, seed=11),
+    config1_16x192x192=dict(B=1, T=16, H=192, W=192, seed=12),
+    config3_32x384x192=dict(B=1, T=32, H=384, W=192, seed=13),
+    config3_32x192x384=dict(B=1, T=32, H=192, W=384, seed=16),
+)
+FULLSIZE_CFG = dict(input_fields=4, output_fields=4, patch_size=16, embed_dim=384, num_heads=6, processor_blocks=12, num_fluid_params=9)
+NSAMP, NSAMP_PARAM = 2048, 16
+
+
+def sample_index(name, numel, n):
+    """Seeded positions at which a tensor is sampled for the full-size statistics (shared with the tests)."""
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+    return torch.randint(0, numel, (min(n, numel),), generator=g)
+
+
+def fullsize_stats(pred, loss, dx, grads):
+    """Kilobytes instead of tensors: per-(b, t, c) moments of the prediction, seeded samples of the
+    prediction and of dx, and per parameter the gradient's L2 norm and NSAMP_PARAM seeded entries."""
+    out = {"loss": np.float64(loss)}
+    p = pred.double()
+    out["pred_mean"] = p.mean(dim=(-1, -2)).numpy()
+    out["pred_std"] = p.std(dim=(-1, -2), unbiased=False).numpy()
+    out["pred_l2"] = p.flatten(-2).norm(dim=-1).numpy()
+    out["pred_samples"] = p.flatten()[sample_index("pred", p.numel(), NSAMP)].numpy()
+    d = dx.double()
+    out["dx_l2"] = d.flatten(-2).norm(dim=-1).numpy()
+    out["dx_samples"] = d.flatten()[sample_index("dx", d.numel(), NSAMP)].numpy()
+    names = sorted(grads)
+    out["grad_l2"] = np.array([float(grads[k].double().norm()) for k in names])
+    out["grad_samples"] = np.concatenate([grads[k].double().flatten()[sample_index(k, grads[k].numel(), NSAMP_PARAM)].numpy() for k in names])
+    return out
+
+
+def gen_fullsize(gold, ref_models, LpLoss, only=None):
+    """The REFERENCE model (fp64 arithmetic on the fp32-valued generator weights and seeded inputs) at BASELINE's full sizes."""
+    import time
+    for name, c in FULLSIZE.items():
+        if only and name not in only:
+            continue
+        t0 = time.time()
+        model = ref_models.get_model("filmavit", time_window=c["T"], drop_path=0.0, **FULLSIZE_CFG).double()
+        model.load_state_dict({k: v.double() for k, v in W.generate(W.param_shapes(**FULLSIZE_CFG), seed=c["seed"]).items()})
+        model.train()
+        x = W.synthetic_clip(c["B"], c["T"], 4, c["H"], c["W"], 100 + c["seed"]).double().requires_grad_(True)
+        y = W.synthetic_clip(c["B"], c["T"], 4, c["H"], c["W"], 200 + c["seed"]).double()
+        fp = W.synthetic_fluid_params(c["B"], 9, 300 + c["seed"]).double()
+        pred = model(x, fp)
+        loss = LpLoss(d=2, p=2, reduce_dims=[0, 1, 2], reductions=["mean", "mean", "sum"])(pred, y)      # modules.py:50
+        loss.backward()
+        stats = fullsize_stats(pred.detach(), float(loss.detach()), x.grad, {k: p.grad for k, p in model.named_parameters()})
+        np.savez(os.path.join(gold, f"fullsize_{name}.npz"), **stats)
+        print(f"fullsize {name}: loss {float(loss.detach()):.9f} ({time.time() - t0:.0f} s)", flush=True)
+
+
 def main():
     gold = os.path.join(REPO, "tests", "golden")
     os.makedirs(gold, exist_ok=True)
+    if "--fullsize" in sys.argv:           # minutes of CPU time: its own switch
+        ref_models, _, LpLoss = _import_reference()
+        torch.set_num_threads(8)
+        gen_fullsize(gold, ref_models, LpLoss, [a for a in sys.argv[1:] if not a.startswith("--")])
+        return
     if "--only-scheduler" in sys.argv or "--only-small" in sys.argv:
         gen_scheduler(gold)
         gen_physics(gold)

@@ -50,3 +50,30 @@ def oracle_run(name, dtype):
     loss = R.lp_loss(pred, y)
     loss.backward()
     return pred.detach(), loss.detach(), x.grad.detach(), {k: v.grad.detach() for k, v in sd.items()}
+
+
+def fullsize_errors(name, pred, loss, dx, grads):
+    """(pred, loss, dx, grads) of any implementation against tests/golden/fullsize_<name>.npz (the REFERENCE in fp64 at a BASELINE
+    size, oracle/gen_golden.py: gen_fullsize).  Returns relative errors: loss, per-(b,t,c) prediction moments, sampled prediction /
+    dx entries, per-(b,t,c) dx norms, and per parameter the gradient norm and sampled entries (structurally-zero families apart)."""
+    from oracle.gen_golden import fullsize_stats
+    z = np.load(os.path.join(GOLDEN, f"fullsize_{name}.npz"))
+    got = fullsize_stats(pred.detach().cpu(), float(torch.as_tensor(loss).detach()), dx.detach().cpu(), {k: g.detach().cpu() for k, g in grads.items()})
+    names = sorted(grads)
+    live = np.array([not structurally_zero(k) for k in names])
+    per = np.repeat(live, [min(16, grads[k].numel()) for k in names])
+    gscale = float(z["grad_l2"].max())
+    e = {
+        "loss": abs(got["loss"] - z["loss"]) / abs(z["loss"]),
+        "pred_samples": rel_l2(got["pred_samples"], z["pred_samples"]),
+        "pred_mean": float(np.abs(got["pred_mean"] - z["pred_mean"]).max() / np.abs(z["pred_l2"]).max()),
+        "pred_std": float(np.abs(got["pred_std"] / z["pred_std"] - 1).max()),
+        "pred_l2": float(np.abs(got["pred_l2"] / z["pred_l2"] - 1).max()),
+        "dx_samples": rel_l2(got["dx_samples"], z["dx_samples"]),
+        "dx_l2": float(np.abs(got["dx_l2"] / z["dx_l2"] - 1).max()),
+        "grad_l2_worst": float(np.abs(got["grad_l2"][live] / z["grad_l2"][live] - 1).max()),
+        "grad_l2_all": rel_l2(got["grad_l2"][live], z["grad_l2"][live]),
+        "grad_samples": rel_l2(got["grad_samples"][per], z["grad_samples"][per]),
+        "grad_zero_families": float(got["grad_l2"][~live].max() / gscale) if (~live).any() else 0.0,
+    }
+    return e

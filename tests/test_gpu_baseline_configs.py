@@ -3,7 +3,8 @@
 box's host cores on the same seeded inputs, plus size-independent properties at the full bench size.
 
   configs[0]  8x96x96 clip, bs 2                      -> fp32 (1e-4) and bf16 parity, forward / loss / dx / every gradient
-  configs[1]  16x192x192 clip (bench shape)           -> one full-resolution sample against the oracle (bf16 tolerances);
+  configs[1]  16x192x192 clip (bench shape)           -> one full-resolution sample against the oracle (bf16 tolerances) and, in fp32
+                                                         and bf16, against the reference's own statistics at that size;
                                                          bs 8: bit-identical reruns, per-sample independence of the batch
   configs[3]  32x384x192 long-aspect clip (24x12 tokens, T = 32: the two-block attention paths at full width), bs 1, fp32
   configs[4]  bs 1 inference: the forward captured in a HIP graph replays bit-identically; 3-step rollout on device
@@ -16,7 +17,7 @@ over 12 blocks with O(1) layer scales; the 3-block golden models of test_gpu_par
 import pytest
 import torch
 
-from tests.helpers import rel_l2, structurally_zero
+from tests.helpers import fullsize_errors, rel_l2, structurally_zero
 
 pytestmark = pytest.mark.gpu
 
@@ -66,7 +67,7 @@ def _product(B, T, H, W, seed, dtype):
     x.requires_grad_(True)
     loss, pred = m.forward_loss(x, c, y)
     loss.backward()
-    return pred.detach().cpu(), float(loss), x.grad.detach().cpu(), {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+    return pred.detach().cpu(), float(loss.detach()), x.grad.detach().cpu(), {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
 
 
 def _compare(prod, orac, dtype):
@@ -91,28 +92,50 @@ def _compare(prod, orac, dtype):
     assert (num / den) ** 0.5 < gt
 
 
+def _against_reference(name, prod, dtype):
+    """The same result against the REFERENCE's own fp64 run at this size, kept as statistics (tests/golden/fullsize_<name>.npz,
+    SURVEY.md section 8c item 5; seeds shared with oracle/gen_golden.py: FULLSIZE).  Same tolerances as `_compare`."""
+    e = fullsize_errors(name, *prod)
+    f32 = dtype == torch.float32
+    ft, dt, gt, fam = (1e-4, 1e-4, 1e-4, 1e-4) if f32 else (8e-2, 2e-1, 1.5e-1, 0.9)
+    assert e["loss"] < ft and e["pred_samples"] < ft and e["pred_mean"] < ft and e["pred_std"] < ft and e["pred_l2"] < ft, e
+    assert e["dx_samples"] < dt and e["dx_l2"] < dt, e
+    assert e["grad_l2_all"] < gt and e["grad_samples"] < gt and e["grad_l2_worst"] < fam, e
+    assert e["grad_zero_families"] < (1e-5 if f32 else 1e-2), e
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_config0_8x96x96_bs2(dtype):
     B, T, H, W, seed = 2, 8, 96, 96, 11
-    _compare(_product(B, T, H, W, seed, dtype), _oracle(B, T, H, W, seed, dtype=torch.float64 if dtype == torch.float32 else torch.float32), dtype)
+    prod = _product(B, T, H, W, seed, dtype)
+    _compare(prod, _oracle(B, T, H, W, seed, dtype=torch.float64 if dtype == torch.float32 else torch.float32), dtype)
+    _against_reference("config0_8x96x96_bs2", prod, dtype)
 
 
-def test_config1_full_resolution_sample_bf16():
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_config1_full_resolution_sample(dtype):
     B, T, H, W, seed = 1, 16, 192, 192, 12
-    _compare(_product(B, T, H, W, seed, torch.bfloat16), _oracle(B, T, H, W, seed), torch.bfloat16)
+    prod = _product(B, T, H, W, seed, dtype)
+    if dtype == torch.bfloat16:
+        _compare(prod, _oracle(B, T, H, W, seed), dtype)
+    _against_reference("config1_16x192x192", prod, dtype)
 
 
 def test_config3_long_aspect_32x384x192_fp32():
     """24 x 12 tokens, T = 32: temporal and axial-H attention take the two-block (L > 16) paths at full model width."""
     B, T, H, W, seed = 1, 32, 384, 192, 13
-    _compare(_product(B, T, H, W, seed, torch.float32), _oracle(B, T, H, W, seed, dtype=torch.float64), torch.float32)
+    prod = _product(B, T, H, W, seed, torch.float32)
+    _compare(prod, _oracle(B, T, H, W, seed, dtype=torch.float64), torch.float32)
+    _against_reference("config3_32x384x192", prod, torch.float32)
 
 
 def test_config3_transposed_32x192x384_fp32():
     """The wide variant SURVEY.md section 8(d) asks for beside configs[3] ("stresses axial-W"): 12 x 24 tokens, so the W pass is the
     one with L = 24."""
     B, T, H, W, seed = 1, 32, 192, 384, 16
-    _compare(_product(B, T, H, W, seed, torch.float32), _oracle(B, T, H, W, seed, dtype=torch.float64), torch.float32)
+    prod = _product(B, T, H, W, seed, torch.float32)
+    _compare(prod, _oracle(B, T, H, W, seed, dtype=torch.float64), torch.float32)
+    _against_reference("config3_32x192x384", prod, torch.float32)
 
 
 def test_config1_bench_size_properties():

@@ -85,3 +85,24 @@ def test_adamw_matches_torch():
         opt.step()
         R.adamw_step(p, grad, m, v, step, 2.5e-4)
         assert rel_l2(p, ref.detach()) < 1e-14
+
+
+def test_oracle_matches_reference_at_full_width_config0():
+    """tests/golden/fullsize_config0_8x96x96_bs2.npz: the REFERENCE film_avit_small (E = 384, 6 heads, 12 blocks, P = 16) in fp64 on
+    BASELINE configs[0] (8 x 96 x 96 clips, bs 2), reduced to statistics (SURVEY.md section 8c item 5).  The oracle reproduces them;
+    the larger configurations of the same fixture family are checked on the GPU box (tests/test_gpu_baseline_configs.py)."""
+    from oracle import weights as W
+    from oracle.gen_golden import FULLSIZE, FULLSIZE_CFG
+    from tests.helpers import fullsize_errors
+    c = FULLSIZE["config0_8x96x96_bs2"]
+    torch.set_num_threads(8)
+    sd = {k: v.double().requires_grad_(True) for k, v in W.generate(W.param_shapes(**FULLSIZE_CFG), seed=c["seed"]).items()}
+    x = W.synthetic_clip(c["B"], c["T"], 4, c["H"], c["W"], 100 + c["seed"]).double().requires_grad_(True)
+    y = W.synthetic_clip(c["B"], c["T"], 4, c["H"], c["W"], 200 + c["seed"]).double()
+    fp = W.synthetic_fluid_params(c["B"], 9, 300 + c["seed"]).double()
+    pred = R.filmavit_forward(sd, x, fp, patch_size=16, num_heads=6)
+    loss = R.lp_loss(pred, y)
+    loss.backward()
+    e = fullsize_errors("config0_8x96x96_bs2", pred, loss, x.grad, {k: v.grad for k, v in sd.items()})
+    assert max(v for k, v in e.items() if k != "grad_zero_families") < 1e-9, e
+    assert e["grad_zero_families"] < 1e-12, e
