@@ -192,7 +192,8 @@ struct Fork {
 
 // ------------------------------------------------------------------------------------------------ small param kernels
 // out-projection fold.  mc[n] = <W[n,:], nb> + bias[n]; alpha = gamma*(1+hi); beta = gamma*(bias*(1+hi) + mc*(lo-hi))
-struct PrepArgs { const float *W, *bias, *nb, *gamma, *lo, *hi; float *alpha, *beta, *mc; int E; void* wscaled; int dtype; };      // wscaled[n][k] = alpha[n] * W[n][k] (compute dtype): the data-gradient GEMM's weight
+struct PrepArgs { const float *W, *bias, *nb, *gamma, *lo, *hi; float *alpha, *beta, *mc; int E; void* wscaled; int dtype;
+                  const float *tab_m, *tab_v; float* tab_out; int tab_F; };     // optional stochastic-depth table tab_out[f][c] = tab_m[f] * tab_v[c] (E columns)      // wscaled[n][k] = alpha[n] * W[n][k] (compute dtype): the data-gradient GEMM's weight
 __device__ __forceinline__ void outproj_prep_row(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ nb,
                                                  const float* __restrict__ gamma, const float* __restrict__ lo, const float* __restrict__ hi,
                                                  float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ mc, int E, int n,
@@ -287,6 +288,11 @@ __global__ void __launch_bounds__(256) cast4_kernel(Cast4 j) {
 }
 // the same casts plus the out-projection fold (grid row cnt, one workgroup per output channel): a stage's parameter-only work in ONE launch
 __global__ void __launch_bounds__(256) stage_prep_kernel(Cast4 j, int cnt, PrepArgs a) {
+    if ((int)blockIdx.y == cnt + 1) {          // the stage's stochastic-depth table (frame_table_kernel's work, no launch of its own)
+        const long n = (long)a.tab_F * a.E;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) a.tab_out[i] = a.tab_m[i / a.E] * a.tab_v[i % a.E];
+        return;
+    }
     if ((int)blockIdx.y == cnt) {
         if ((int)blockIdx.x < a.E) outproj_prep_row(a.W, a.bias, a.nb, a.gamma, a.lo, a.hi, a.alpha, a.beta, a.mc, a.E, blockIdx.x, a.wscaled, a.dtype);
         return;
@@ -311,7 +317,7 @@ int wviews(const D& d, int cnt, const float* const* src, void* const* dst, const
     Cast4 j;
     for (int i = 0; i < 4; ++i) { j.src[i] = src[i < cnt ? i : 0]; j.dst[i] = (bf16*)dst[i < cnt ? i : 0]; j.n[i] = i < cnt ? n[i] : 0; out[i < cnt ? i : 0] = dst[i < cnt ? i : 0]; }
     for (int i = 0; i < cnt; ++i) out[i] = dst[i];
-    if (prep) hipLaunchKernelGGL(stage_prep_kernel, dim3(std::max(64, prep->E), cnt + 1), dim3(256), 0, st, j, cnt, *prep);
+    if (prep) hipLaunchKernelGGL(stage_prep_kernel, dim3(std::max(64, prep->E), cnt + (prep->tab_out ? 2 : 1)), dim3(256), 0, st, j, cnt, *prep);
     else hipLaunchKernelGGL(cast4_kernel, dim3(64, cnt), dim3(256), 0, st, j);
     BF_CHECK_LAUNCH();
     return 0;
@@ -568,7 +574,8 @@ extern "C" int bf_temporal_fwd(const bf_dims* dims, const bf_temporal_params* p,
         void* dst[2] = {sv.win_c, sv.wout_c};
         const long n[2] = {3L * d.E * d.E, (long)d.E * d.E};
         const void* out[4];
-        const PrepArgs prep{p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr, sv.alpha, sv.beta, sv.mc, d.E, sv.wout_s, d.dtype};
+        const PrepArgs prep{p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr, sv.alpha, sv.beta, sv.mc, d.E, sv.wout_s, d.dtype,
+                            nullptr, nullptr, nullptr, 0};
         TRY(wviews(d, 2, src, dst, n, out, st, &prep));
         win_c = out[0]; wout_c = out[1];
     }
@@ -639,8 +646,10 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
         void* dst[4] = {sv.win_c, sv.wout_c, sv.w1_c, sv.w2_c};
         const long n[4] = {3L * d.E * d.E, (long)d.E * d.E, 4L * d.E * d.E, 4L * d.E * d.E};
         const void* out[4];
+        const bool tab = drop_mlp && d.dtype != BF_DTYPE_F32;      // gtab[f][c] = drop_mlp[f] * gamma_mlp[c], in the same launch
         const PrepArgs prep{p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att, d.feat_scale ? p->low_freq_scalar : nullptr,
-                            d.feat_scale ? p->high_freq_scalar : nullptr, sv.alpha, sv.beta, sv.mc, d.E, sv.wout_s, d.dtype};
+                            d.feat_scale ? p->high_freq_scalar : nullptr, sv.alpha, sv.beta, sv.mc, d.E, sv.wout_s, d.dtype,
+                            tab ? drop_mlp : nullptr, tab ? p->gamma_mlp : nullptr, tab ? sv.gtab : nullptr, (int)d.F};
         TRY(wviews(d, 4, src, dst, n, out, st, &prep));
         win_c = out[0]; wout_c = out[1]; w1_c = out[2]; w2_c = out[3];
     }
@@ -681,8 +690,10 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
     const float* g3 = p->gamma_mlp;
     int g3div = (int)d.F;
     if (drop_mlp) {
-        hipLaunchKernelGGL(frame_table_kernel, dim3(bf_cdiv(d.F * d.E, 256)), dim3(256), 0, st, drop_mlp, 1, (const float*)p->gamma_mlp, sv.gtab, (int)d.F, d.E);
-        BF_CHECK_LAUNCH();
+        if (d.dtype == BF_DTYPE_F32) {      // bf16: made by the stage's preparation launch above
+            hipLaunchKernelGGL(frame_table_kernel, dim3(bf_cdiv(d.F * d.E, 256)), dim3(256), 0, st, drop_mlp, 1, (const float*)p->gamma_mlp, sv.gtab, (int)d.F, d.E);
+            BF_CHECK_LAUNCH();
+        }
         g3 = sv.gtab; g3div = 1;
     }
     TRY(bf_in_stats_apply(d.dtype, sv.z, (int)d.F, (int)d.S, d.E, p->mlp_norm_w, p->mlp_norm_b, g3, g3div, nullptr, sv.mean3, sv.rstd3,
