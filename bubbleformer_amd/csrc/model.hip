@@ -984,13 +984,19 @@ extern "C" int bf_debed_fwd(const bf_dims* dims, const bf_debed_params* p, const
                             sv.rstd[i], sv.sc[i], sv.sh[i], sc.in_ws, st));
         } else {
             TRY(bf_wprep(d.dtype, 0, p->conv_w[i], sv.wc[i], cin, 4 * co, sv.Np, st));
-            bf_operand Bo = op_plain(sv.wc[i], sv.Np, BF_LAY_XC);
-            float* pm = (float*)sc.t4;
-            bf_epilogue e = epi_store(pm, sv.Np);
-            e.out_mode = BF_OUT_STORE_F32;
-            TRY(bf_gemm(d.dtype, (int)sv.Pin[i], sv.Np, cin, &A, &Bo, &e, 1, st));
             if (target) ZERO(sv.lossbuf, (size_t)d.F * d.cout * 2 * 4);
-            TRY(bf_pm2nchw(pm, pred, target, sv.lossbuf, (int)d.F, co, sv.gh[i], sv.gw[i], sv.Np, st));
+            // InstanceNorm affine + GELU + the 2x2 transposed convolution + NCHW store + loss partials in one streaming pass where it applies
+            const int rc = i > 0 ? bf_debed_last(d.dtype, sv.y[i - 1], sv.sc[i - 1], sv.sh[i - 1], sv.wc[i], pred, target, sv.lossbuf, (int)d.F, cin, co,
+                                                 sv.gh[i], sv.gw[i], sv.Np, st) : 1;
+            if (rc < 0) return rc;
+            if (rc == 1) {
+                bf_operand Bo = op_plain(sv.wc[i], sv.Np, BF_LAY_XC);
+                float* pm = (float*)sc.t4;
+                bf_epilogue e = epi_store(pm, sv.Np);
+                e.out_mode = BF_OUT_STORE_F32;
+                TRY(bf_gemm(d.dtype, (int)sv.Pin[i], sv.Np, cin, &A, &Bo, &e, 1, st));
+                TRY(bf_pm2nchw(pm, pred, target, sv.lossbuf, (int)d.F, co, sv.gh[i], sv.gw[i], sv.Np, st));
+            }
             if (target) TRY(bf_lploss_finalize(sv.lossbuf, (int)d.F, co, loss, sv.coef, st));
         }
     }

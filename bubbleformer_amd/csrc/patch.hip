@@ -98,6 +98,83 @@ __global__ void __launch_bounds__(NT) pm2nchw_kernel(const float* __restrict__ p
         }
     }
 }
+// ---------------------------------------------------------------------------- last HMLPDebed stage in one pass (bf16)
+// pred[f][co][2y+ky][2x+kx] = sum_ci gelu(act[p][ci] * sc[f][ci] + sh[f][ci]) * wc[ci][co*4 + ky*2 + kx]   (layers/patching.py:92-104:
+// the last ConvTranspose2d(k=2, s=2) after InstanceNorm + GELU), plus the relative-L2 partial sums of pm2nchw_kernel.
+// K = Ci <= 128 and N = 16: a 128-wide GEMM tile is 7/8 padding and each workgroup's life is a cold prologue and an epilogue; here a wave
+// streams 16-row groups straight into MFMA operand registers (rows = 16 consecutive pixels of one image row), the normalisation and
+// GELU are applied there, the 16 x 16 result is already (co, ky, kx) x pixel, and it leaves as float2 rows of the NCHW prediction --
+// no patch-major fp32 intermediate and no second pass.  The MFMA sequence over k is the GEMM path's (32 at a time, ascending).
+constexpr int DL_GPW = 16;      // 16-row groups per wave (contiguous: one frame, so the loss partials stay in registers)
+template <int KS>
+__global__ void __launch_bounds__(NT) debed_last_kernel(const bf16* __restrict__ act, const float* __restrict__ sc, const float* __restrict__ sh,
+                                                       const bf16* __restrict__ wc, float* __restrict__ pred, const float* __restrict__ y,
+                                                       float* __restrict__ lossbuf, int Co, int h, int w) {
+    constexpr int Ci = 32 * KS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int f = blockIdx.y;
+    const int GF = h * w / 16;                                      // groups per frame
+    const int g0 = (blockIdx.x * (NT / 64) + wave) * DL_GPW;
+    if (g0 >= GF) return;
+    const int g1 = min(g0 + DL_GPW, GF);
+    const int H = 2 * h, W = 2 * w;
+    // weights as the first MFMA operand: lane holds wc[k = 32 s + 8 lg + j][n = li]
+    bf16x8 wf[KS];
+    float a_sc[KS][8], a_sh[KS][8];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 32 * s + 8 * lg + j;
+            wf[s][j] = wc[k * 16 + li];
+            a_sc[s][j] = sc[(long)f * Ci + k];
+            a_sh[s][j] = sh[(long)f * Ci + k];
+        }
+    }
+    const bf16* rows = act + ((long)f * h * w + li) * Ci + 8 * lg;
+    bf16x8 cur[KS], nxt[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) cur[s] = *reinterpret_cast<const bf16x8*>(rows + (long)g0 * 16 * Ci + 32 * s);
+    float num = 0.f, den = 0.f;
+    const bool live = lg < Co;
+    for (int g = g0; g < g1; ++g) {
+        if (g + 1 < g1) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) nxt[s] = *reinterpret_cast<const bf16x8*>(rows + (long)(g + 1) * 16 * Ci + 32 * s);
+        }
+        const int px = g * 16 + li, yo = px / w, xo = px - yo * w;
+        const long o = (((long)f * Co + lg) * H + 2 * yo) * W + 2 * xo;
+        float2 y0 = make_float2(0.f, 0.f), y1 = y0;
+        if (y && live) { y0 = *reinterpret_cast<const float2*>(y + o); y1 = *reinterpret_cast<const float2*>(y + o + W); }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bf16x8 a;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = (bf16)gelu_f((float)cur[s][j] * a_sc[s][j] + a_sh[s][j]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], a, acc, 0, 0, 0);      // acc[j] = out[n = 4 lg + j][pixel li]
+        }
+        if (live) {
+            *reinterpret_cast<float2*>(pred + o) = make_float2(acc[0], acc[1]);
+            *reinterpret_cast<float2*>(pred + o + W) = make_float2(acc[2], acc[3]);
+            if (y) {
+                num += (acc[0] - y0.x) * (acc[0] - y0.x) + (acc[1] - y0.y) * (acc[1] - y0.y) + (acc[2] - y1.x) * (acc[2] - y1.x) + (acc[3] - y1.y) * (acc[3] - y1.y);
+                den += y0.x * y0.x + y0.y * y0.y + y1.x * y1.x + y1.y * y1.y;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) cur[s] = nxt[s];
+    }
+    if (y) {        // the 16 lanes of a k-group share (f, co): one pair of atomics per wave and output channel
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) { num += __shfl_xor(num, m, 64); den += __shfl_xor(den, m, 64); }
+        if (li == 0 && live) {
+            atomicAdd(lossbuf + ((long)f * Co + lg) * 2, num);
+            atomicAdd(lossbuf + ((long)f * Co + lg) * 2 + 1, den);
+        }
+    }
+}
 // loss = sum_c mean_f sqrt(num/den);  coef[f][c] = 1 / (F * sqrt(num) * sqrt(den))   (single block)
 __global__ void lploss_finalize_kernel(const float* __restrict__ lossbuf, int F, int Co, float* __restrict__ loss, float* __restrict__ coef) {
     __shared__ float red[NT];
@@ -299,6 +376,24 @@ extern "C" int bf_pm2nchw(const float* pm, float* pred, const float* y, float* l
     BF_REQUIRE(!y || lossbuf, "bf_pm2nchw: loss buffer missing");
     dim3 grid(std::max(1, std::min(bf_cdiv((long)h * w, NT), 64)), frames);
     hipLaunchKernelGGL(pm2nchw_kernel, grid, dim3(NT), 0, (hipStream_t)stream, pm, pred, y, lossbuf, Co, h, w, Np);
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bf_debed_last(int dtype, const void* act, const float* sc, const float* sh, const void* wc, float* pred, const float* y,
+                             float* lossbuf, int frames, int Ci, int Co, int h, int w, int Np, bf_stream_t stream) {
+    BF_REQUIRE(act && sc && sh && wc && pred && frames > 0 && Ci > 0 && Co > 0 && h > 0 && w > 0, "bf_debed_last: bad arguments");
+    BF_REQUIRE(!y || lossbuf, "bf_debed_last: loss buffer missing");
+    // shapes the streaming kernel does not take (the caller falls back to GEMM + bf_pm2nchw): not an error
+    if (dtype != BF_DTYPE_BF16 || Np != 16 || Co > 4 || Ci % 32 != 0 || Ci > 128 || w % 16 != 0) return 1;
+    static const bool off = []() { const char* v = getenv("BF_DEBED_LAST"); return v && v[0] == '0'; }();
+    if (off) return 1;
+    const int GF = h * w / 16;
+    dim3 grid(bf_cdiv(GF, (NT / 64) * DL_GPW), frames);
+    hipStream_t st = (hipStream_t)stream;
+#define DL(KS) hipLaunchKernelGGL(debed_last_kernel<KS>, grid, dim3(NT), 0, st, (const bf16*)act, sc, sh, (const bf16*)wc, pred, y, lossbuf, Co, h, w)
+    switch (Ci / 32) { case 1: DL(1); break; case 2: DL(2); break; case 3: DL(3); break; default: DL(4); break; }
+#undef DL
     BF_CHECK_LAUNCH();
     return 0;
 }

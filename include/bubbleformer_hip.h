@@ -167,6 +167,11 @@ int bf_im2col_nchw(int dtype, const float* x, void* out, int frames, int C, int 
 int bf_col2im_nchw(int dtype, const void* g, float* dx, int frames, int C, int H, int W, int Kp, bf_stream_t stream);
 int bf_pm2nchw(const float* pm, float* pred, const float* y, float* lossbuf, int frames, int Co, int h, int w, int Np,
                bf_stream_t stream);
+/* Last HMLPDebed stage in one pass (layers/patching.py:92-104: InstanceNorm affine + GELU on the input rows, ConvTranspose2d(k=2,s=2)
+ * to the NCHW prediction) with the relative-L2 partial sums of bf_pm2nchw; act [frames*h*w][Ci], sc/sh [frames][Ci], wc [Ci][Np] with
+ * n = co*4 + ky*2 + kx.  Returns 1 (nothing launched) for shapes it does not take: fp32, Np != 16, Co > 4, Ci % 32, Ci > 128, w % 16. */
+int bf_debed_last(int dtype, const void* act, const float* sc, const float* sh, const void* wc, float* pred, const float* y,
+                  float* lossbuf, int frames, int Ci, int Co, int h, int w, int Np, bf_stream_t stream);
 int bf_lploss_finalize(const float* lossbuf, int frames, int Co, float* loss, float* coef, bf_stream_t stream);
 int bf_nchw2pm(int dtype, const float* dpred, const float* pred, const float* y, const float* coef, const float* gscale,
                void* dpm, int frames, int Co, int h, int w, int Np, bf_stream_t stream);

@@ -395,3 +395,42 @@ def test_axial_attention_forward_with_instance_norm(K, h, w, heads, d):
     # a shape the one-launch form does not cover is refused, the caller then takes the two-step path
     assert lib.bf_attn_axial_norm_fwd(1, _p(qkv), _p(o), _p(on), 1, 20, 2, heads, d, *[_p(t) for t in prm], _p(hx), _p(hy), _p(nw), _p(nb),
                                       _p(mean), _p(rstd), _p(sc), _p(sh), _stream()) == 1
+
+
+@pytest.mark.parametrize("Ci,Co,h,w", [(96, 4, 96, 96), (32, 3, 6, 16), (64, 1, 5, 32), (128, 4, 3, 48)])
+def test_debed_last_stage_one_pass(Ci, Co, h, w):
+    """bf_debed_last (InstanceNorm affine + GELU + ConvTranspose2d(k=2, s=2) + NCHW store + relative-L2 partial sums in one streaming
+    kernel) against torch on the same bf16-rounded operands (layers/patching.py:92-104 last stage; utils/losses.py:79-89 sums), and the
+    shapes it declines (return 1: the caller keeps GEMM + bf_pm2nchw)."""
+    from bubbleformer_amd import _lib as L
+    from bubbleformer_amd.ops import _p, _stream
+    lib = L.lib()
+    Fr = 3
+    g = torch.Generator(device="cuda").manual_seed(23)
+    act = torch.randn(Fr * h * w, Ci, device="cuda", generator=g).bfloat16()
+    sc = 1 + 0.2 * torch.randn(Fr, Ci, device="cuda", generator=g)
+    sh = 0.3 * torch.randn(Fr, Ci, device="cuda", generator=g)
+    Wt = (torch.randn(Ci, Co, 2, 2, device="cuda", generator=g) / Ci ** 0.5)
+    wc = torch.zeros(Ci, 16, device="cuda")
+    wc[:, :4 * Co] = Wt.reshape(Ci, 4 * Co)
+    wc = wc.bfloat16()
+    y = torch.randn(Fr, Co, 2 * h, 2 * w, device="cuda", generator=g)
+    pred = torch.full((Fr, Co, 2 * h, 2 * w), float("nan"), device="cuda")
+    lossbuf = torch.zeros(Fr, Co, 2, device="cuda")
+    L.check(lib.bf_debed_last(1, _p(act), _p(sc), _p(sh), _p(wc), _p(pred), _p(y), _p(lossbuf), Fr, Ci, Co, h, w, 16, _stream()), "debed_last")
+    a = torch.nn.functional.gelu(act.float().view(Fr, h * w, Ci) * sc[:, None] + sh[:, None]).bfloat16().float()
+    a = a.view(Fr, h, w, Ci).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv_transpose2d(a.double(), wc[:, :4 * Co].double().view(Ci, Co, 2, 2), stride=2)
+    assert torch.isfinite(pred).all()
+    assert _rel(pred, ref) < 2e-3
+    num = (pred.double() - y.double()).pow(2).sum(dim=(-1, -2))
+    den = y.double().pow(2).sum(dim=(-1, -2))
+    assert _rel(lossbuf[..., 0], num) < 1e-5 and _rel(lossbuf[..., 1], den) < 1e-5
+    # without a target: prediction only
+    pred2 = torch.zeros_like(pred)
+    L.check(lib.bf_debed_last(1, _p(act), _p(sc), _p(sh), _p(wc), _p(pred2), None, None, Fr, Ci, Co, h, w, 16, _stream()), "debed_last")
+    assert torch.equal(pred2, pred)
+    # declined shapes
+    assert lib.bf_debed_last(0, _p(act), _p(sc), _p(sh), _p(wc), _p(pred), None, None, Fr, Ci, Co, h, w, 16, _stream()) == 1      # fp32
+    assert lib.bf_debed_last(1, _p(act), _p(sc), _p(sh), _p(wc), _p(pred), None, None, Fr, Ci, Co, h, w, 24, _stream()) == 1      # Np != 16
+    assert lib.bf_debed_last(1, _p(act), _p(sc), _p(sh), _p(wc), _p(pred), None, None, Fr, Ci, Co, h * 2, w // 2 + 4, 16, _stream()) == 1      # w % 16
