@@ -1026,7 +1026,10 @@ extern "C" int bf_debed_bwd(const bf_dims* dims, const bf_debed_params* p, const
         void* dact = i == 0 ? dx : buf(i);
         if (last) {
             void* dpm = sc.t1;
-            TRY(bf_nchw2pm(d.dtype, dpred, pred, target, sv.coef, loss_scale, dpm, (int)d.F, co, sv.gh[i], sv.gw[i], sv.Np, st));
+            // the loss gradient in patch-major rows and the data gradient of the transposed convolution in one pass where it applies
+            const int rc = bf_debed_last_bwd(d.dtype, dpred, pred, target, sv.coef, loss_scale, sv.wc[i], dpm, dact, (int)d.F, cin, co, sv.gh[i], sv.gw[i], sv.Np, st);
+            if (rc < 0) return rc;
+            if (rc == 1) TRY(bf_nchw2pm(d.dtype, dpred, pred, target, sv.coef, loss_scale, dpm, (int)d.F, co, sv.gh[i], sv.gw[i], sv.Np, st));
             TRY(fk.begin(&ss));
             ZERO_ON(ss, sc.wg, (size_t)sv.Np * cin * 4);
             {   // wg[n][ci] = sum_p dpm[p][n] * act[p][ci]
@@ -1037,7 +1040,7 @@ extern "C" int bf_debed_bwd(const bf_dims* dims, const bf_debed_params* p, const
                 TRY(bf_gemm(d.dtype, sv.Np, cin, (int)sv.Pin[i], &A, &Bo, &e, splitk_for(sv.Np, cin, sv.Pin[i]), ss));
             }
             TRY(bf_wgrad_unprep(0, sc.wg, g->conv_w[i], cin, 4 * co, sv.Np, 1, ss));
-            {   // dact[p][ci] = sum_n dpm[p][n] * wt[ci][n]
+            if (rc == 1) {   // dact[p][ci] = sum_n dpm[p][n] * wt[ci][n]
                 bf_operand A = op_plain(dpm, sv.Np, BF_LAY_KC);
                 bf_operand Bo = op_plain(sv.wc[i], sv.Np, BF_LAY_KC);
                 bf_epilogue e = epi_store(dact, cin);

@@ -175,6 +175,74 @@ __global__ void __launch_bounds__(NT) debed_last_kernel(const bf16* __restrict__
         }
     }
 }
+// The same stage backwards: dpm[p][co*4 + ky*2 + kx] = d pred[f][co][2y+ky][2x+kx] (given, or coef[f][co] * gscale * (pred - y) of the fused
+// loss), written for the weight-gradient GEMM, and dact[p][ci] = sum_n dpm[p][n] * wc[ci][n] in the same pass (K = 16: one
+// v_mfma_f32_16x16x16_bf16 per 16 input channels).  The weight rows are dealt to the MFMA tiles so that a lane ends up with 4T
+// CONSECUTIVE input channels of its pixel (tile t, row 4 lg + j  <->  ci = 4T lg + 4t + j): dact leaves as whole 16-byte pieces, a
+// wave writes 16 complete rows.  Replaces bf_nchw2pm + a 128-wide GEMM tile with K = 16.
+template <int T>
+__global__ void __launch_bounds__(NT) debed_last_bwd_kernel(const float* __restrict__ dpred, const float* __restrict__ pred, const float* __restrict__ y,
+                                                           const float* __restrict__ coef, const float* __restrict__ gscale,
+                                                           const bf16* __restrict__ wc, bf16* __restrict__ dpm, bf16* __restrict__ dact,
+                                                           int Co, int h, int w) {
+    constexpr int Ci = 16 * T;
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int f = blockIdx.y;
+    const int GF = h * w / 16;
+    const int g0 = (blockIdx.x * (NT / 64) + wave) * DL_GPW;
+    if (g0 >= GF) return;
+    const int g1 = min(g0 + DL_GPW, GF);
+    const int H = 2 * h, W = 2 * w;
+    const bool live = lg < Co;
+    s16x4 wf[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int ci = 4 * T * (li >> 2) + 4 * t + (li & 3);
+        wf[t] = *reinterpret_cast<const s16x4*>(wc + ci * 16 + 4 * lg);
+    }
+    const float cf = (!dpred && live) ? coef[(long)f * Co + lg] * (gscale ? gscale[0] : 1.f) : 0.f;
+    auto fetch = [&](int g, float2 (&r)[4]) {
+        const int px = g * 16 + li, yo = px / w, xo = px - yo * w;
+        const long o = (((long)f * Co + lg) * H + 2 * yo) * W + 2 * xo;
+        if (!live) { r[0] = r[1] = r[2] = r[3] = make_float2(0.f, 0.f); return; }
+        if (dpred) { r[0] = *reinterpret_cast<const float2*>(dpred + o); r[1] = *reinterpret_cast<const float2*>(dpred + o + W); r[2] = r[3] = make_float2(0.f, 0.f); }
+        else {
+            r[0] = *reinterpret_cast<const float2*>(pred + o); r[1] = *reinterpret_cast<const float2*>(pred + o + W);
+            r[2] = *reinterpret_cast<const float2*>(y + o); r[3] = *reinterpret_cast<const float2*>(y + o + W);
+        }
+    };
+    float2 cur[4], nxt[4];
+    fetch(g0, cur);
+    for (int g = g0; g < g1; ++g) {
+        if (g + 1 < g1) fetch(g + 1, nxt);
+        float v[4];
+        if (dpred) { v[0] = cur[0].x; v[1] = cur[0].y; v[2] = cur[1].x; v[3] = cur[1].y; }
+        else { v[0] = cf * (cur[0].x - cur[2].x); v[1] = cf * (cur[0].y - cur[2].y); v[2] = cf * (cur[1].x - cur[3].x); v[3] = cf * (cur[1].y - cur[3].y); }
+        const bf16x4v b = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        const long p = (long)f * h * w + g * 16 + li;
+        *reinterpret_cast<bf16x4v*>(dpm + p * 16 + 4 * lg) = b;
+        const s16x4 bs = __builtin_bit_cast(s16x4, b);
+        bf16 o[4 * T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wf[t], bs, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[4 * t + j] = (bf16)acc[j];
+        }
+        bf16* dst = dact + p * Ci + 4 * T * lg;
+#pragma unroll
+        for (int q = 0; q < 4 * T / 8; ++q) {
+            bf16x8 o8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o8[j] = o[8 * q + j];
+            *reinterpret_cast<bf16x8*>(dst + 8 * q) = o8;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+    }
+}
 // loss = sum_c mean_f sqrt(num/den);  coef[f][c] = 1 / (F * sqrt(num) * sqrt(den))   (single block)
 __global__ void lploss_finalize_kernel(const float* __restrict__ lossbuf, int F, int Co, float* __restrict__ loss, float* __restrict__ coef) {
     __shared__ float red[NT];
@@ -394,6 +462,22 @@ extern "C" int bf_debed_last(int dtype, const void* act, const float* sc, const 
 #define DL(KS) hipLaunchKernelGGL(debed_last_kernel<KS>, grid, dim3(NT), 0, st, (const bf16*)act, sc, sh, (const bf16*)wc, pred, y, lossbuf, Co, h, w)
     switch (Ci / 32) { case 1: DL(1); break; case 2: DL(2); break; case 3: DL(3); break; default: DL(4); break; }
 #undef DL
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bf_debed_last_bwd(int dtype, const float* dpred, const float* pred, const float* y, const float* coef, const float* gscale,
+                                 const void* wc, void* dpm, void* dact, int frames, int Ci, int Co, int h, int w, int Np, bf_stream_t stream) {
+    BF_REQUIRE(wc && dpm && dact && (dpred || (pred && y && coef)) && frames > 0 && Ci > 0 && Co > 0 && h > 0 && w > 0, "bf_debed_last_bwd: bad arguments");
+    if (dtype != BF_DTYPE_BF16 || Np != 16 || Co > 4 || Ci % 32 != 0 || Ci > 128 || w % 16 != 0) return 1;      // caller keeps bf_nchw2pm + GEMM
+    static const bool off = []() { const char* v = getenv("BF_DEBED_LAST_BWD"); return v && v[0] == '0'; }();
+    if (off) return 1;
+    const int GF = h * w / 16;
+    dim3 grid(bf_cdiv(GF, (NT / 64) * DL_GPW), frames);
+    hipStream_t st = (hipStream_t)stream;
+#define DLB(T) hipLaunchKernelGGL(debed_last_bwd_kernel<T>, grid, dim3(NT), 0, st, dpred, pred, y, coef, gscale, (const bf16*)wc, (bf16*)dpm, (bf16*)dact, Co, h, w)
+    switch (Ci / 32) { case 1: DLB(2); break; case 2: DLB(4); break; case 3: DLB(6); break; default: DLB(8); break; }
+#undef DLB
     BF_CHECK_LAUNCH();
     return 0;
 }

@@ -172,6 +172,10 @@ int bf_pm2nchw(const float* pm, float* pred, const float* y, float* lossbuf, int
  * n = co*4 + ky*2 + kx.  Returns 1 (nothing launched) for shapes it does not take: fp32, Np != 16, Co > 4, Ci % 32, Ci > 128, w % 16. */
 int bf_debed_last(int dtype, const void* act, const float* sc, const float* sh, const void* wc, float* pred, const float* y,
                   float* lossbuf, int frames, int Ci, int Co, int h, int w, int Np, bf_stream_t stream);
+/* ... and its backward: dpm [frames*h*w][Np] (bf_nchw2pm's output, kept for the weight-gradient GEMM) and dact[p][ci] = sum_n dpm[p][n]*wc[ci][n]
+ * in one pass.  Same declined shapes (returns 1). */
+int bf_debed_last_bwd(int dtype, const float* dpred, const float* pred, const float* y, const float* coef, const float* gscale,
+                      const void* wc, void* dpm, void* dact, int frames, int Ci, int Co, int h, int w, int Np, bf_stream_t stream);
 int bf_lploss_finalize(const float* lossbuf, int frames, int Co, float* loss, float* coef, bf_stream_t stream);
 int bf_nchw2pm(int dtype, const float* dpred, const float* pred, const float* y, const float* coef, const float* gscale,
                void* dpm, int frames, int Co, int h, int w, int Np, bf_stream_t stream);

@@ -434,3 +434,39 @@ def test_debed_last_stage_one_pass(Ci, Co, h, w):
     assert lib.bf_debed_last(0, _p(act), _p(sc), _p(sh), _p(wc), _p(pred), None, None, Fr, Ci, Co, h, w, 16, _stream()) == 1      # fp32
     assert lib.bf_debed_last(1, _p(act), _p(sc), _p(sh), _p(wc), _p(pred), None, None, Fr, Ci, Co, h, w, 24, _stream()) == 1      # Np != 16
     assert lib.bf_debed_last(1, _p(act), _p(sc), _p(sh), _p(wc), _p(pred), None, None, Fr, Ci, Co, h * 2, w // 2 + 4, 16, _stream()) == 1      # w % 16
+
+
+@pytest.mark.parametrize("Ci,Co,h,w", [(96, 4, 96, 96), (32, 3, 6, 16), (64, 1, 5, 32), (128, 4, 3, 48)])
+@pytest.mark.parametrize("fused_loss", [False, True])
+def test_debed_last_stage_backward_one_pass(Ci, Co, h, w, fused_loss):
+    """bf_debed_last_bwd: patch-major loss gradient (given, or coef * gscale * (pred - y)) and the transposed convolution's data gradient
+    in one kernel, against bf_nchw2pm's definition and a plain matmul on the same bf16 operands."""
+    from bubbleformer_amd import _lib as L
+    from bubbleformer_amd.ops import _p, _stream
+    lib = L.lib()
+    Fr = 3
+    g = torch.Generator(device="cuda").manual_seed(29)
+    wc = torch.zeros(Ci, 16, device="cuda")
+    wc[:, :4 * Co] = torch.randn(Ci, 4 * Co, device="cuda", generator=g) / 4
+    wc = wc.bfloat16()
+    pred = torch.randn(Fr, Co, 2 * h, 2 * w, device="cuda", generator=g)
+    y = torch.randn(Fr, Co, 2 * h, 2 * w, device="cuda", generator=g)
+    coef = 0.5 + torch.rand(Fr, Co, device="cuda", generator=g)
+    gs = torch.tensor([0.7], device="cuda")
+    dpred = coef[:, :, None, None] * gs * (pred - y)
+    P = Fr * h * w
+    dpm = torch.full((P, 16), float("nan"), device="cuda", dtype=torch.bfloat16)
+    dact = torch.full((P, Ci), float("nan"), device="cuda", dtype=torch.bfloat16)
+    if fused_loss:
+        rc = lib.bf_debed_last_bwd(1, None, _p(pred), _p(y), _p(coef), _p(gs), _p(wc), _p(dpm), _p(dact), Fr, Ci, Co, h, w, 16, _stream())
+    else:
+        rc = lib.bf_debed_last_bwd(1, _p(dpred), None, None, None, None, _p(wc), _p(dpm), _p(dact), Fr, Ci, Co, h, w, 16, _stream())
+    L.check(rc, "debed_last_bwd")
+    ref_pm = torch.zeros(P, 16, device="cuda")
+    ref_pm[:, :4 * Co] = dpred.view(Fr, Co, h, 2, w, 2).permute(0, 2, 4, 1, 3, 5).reshape(P, 4 * Co)       # n = co*4 + ky*2 + kx
+    ref_pm = ref_pm.bfloat16()
+    assert torch.equal(dpm, ref_pm)
+    ref = ref_pm.double() @ wc.double().t()
+    assert torch.isfinite(dact.float()).all()
+    assert _rel(dact, ref) < 4e-3                      # one bf16 rounding of the result
+    assert lib.bf_debed_last_bwd(0, _p(dpred), None, None, None, None, _p(wc), _p(dpm), _p(dact), Fr, Ci, Co, h, w, 16, _stream()) == 1
