@@ -856,16 +856,21 @@ extern "C" int bf_embed_fwd(const bf_dims* dims, const bf_embed_params* p, const
     const int n = d.nst, H = d.h * d.patch, W = d.w * d.patch;
     if (d.nfluid > 0)
         TRY(bf_film_net_fwd(fluid, p->film_ln_w, p->film_ln_b, p->film_w, p->film_b, sv.gb, sv.chat, sv.crstd, d.B, d.nfluid, 2 * d.E, st));
-    TRY(bf_im2col_nchw(d.dtype, x, sv.patches, (int)d.F, d.cin, H, W, sv.Kp, st));
     for (int i = 0; i < n; ++i) {
         const void* wc;
         if (i == 0) {
             TRY(bf_wprep(d.dtype, 0, p->conv_w[0], sv.wc[0], sv.C[0], 4 * d.cin, sv.Kp, st));
             wc = sv.wc[0];
-            bf_operand A = op_plain(sv.patches, sv.Kp, BF_LAY_KC);
-            bf_operand Bo = op_plain(wc, sv.Kp, BF_LAY_KC);
-            bf_epilogue e = epi_store(sv.y[0], sv.C[0]);
-            TRY(bf_gemm(d.dtype, (int)sv.P[0], sv.C[0], sv.Kp, &A, &Bo, &e, 1, st));
+            // patch rows and the K = 16 contraction in one streaming pass where it applies, else im2col + GEMM
+            const int rc = bf_embed_first(d.dtype, x, wc, sv.patches, sv.y[0], (int)d.F, sv.C[0], d.cin, H / 2, W / 2, sv.Kp, st);
+            if (rc < 0) return rc;
+            if (rc == 1) {
+                TRY(bf_im2col_nchw(d.dtype, x, sv.patches, (int)d.F, d.cin, H, W, sv.Kp, st));
+                bf_operand A = op_plain(sv.patches, sv.Kp, BF_LAY_KC);
+                bf_operand Bo = op_plain(wc, sv.Kp, BF_LAY_KC);
+                bf_epilogue e = epi_store(sv.y[0], sv.C[0]);
+                TRY(bf_gemm(d.dtype, (int)sv.P[0], sv.C[0], sv.Kp, &A, &Bo, &e, 1, st));
+            }
         } else {
             const int cp = sv.C[i - 1];
             TRY(bf_wprep(d.dtype, 1, p->conv_w[i], sv.wc[i], sv.C[i], 4 * cp, 4 * cp, st));

@@ -482,6 +482,16 @@ extern "C" int bf_debed_last_bwd(int dtype, const float* dpred, const float* pre
     return 0;
 }
 
+// The first HMLPEmbed stage is the same contraction (layers/patching.py:30-48, Conv2d(k=2, s=2, bias=False) on the NCHW clip): rows of 2x2
+// patches of x (k = c*4 + ky*2 + kx) times conv weight [C0][16]; `patches` is kept for the weight-gradient GEMM.
+extern "C" int bf_embed_first(int dtype, const float* x, const void* wc, void* patches, void* y0, int frames, int C0, int cin, int h2, int w2,
+                              int Kp, bf_stream_t stream) {
+    BF_REQUIRE(x && wc && patches && y0, "bf_embed_first: null pointer");
+    static const bool off = []() { const char* v = getenv("BF_EMBED_FIRST"); return v && v[0] == '0'; }();
+    if (off) return 1;
+    return bf_debed_last_bwd(dtype, x, nullptr, nullptr, nullptr, nullptr, wc, patches, y0, frames, C0, cin, h2, w2, Kp, stream);
+}
+
 extern "C" int bf_lploss_finalize(const float* lossbuf, int frames, int Co, float* loss, float* coef, bf_stream_t stream) {
     BF_REQUIRE(lossbuf && loss && frames > 0 && Co > 0, "bf_lploss_finalize: bad arguments");
     hipLaunchKernelGGL(lploss_finalize_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, lossbuf, frames, Co, loss, coef);

@@ -176,6 +176,11 @@ int bf_debed_last(int dtype, const void* act, const float* sc, const float* sh, 
  * in one pass.  Same declined shapes (returns 1). */
 int bf_debed_last_bwd(int dtype, const float* dpred, const float* pred, const float* y, const float* coef, const float* gscale,
                       const void* wc, void* dpm, void* dact, int frames, int Ci, int Co, int h, int w, int Np, bf_stream_t stream);
+/* First HMLPEmbed stage (layers/patching.py:30-48: Conv2d(k=2, s=2, bias=False) on the NCHW fp32 clip) in one pass: patches [P][Kp]
+ * (k = c*4 + ky*2 + kx, what bf_im2col_nchw writes; kept for the weight gradient) and y0[p][co] = sum_k patches[p][k] * wc[co][k].
+ * Same kernel and declined shapes as bf_debed_last_bwd (returns 1). */
+int bf_embed_first(int dtype, const float* x, const void* wc, void* patches, void* y0, int frames, int C0, int cin, int h2, int w2,
+                   int Kp, bf_stream_t stream);
 int bf_lploss_finalize(const float* lossbuf, int frames, int Co, float* loss, float* coef, bf_stream_t stream);
 int bf_nchw2pm(int dtype, const float* dpred, const float* pred, const float* y, const float* coef, const float* gscale,
                void* dpm, int frames, int Co, int h, int w, int Np, bf_stream_t stream);
