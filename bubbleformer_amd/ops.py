@@ -336,12 +336,18 @@ class _DebedFn(torch.autograd.Function):
                                  _p(saved), _p(scratch_for(d, x.device)), _stream()), "bf_debed_fwd")
         ctx.cfg = (patch, cout, nst, target is not None)
         ctx.save_for_backward(x, saved, pred, target if target is not None else pred, *params)
+        ctx.set_materialize_grads(False)      # an unused output must not cost a zero-filled gradient the size of the prediction
         return pred, loss
 
     @staticmethod
     def backward(ctx, dpred, dloss):
         x, saved, pred, target, *params = ctx.saved_tensors
         patch, cout, nst, fused = ctx.cfg
+        if fused and dpred is not None:
+            raise L.BubbleformerHipError("debed_with_loss: a gradient w.r.t. the prediction is not supported beside the fused loss; "
+                                         "use debed() and a separate loss for that")
+        if (dloss if fused else dpred) is None:
+            return (None,) * (5 + len(params))
         B, T, h, w, E = x.shape
         d = make_dims(x.dtype, B, T, h, w, E, 1, patch=patch, cin=1, cout=cout)
         lib = L.lib()
