@@ -856,14 +856,21 @@ extern "C" int bf_embed_fwd(const bf_dims* dims, const bf_embed_params* p, const
     const int n = d.nst, H = d.h * d.patch, W = d.w * d.patch;
     if (d.nfluid > 0)
         TRY(bf_film_net_fwd(fluid, p->film_ln_w, p->film_ln_b, p->film_w, p->film_b, sv.gb, sv.chat, sv.crstd, d.B, d.nfluid, 2 * d.E, st));
+    bool stats_done = false;
     for (int i = 0; i < n; ++i) {
         const void* wc;
         if (i == 0) {
             TRY(bf_wprep(d.dtype, 0, p->conv_w[0], sv.wc[0], sv.C[0], 4 * d.cin, sv.Kp, st));
             wc = sv.wc[0];
             // patch rows and the K = 16 contraction in one streaming pass where it applies, else im2col + GEMM
-            const int rc = bf_embed_first(d.dtype, x, wc, sv.patches, sv.y[0], (int)d.F, sv.C[0], d.cin, H / 2, W / 2, sv.Kp, st);
+            // ... which also leaves the InstanceNorm slice partials of its output (no second read of the 226 MB map for the statistics)
+            const int S0 = sv.gh[0] * sv.gw[0];
+            static const bool part_on = []() { const char* v = getenv("BF_EMBED_STATS"); return !(v && v[0] == '0'); }();
+            const bool part_ok = part_on && n > 1 && bf_in_ws_floats(d.dtype, (int)d.F, S0, sv.C[0]) >= (int64_t)2 * d.F * sv.C[0] * (1 + (S0 + 255) / 256);      // the sliced workspace holds 256-row slices
+            const int rc = bf_embed_first(d.dtype, x, wc, sv.patches, sv.y[0], (int)d.F, sv.C[0], d.cin, H / 2, W / 2, sv.Kp,
+                                          part_ok ? sc.in_ws + (size_t)2 * d.F * sv.C[0] : nullptr, st);
             if (rc < 0) return rc;
+            stats_done = rc == 0 && part_ok;
             if (rc == 1) {
                 TRY(bf_im2col_nchw(d.dtype, x, sv.patches, (int)d.F, d.cin, H, W, sv.Kp, st));
                 bf_operand A = op_plain(sv.patches, sv.Kp, BF_LAY_KC);
@@ -883,6 +890,12 @@ extern "C" int bf_embed_fwd(const bf_dims* dims, const bf_embed_params* p, const
         }
         const bool last = i == n - 1;
         const bool film = last && d.nfluid > 0;
+        if (i == 0 && stats_done) {
+            const int mrc = bf_in_stats_merge_slices(d.dtype, (int)d.F, sv.gh[0] * sv.gw[0], sv.C[0], 256, p->in_w[0], p->in_b[0], nullptr, 1, nullptr,
+                                                     sv.mean[0], sv.rstd[0], sv.sc[0], sv.sh[0], sc.in_ws, st);
+            if (mrc < 0) return mrc;
+            if (mrc == 0) continue;
+        }
         TRY(bf_in_stats(d.dtype, sv.y[i], (int)d.F, sv.gh[i] * sv.gw[i], sv.C[i], p->in_w[i], p->in_b[i], film ? sv.gb : nullptr, d.T,
                         film ? sv.gb + (size_t)d.B * d.E : nullptr, sv.mean[i], sv.rstd[i], sv.sc[i], sv.sh[i], sc.in_ws, st));
     }

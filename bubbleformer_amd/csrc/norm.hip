@@ -627,6 +627,20 @@ static int in_stats_impl(int dtype, const void* x, int frames, int S, int C, con
     return 0;
 }
 
+// Statistics from slice partials a producer kernel already wrote (bf_embed_first): ws + 2*frames*C holds {mean, M2} per `rows`-row slice.
+// Returns 1 when the workspace bf_in_ws_floats sizes for (S, C) would not hold that many slices.
+extern "C" int bf_in_stats_merge_slices(int dtype, int frames, int S, int C, int rows, const float* w, const float* b, const float* g, int gdiv,
+                                        const float* gb, float* mean, float* rstd, float* sc, float* sh, float* ws, bf_stream_t stream) {
+    BF_REQUIRE(w && b && mean && rstd && sc && sh && ws && frames > 0 && S > 0 && C > 0 && rows > 0, "bf_in_stats_merge_slices: bad arguments");
+    const SliceCfg cfg = slice_cfg(dtype, S, C);
+    if (!cfg.sliced || bf_cdiv(S, rows) > bf_cdiv(S, cfg.rows)) return 1;
+    if (gdiv < 1) gdiv = 1;
+    hipLaunchKernelGGL(in_stats_merge_kernel, dim3(bf_cdiv(C, 64), frames), dim3(NT), 0, (hipStream_t)stream, (const float*)(ws + (size_t)2 * frames * C), frames,
+                       S, C, bf_cdiv(S, rows), rows, w, b, g, gdiv, gb, mean, rstd, sc, sh);
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int bf_in_stats(int dtype, const void* x, int frames, int S, int C, const float* w, const float* b,
                            const float* g, int gdiv, const float* gb, float* mean, float* rstd, float* sc, float* sh,
                            float* ws, bf_stream_t stream) {

@@ -184,7 +184,7 @@ template <int T>
 __global__ void __launch_bounds__(NT) debed_last_bwd_kernel(const float* __restrict__ dpred, const float* __restrict__ pred, const float* __restrict__ y,
                                                            const float* __restrict__ coef, const float* __restrict__ gscale,
                                                            const bf16* __restrict__ wc, bf16* __restrict__ dpm, bf16* __restrict__ dact,
-                                                           int Co, int h, int w) {
+                                                           int Co, int h, int w, float* __restrict__ part) {
     constexpr int Ci = 16 * T;
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -215,6 +215,9 @@ __global__ void __launch_bounds__(NT) debed_last_bwd_kernel(const float* __restr
     };
     float2 cur[4], nxt[4];
     fetch(g0, cur);
+    float s1[4 * T], s2[4 * T];       // optional InstanceNorm statistics of the rows written (this wave's 16 DL_GPW rows = one slice)
+#pragma unroll
+    for (int k = 0; k < 4 * T; ++k) s1[k] = s2[k] = 0.f;
     for (int g = g0; g < g1; ++g) {
         if (g + 1 < g1) fetch(g + 1, nxt);
         float v[4];
@@ -231,6 +234,10 @@ __global__ void __launch_bounds__(NT) debed_last_bwd_kernel(const float* __restr
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[4 * t + j] = (bf16)acc[j];
         }
+        if (part) {
+#pragma unroll
+            for (int k = 0; k < 4 * T; ++k) { const float v2 = (float)o[k]; s1[k] += v2; s2[k] += v2 * v2; }      // of the values as stored
+        }
         bf16* dst = dact + p * Ci + 4 * T * lg;
 #pragma unroll
         for (int q = 0; q < 4 * T / 8; ++q) {
@@ -241,6 +248,19 @@ __global__ void __launch_bounds__(NT) debed_last_bwd_kernel(const float* __restr
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+    }
+    if (part) {      // {slice mean, centred second moment} in in_stats_slice_kernel's layout: in_stats_merge_kernel finishes the frame
+        const float n = (float)((g1 - g0) * 16);
+        const int nsl = (GF + DL_GPW - 1) / DL_GPW, sl = g0 / DL_GPW;
+        float2* o2 = reinterpret_cast<float2*>(part) + ((long)f * nsl + sl) * Ci + 4 * T * lg;
+#pragma unroll
+        for (int k = 0; k < 4 * T; ++k) {
+            float a = s1[k], b = s2[k];
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+            const float mu = a / n;
+            if (li == 0) o2[k] = make_float2(mu, fmaxf(b - a * mu, 0.f));
+        }
     }
 }
 // loss = sum_c mean_f sqrt(num/den);  coef[f][c] = 1 / (F * sqrt(num) * sqrt(den))   (single block)
@@ -466,8 +486,9 @@ extern "C" int bf_debed_last(int dtype, const void* act, const float* sc, const 
     return 0;
 }
 
-extern "C" int bf_debed_last_bwd(int dtype, const float* dpred, const float* pred, const float* y, const float* coef, const float* gscale,
-                                 const void* wc, void* dpm, void* dact, int frames, int Ci, int Co, int h, int w, int Np, bf_stream_t stream) {
+static int debed_last_bwd_launch(int dtype, const float* dpred, const float* pred, const float* y, const float* coef, const float* gscale,
+                                 const void* wc, void* dpm, void* dact, int frames, int Ci, int Co, int h, int w, int Np, float* part,
+                                 bf_stream_t stream) {
     BF_REQUIRE(wc && dpm && dact && (dpred || (pred && y && coef)) && frames > 0 && Ci > 0 && Co > 0 && h > 0 && w > 0, "bf_debed_last_bwd: bad arguments");
     if (dtype != BF_DTYPE_BF16 || Np != 16 || Co > 4 || Ci % 32 != 0 || Ci > 128 || w % 16 != 0) return 1;      // caller keeps bf_nchw2pm + GEMM
     static const bool off = []() { const char* v = getenv("BF_DEBED_LAST_BWD"); return v && v[0] == '0'; }();
@@ -475,21 +496,28 @@ extern "C" int bf_debed_last_bwd(int dtype, const float* dpred, const float* pre
     const int GF = h * w / 16;
     dim3 grid(bf_cdiv(GF, (NT / 64) * DL_GPW), frames);
     hipStream_t st = (hipStream_t)stream;
-#define DLB(T) hipLaunchKernelGGL(debed_last_bwd_kernel<T>, grid, dim3(NT), 0, st, dpred, pred, y, coef, gscale, (const bf16*)wc, (bf16*)dpm, (bf16*)dact, Co, h, w)
+#define DLB(T) hipLaunchKernelGGL(debed_last_bwd_kernel<T>, grid, dim3(NT), 0, st, dpred, pred, y, coef, gscale, (const bf16*)wc, (bf16*)dpm, (bf16*)dact, Co, h, w, part)
     switch (Ci / 32) { case 1: DLB(2); break; case 2: DLB(4); break; case 3: DLB(6); break; default: DLB(8); break; }
 #undef DLB
     BF_CHECK_LAUNCH();
     return 0;
 }
 
+extern "C" int bf_debed_last_bwd(int dtype, const float* dpred, const float* pred, const float* y, const float* coef, const float* gscale,
+                                 const void* wc, void* dpm, void* dact, int frames, int Ci, int Co, int h, int w, int Np, bf_stream_t stream) {
+    return debed_last_bwd_launch(dtype, dpred, pred, y, coef, gscale, wc, dpm, dact, frames, Ci, Co, h, w, Np, nullptr, stream);
+}
+
 // The first HMLPEmbed stage is the same contraction (layers/patching.py:30-48, Conv2d(k=2, s=2, bias=False) on the NCHW clip): rows of 2x2
 // patches of x (k = c*4 + ky*2 + kx) times conv weight [C0][16]; `patches` is kept for the weight-gradient GEMM.
+// `stat_part` (optional): per 256-row slice {mean, centred second moment} of y0 as stored, [frames][ceil(h2*w2/256)][C0][2] floats -- the
+// partials bf_in_stats_merge_slices turns into the stage's InstanceNorm statistics, so that y0 is not read again for them.
 extern "C" int bf_embed_first(int dtype, const float* x, const void* wc, void* patches, void* y0, int frames, int C0, int cin, int h2, int w2,
-                              int Kp, bf_stream_t stream) {
+                              int Kp, float* stat_part, bf_stream_t stream) {
     BF_REQUIRE(x && wc && patches && y0, "bf_embed_first: null pointer");
     static const bool off = []() { const char* v = getenv("BF_EMBED_FIRST"); return v && v[0] == '0'; }();
     if (off) return 1;
-    return bf_debed_last_bwd(dtype, x, nullptr, nullptr, nullptr, nullptr, wc, patches, y0, frames, C0, cin, h2, w2, Kp, stream);
+    return debed_last_bwd_launch(dtype, x, nullptr, nullptr, nullptr, nullptr, wc, patches, y0, frames, C0, cin, h2, w2, Kp, stat_part, stream);
 }
 
 extern "C" int bf_lploss_finalize(const float* lossbuf, int frames, int Co, float* loss, float* coef, bf_stream_t stream) {

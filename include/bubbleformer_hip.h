@@ -180,7 +180,11 @@ int bf_debed_last_bwd(int dtype, const float* dpred, const float* pred, const fl
  * (k = c*4 + ky*2 + kx, what bf_im2col_nchw writes; kept for the weight gradient) and y0[p][co] = sum_k patches[p][k] * wc[co][k].
  * Same kernel and declined shapes as bf_debed_last_bwd (returns 1). */
 int bf_embed_first(int dtype, const float* x, const void* wc, void* patches, void* y0, int frames, int C0, int cin, int h2, int w2,
-                   int Kp, bf_stream_t stream);
+                   int Kp, float* stat_part, bf_stream_t stream);
+/* stat_part (optional): {mean, centred second moment} of y0 per 256-row slice, [frames][ceil(h2*w2/256)][C0][2]; finished by
+ * bf_in_stats_merge_slices(..., rows = 256, ws) with ws + 2*frames*C0 == stat_part (the layout bf_in_stats uses for long frames). */
+int bf_in_stats_merge_slices(int dtype, int frames, int S, int C, int rows, const float* w, const float* b, const float* g, int gdiv,
+                             const float* gb, float* mean, float* rstd, float* sc, float* sh, float* ws, bf_stream_t stream);
 int bf_lploss_finalize(const float* lossbuf, int frames, int Co, float* loss, float* coef, bf_stream_t stream);
 int bf_nchw2pm(int dtype, const float* dpred, const float* pred, const float* y, const float* coef, const float* gscale,
                void* dpm, int frames, int Co, int h, int w, int Np, bf_stream_t stream);

@@ -470,3 +470,42 @@ def test_debed_last_stage_backward_one_pass(Ci, Co, h, w, fused_loss):
     assert torch.isfinite(dact.float()).all()
     assert _rel(dact, ref) < 4e-3                      # one bf16 rounding of the result
     assert lib.bf_debed_last_bwd(0, _p(dpred), None, None, None, None, _p(wc), _p(dpm), _p(dact), Fr, Ci, Co, h, w, 16, _stream()) == 1
+
+
+@pytest.mark.parametrize("cin,h2,w2", [(4, 96, 96), (3, 40, 32), (4, 33, 16)])
+def test_embed_first_stage_one_pass_with_statistics(cin, h2, w2):
+    """bf_embed_first: 2x2 patches of the fp32 NCHW clip x the [C0][16] convolution weight (layers/patching.py:30-48, first stage) in one
+    kernel, the patch rows bf_im2col_nchw would write, and -- optionally -- the InstanceNorm slice partials of its output, which
+    bf_in_stats_merge_slices turns into the same statistics bf_in_stats computes from the stored rows (ragged last slice included)."""
+    from bubbleformer_amd import _lib as L
+    from bubbleformer_amd.ops import _p, _stream
+    lib = L.lib()
+    Fr, C0 = 3, 96
+    g = torch.Generator(device="cuda").manual_seed(31)
+    x = torch.randn(Fr, cin, 2 * h2, 2 * w2, device="cuda", generator=g) + 0.5
+    Wc = torch.zeros(C0, 16, device="cuda")
+    Wc[:, :4 * cin] = torch.randn(C0, 4 * cin, device="cuda", generator=g) / 2
+    Wc = Wc.bfloat16()
+    P, S = Fr * h2 * w2, h2 * w2
+    patches = torch.full((P, 16), float("nan"), device="cuda", dtype=torch.bfloat16)
+    y0 = torch.full((P, C0), float("nan"), device="cuda", dtype=torch.bfloat16)
+    nws = lib.bf_in_ws_floats(1, Fr, S, C0)
+    ws = torch.zeros(nws, device="cuda")
+    part = ws[2 * Fr * C0:]
+    assert nws >= 2 * Fr * C0 * (1 + (S + 255) // 256)
+    L.check(lib.bf_embed_first(1, _p(x), _p(Wc), _p(patches), _p(y0), Fr, C0, cin, h2, w2, 16, _p(part), _stream()), "embed_first")
+    ref_p = torch.zeros(P, 16, device="cuda")
+    ref_p[:, :4 * cin] = x.view(Fr, cin, h2, 2, w2, 2).permute(0, 2, 4, 1, 3, 5).reshape(P, 4 * cin)      # k = c*4 + ky*2 + kx
+    ref_p = ref_p.bfloat16()
+    assert torch.equal(patches, ref_p)
+    assert _rel(y0, ref_p.double() @ Wc.double().t()) < 4e-3
+    w, b = 1 + 0.1 * torch.randn(C0, device="cuda", generator=g), 0.1 * torch.randn(C0, device="cuda", generator=g)
+    got = [torch.empty(Fr, C0, device="cuda") for _ in range(4)]
+    L.check(lib.bf_in_stats_merge_slices(1, Fr, S, C0, 256, _p(w), _p(b), None, 1, None, *[_p(t) for t in got], _p(ws), _stream()), "merge")
+    ref = [torch.empty(Fr, C0, device="cuda") for _ in range(4)]
+    ws2 = torch.zeros(nws, device="cuda")
+    L.check(lib.bf_in_stats(1, _p(y0), Fr, S, C0, _p(w), _p(b), None, 1, None, *[_p(t) for t in ref], _p(ws2), _stream()), "in_stats")
+    yf = y0.float().view(Fr, S, C0)
+    assert _rel(got[0], yf.mean(1)) < 1e-5 and _rel(got[1], (yf.var(1, unbiased=False) + 1e-5).rsqrt()) < 1e-5
+    for a, r in zip(got, ref):
+        assert _rel(a, r) < 1e-5
