@@ -857,10 +857,18 @@ extern "C" int bf_embed_fwd(const bf_dims* dims, const bf_embed_params* p, const
     if (d.nfluid > 0)
         TRY(bf_film_net_fwd(fluid, p->film_ln_w, p->film_ln_b, p->film_w, p->film_b, sv.gb, sv.chat, sv.crstd, d.B, d.nfluid, 2 * d.E, st));
     bool stats_done = false;
+    {   // every stage's convolution weight in GEMM layout / compute dtype: one launch
+        int mode[BF_MAX_STAGES], R[BF_MAX_STAGES], K[BF_MAX_STAGES], Kp[BF_MAX_STAGES];
+        const float* src[BF_MAX_STAGES]; void* dst[BF_MAX_STAGES];
+        for (int i = 0; i < n; ++i) {
+            src[i] = p->conv_w[i]; dst[i] = sv.wc[i]; mode[i] = i == 0 ? 0 : 1; R[i] = sv.C[i];
+            K[i] = i == 0 ? 4 * d.cin : 4 * sv.C[i - 1]; Kp[i] = i == 0 ? sv.Kp : K[i];
+        }
+        TRY(bf_wprep_multi(d.dtype, n, mode, src, dst, R, K, Kp, st));
+    }
     for (int i = 0; i < n; ++i) {
         const void* wc;
         if (i == 0) {
-            TRY(bf_wprep(d.dtype, 0, p->conv_w[0], sv.wc[0], sv.C[0], 4 * d.cin, sv.Kp, st));
             wc = sv.wc[0];
             // patch rows and the K = 16 contraction in one streaming pass where it applies, else im2col + GEMM
             // ... which also leaves the InstanceNorm slice partials of its output (no second read of the 226 MB map for the statistics)
@@ -880,7 +888,6 @@ extern "C" int bf_embed_fwd(const bf_dims* dims, const bf_embed_params* p, const
             }
         } else {
             const int cp = sv.C[i - 1];
-            TRY(bf_wprep(d.dtype, 1, p->conv_w[i], sv.wc[i], sv.C[i], 4 * cp, 4 * cp, st));
             bf_operand A = op_plain(sv.y[i - 1], cp, BF_LAY_KC);
             op_gather(A, sv.gw[i], sv.gh[i], cp);
             op_affine(A, BF_PRO_AFFINE_GELU, sv.sc[i - 1], sv.sh[i - 1], (long)sv.gh[i] * sv.gw[i], cp);
@@ -987,13 +994,22 @@ extern "C" int bf_debed_fwd(const bf_dims* dims, const bf_debed_params* p, const
     DebedSaved sv(d, saved);
     Scratch sc(d, scratch);
     const int n = d.nst;
+    {   // every stage's transposed-convolution weight in GEMM layout / compute dtype: one launch
+        int mode[BF_MAX_STAGES], R[BF_MAX_STAGES], K[BF_MAX_STAGES], Kp[BF_MAX_STAGES];
+        const float* src[BF_MAX_STAGES]; void* dst[BF_MAX_STAGES];
+        for (int i = 0; i < n; ++i) {
+            const bool last = i == n - 1;
+            src[i] = p->conv_w[i]; dst[i] = sv.wc[i]; mode[i] = last ? 0 : 2;
+            R[i] = last ? sv.Cin[i] : 4 * sv.Co[i]; K[i] = last ? 4 * sv.Co[i] : sv.Cin[i]; Kp[i] = last ? sv.Np : sv.Cin[i];
+        }
+        TRY(bf_wprep_multi(d.dtype, n, mode, src, dst, R, K, Kp, st));
+    }
     for (int i = 0; i < n; ++i) {
         const bool last = i == n - 1;
         const int cin = sv.Cin[i], co = sv.Co[i];
         bf_operand A = op_plain(i == 0 ? x : sv.y[i - 1], cin, BF_LAY_KC);
         if (i > 0) op_affine(A, BF_PRO_AFFINE_GELU, sv.sc[i - 1], sv.sh[i - 1], (long)sv.gh[i] * sv.gw[i], cin);
         if (!last) {
-            TRY(bf_wprep(d.dtype, 2, p->conv_w[i], sv.wc[i], 4 * co, cin, cin, st));
             bf_operand Bo = op_plain(sv.wc[i], cin, BF_LAY_KC);
             bf_epilogue e = epi_store(sv.y[i], co);
             epi_scatter(e, sv.gw[i], sv.gh[i], co);
@@ -1001,7 +1017,6 @@ extern "C" int bf_debed_fwd(const bf_dims* dims, const bf_debed_params* p, const
             TRY(bf_in_stats(d.dtype, sv.y[i], (int)d.F, 4 * sv.gh[i] * sv.gw[i], co, p->in_w[i], p->in_b[i], nullptr, 1, nullptr, sv.mean[i],
                             sv.rstd[i], sv.sc[i], sv.sh[i], sc.in_ws, st));
         } else {
-            TRY(bf_wprep(d.dtype, 0, p->conv_w[i], sv.wc[i], cin, 4 * co, sv.Np, st));
             if (target) ZERO(sv.lossbuf, (size_t)d.F * d.cout * 2 * 4);
             // InstanceNorm affine + GELU + the 2x2 transposed convolution + NCHW store + loss partials in one streaming pass where it applies
             const int rc = i > 0 ? bf_debed_last(d.dtype, sv.y[i - 1], sv.sc[i - 1], sv.sh[i - 1], sv.wc[i], pred, target, sv.lossbuf, (int)d.F, cin, co,

@@ -332,6 +332,24 @@ __global__ void __launch_bounds__(NT) wprep_kernel(const float* __restrict__ src
         dst[i] = from_f<T>(v);
     }
 }
+// all stages of an embed / debed call in ONE launch (blockIdx.y = stage)
+struct WprepJobs { const float* src[BF_MAX_STAGES]; void* dst[BF_MAX_STAGES]; int mode[BF_MAX_STAGES], R[BF_MAX_STAGES], K[BF_MAX_STAGES], Kp[BF_MAX_STAGES]; };
+template <typename T>
+__global__ void __launch_bounds__(NT) wprep_multi_kernel(WprepJobs j) {
+    const int s = blockIdx.y;
+    const float* __restrict__ src = j.src[s];
+    T* __restrict__ dst = reinterpret_cast<T*>(j.dst[s]);
+    const int mode = j.mode[s], R = j.R[s], K = j.K[s], Kp = j.Kp[s];
+    const long total = (long)R * Kp;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int r = (int)(i / Kp), k = (int)(i % Kp);
+        float v = 0.f;
+        if (mode == 0) { if (k < K) v = src[(long)r * K + k]; }
+        else if (mode == 1) { const int Ci = K / 4, q = k / Ci, ci = k % Ci; v = src[((long)r * Ci + ci) * 4 + q]; }
+        else { const int Co = R / 4, q = r / Co, co = r % Co; v = src[((long)k * Co + co) * 4 + q]; }
+        dst[i] = from_f<T>(v);
+    }
+}
 // gradient of the prepared operand (fp32, prepared layout) accumulated into the state_dict layout
 __global__ void __launch_bounds__(NT) wgrad_unprep_kernel(const float* __restrict__ gsrc, float* __restrict__ gdst, int mode, int R, int K, int Kp,
                                                          int transposed) {
@@ -542,6 +560,23 @@ extern "C" int bf_wprep(int dtype, int mode, const float* src, void* dst, int R,
     BF_REQUIRE(mode == 0 || Kp == K, "bf_wprep: padding only with mode 0");
     if (dtype == BF_DTYPE_BF16) hipLaunchKernelGGL(wprep_kernel<bf16>, dim3(grid_for((long)R * Kp)), dim3(NT), 0, (hipStream_t)stream, src, (bf16*)dst, mode, R, K, Kp);
     else hipLaunchKernelGGL(wprep_kernel<float>, dim3(grid_for((long)R * Kp)), dim3(NT), 0, (hipStream_t)stream, src, (float*)dst, mode, R, K, Kp);
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
+// bf_wprep for n <= BF_MAX_STAGES weights at once (same modes and argument meaning per entry)
+int bf_wprep_multi(int dtype, int n, const int* mode, const float* const* src, void* const* dst, const int* R, const int* K, const int* Kp, hipStream_t st) {
+    BF_REQUIRE(n >= 1 && n <= BF_MAX_STAGES && mode && src && dst && R && K && Kp, "bf_wprep_multi: bad arguments");
+    WprepJobs j;
+    long most = 0;
+    for (int i = 0; i < n; ++i) {
+        BF_REQUIRE(src[i] && dst[i] && R[i] > 0 && K[i] > 0 && Kp[i] >= K[i] && mode[i] >= 0 && mode[i] <= 2 && (mode[i] == 0 || Kp[i] == K[i]), "bf_wprep_multi: bad entry");
+        j.src[i] = src[i]; j.dst[i] = dst[i]; j.mode[i] = mode[i]; j.R[i] = R[i]; j.K[i] = K[i]; j.Kp[i] = Kp[i];
+        most = std::max(most, (long)R[i] * Kp[i]);
+    }
+    const dim3 grid(std::min<long>(bf_cdiv(most, NT), 256), n);
+    if (dtype == BF_DTYPE_BF16) hipLaunchKernelGGL(wprep_multi_kernel<bf16>, grid, dim3(NT), 0, st, j);
+    else hipLaunchKernelGGL(wprep_multi_kernel<float>, grid, dim3(NT), 0, st, j);
     BF_CHECK_LAUNCH();
     return 0;
 }
