@@ -52,7 +52,7 @@ class _AxialBase(nn.Module):
         self.debed = HMLPDebed(patch_size=patch_size, embed_dim=embed_dim, out_channels=output_fields)
 
     def _process(self, tok):
-        # training mode: the per-sample stochastic-depth factors of ALL blocks come from one uniform draw (2 launches per step
+        # training mode: the per-sample stochastic-depth factors of ALL blocks come from one draw (2 launches per step
         # instead of 6 per block); each DropPath call of the reference still gets its own independent Bernoulli(keep) samples.
         rates = [float(getattr(blk.temporal.drop_path, "drop_prob", 0.0)) for blk in self.blocks]
         table = None
@@ -64,7 +64,7 @@ class _AxialBase(nn.Module):
                 cache.clear()
                 cache[key] = torch.tensor([1.0 - r for r in rates], dtype=torch.float32, device=tok.device)[:, None]
             keep = cache[key]
-            table = (torch.rand(len(rates), B + 2 * F, dtype=torch.float32, device=tok.device) < keep).float() / keep
+            table = torch.bernoulli(keep.expand(len(rates), B + 2 * F)).div_(keep)      # two launches: Bernoulli(keep) / keep
         for i, blk in enumerate(self.blocks):
             if table is not None and rates[i] > 0.0:
                 row = table[i]
