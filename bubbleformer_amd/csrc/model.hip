@@ -903,10 +903,14 @@ extern "C" int bf_embed_fwd(const bf_dims* dims, const bf_embed_params* p, const
             if (mrc < 0) return mrc;
             if (mrc == 0) continue;
         }
+        if (last) {       // the tokens (InstanceNorm affine, FiLM folded in) leave the statistics kernel itself where a frame fits its registers
+            TRY(bf_in_stats_apply(d.dtype, sv.y[i], (int)d.F, sv.gh[i] * sv.gw[i], sv.C[i], p->in_w[i], p->in_b[i], film ? sv.gb : nullptr, d.T,
+                                  film ? sv.gb + (size_t)d.B * d.E : nullptr, sv.mean[i], sv.rstd[i], sv.sc[i], sv.sh[i], sc.in_ws, nullptr, out, st));
+            break;
+        }
         TRY(bf_in_stats(d.dtype, sv.y[i], (int)d.F, sv.gh[i] * sv.gw[i], sv.C[i], p->in_w[i], p->in_b[i], film ? sv.gb : nullptr, d.T,
                         film ? sv.gb + (size_t)d.B * d.E : nullptr, sv.mean[i], sv.rstd[i], sv.sc[i], sv.sh[i], sc.in_ws, st));
     }
-    TRY(bf_affine_apply(d.dtype, sv.y[n - 1], nullptr, sv.sc[n - 1], sv.sh[n - 1], out, d.N, (int)d.S, d.E, st));
     return 0;
 }
 
