@@ -177,14 +177,15 @@ __global__ void __launch_bounds__(NT) debed_last_kernel(const bf16* __restrict__
 }
 // The same stage backwards: dpm[p][co*4 + ky*2 + kx] = d pred[f][co][2y+ky][2x+kx] (given, or coef[f][co] * gscale * (pred - y) of the fused
 // loss), written for the weight-gradient GEMM, and dact[p][ci] = sum_n dpm[p][n] * wc[ci][n] in the same pass (K = 16: one
-// v_mfma_f32_16x16x16_bf16 per 16 input channels).  The weight rows are dealt to the MFMA tiles so that a lane ends up with 4T
-// CONSECUTIVE input channels of its pixel (tile t, row 4 lg + j  <->  ci = 4T lg + 4t + j): dact leaves as whole 16-byte pieces, a
-// wave writes 16 complete rows.  Replaces bf_nchw2pm + a 128-wide GEMM tile with K = 16.
+// v_mfma_f32_16x16x16_bf16 per 16 input channels).  The weight rows are dealt to the MFMA tiles so that a lane ends up with runs of 8
+// consecutive input channels of its pixel and the four lanes of a pixel with 32 (tile pair q, lane group lg  <->  ci = 32 q + 8 lg + ..):
+// each store instruction writes 64 contiguous bytes of 16 rows, a wave 16 complete rows (BF_DL_PERM=0: 4T consecutive channels per
+// lane, 16-byte pieces 8T bytes apart -- 0.13 % slower end to end).  Replaces bf_nchw2pm + a 128-wide GEMM tile with K = 16.
 template <int T>
 __global__ void __launch_bounds__(NT) debed_last_bwd_kernel(const float* __restrict__ dpred, const float* __restrict__ pred, const float* __restrict__ y,
                                                            const float* __restrict__ coef, const float* __restrict__ gscale,
                                                            const bf16* __restrict__ wc, bf16* __restrict__ dpm, bf16* __restrict__ dact,
-                                                           int Co, int h, int w, float* __restrict__ part) {
+                                                           int Co, int h, int w, float* __restrict__ part, int perm) {
     constexpr int Ci = 16 * T;
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -199,7 +200,10 @@ __global__ void __launch_bounds__(NT) debed_last_bwd_kernel(const float* __restr
     s16x4 wf[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        const int ci = 4 * T * (li >> 2) + 4 * t + (li & 3);
+        // lane (pixel li, group lg) ends up with output channel chan(k) in o[k], k = 4 t + j:
+        //   perm 0: chan = 4T lg + k            (4T consecutive channels per lane: a store instruction writes 16-byte pieces 8T bytes apart)
+        //   perm 1: chan = 32 (k / 8) + 8 lg + k % 8   (store instruction q writes the 64 contiguous bytes [64 q, 64 q + 64) of each row)
+        const int ci = perm ? 32 * (t >> 1) + 8 * (li >> 2) + 4 * (t & 1) + (li & 3) : 4 * T * (li >> 2) + 4 * t + (li & 3);
         wf[t] = *reinterpret_cast<const s16x4*>(wc + ci * 16 + 4 * lg);
     }
     const float cf = (!dpred && live) ? coef[(long)f * Co + lg] * (gscale ? gscale[0] : 1.f) : 0.f;
@@ -238,13 +242,14 @@ __global__ void __launch_bounds__(NT) debed_last_bwd_kernel(const float* __restr
 #pragma unroll
             for (int k = 0; k < 4 * T; ++k) { const float v2 = (float)o[k]; s1[k] += v2; s2[k] += v2 * v2; }      // of the values as stored
         }
-        bf16* dst = dact + p * Ci + 4 * T * lg;
+        bf16* dst = dact + p * Ci + (perm ? 8 * lg : 4 * T * lg);
+        const int qs = perm ? 32 : 8;
 #pragma unroll
         for (int q = 0; q < 4 * T / 8; ++q) {
             bf16x8 o8;
 #pragma unroll
             for (int j = 0; j < 8; ++j) o8[j] = o[8 * q + j];
-            *reinterpret_cast<bf16x8*>(dst + 8 * q) = o8;
+            *reinterpret_cast<bf16x8*>(dst + qs * q) = o8;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
@@ -252,14 +257,15 @@ __global__ void __launch_bounds__(NT) debed_last_bwd_kernel(const float* __restr
     if (part) {      // {slice mean, centred second moment} in in_stats_slice_kernel's layout: in_stats_merge_kernel finishes the frame
         const float n = (float)((g1 - g0) * 16);
         const int nsl = (GF + DL_GPW - 1) / DL_GPW, sl = g0 / DL_GPW;
-        float2* o2 = reinterpret_cast<float2*>(part) + ((long)f * nsl + sl) * Ci + 4 * T * lg;
+        float2* o2 = reinterpret_cast<float2*>(part) + ((long)f * nsl + sl) * Ci;
 #pragma unroll
         for (int k = 0; k < 4 * T; ++k) {
+            const int chan = perm ? 32 * (k >> 3) + 8 * lg + (k & 7) : 4 * T * lg + k;
             float a = s1[k], b = s2[k];
 #pragma unroll
             for (int m = 8; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
             const float mu = a / n;
-            if (li == 0) o2[k] = make_float2(mu, fmaxf(b - a * mu, 0.f));
+            if (li == 0) o2[chan] = make_float2(mu, fmaxf(b - a * mu, 0.f));
         }
     }
 }
@@ -514,7 +520,8 @@ static int debed_last_bwd_launch(int dtype, const float* dpred, const float* pre
     const int GF = h * w / 16;
     dim3 grid(bf_cdiv(GF, (NT / 64) * DL_GPW), frames);
     hipStream_t st = (hipStream_t)stream;
-#define DLB(T) hipLaunchKernelGGL(debed_last_bwd_kernel<T>, grid, dim3(NT), 0, st, dpred, pred, y, coef, gscale, (const bf16*)wc, (bf16*)dpm, (bf16*)dact, Co, h, w, part)
+    static const int perm = []() { const char* v = getenv("BF_DL_PERM"); return v ? atoi(v) : 1; }();
+#define DLB(T) hipLaunchKernelGGL(debed_last_bwd_kernel<T>, grid, dim3(NT), 0, st, dpred, pred, y, coef, gscale, (const bf16*)wc, (bf16*)dpm, (bf16*)dact, Co, h, w, part, perm)
     switch (Ci / 32) { case 1: DLB(2); break; case 2: DLB(4); break; case 3: DLB(6); break; default: DLB(8); break; }
 #undef DLB
     BF_CHECK_LAUNCH();
