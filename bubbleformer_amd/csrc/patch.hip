@@ -503,6 +503,8 @@ extern "C" int bf_debed_last(int dtype, const void* act, const float* sc, const 
     const int GF = h * w / 16;
     dim3 grid(bf_cdiv(GF, (NT / 64) * DL_GPW), frames);
     hipStream_t st = (hipStream_t)stream;
+    const double P = (double)frames * h * w;
+    BfProfScope prof(st, "debed_last", 2.0 * P * Ci * 16, P * (2.0 * Ci + 16.0 * Co * (y ? 2 : 1)));
 #define DL(KS) hipLaunchKernelGGL(debed_last_kernel<KS>, grid, dim3(NT), 0, st, (const bf16*)act, sc, sh, (const bf16*)wc, pred, y, lossbuf, Co, h, w)
     switch (Ci / 32) { case 1: DL(1); break; case 2: DL(2); break; case 3: DL(3); break; default: DL(4); break; }
 #undef DL
@@ -521,6 +523,8 @@ static int debed_last_bwd_launch(int dtype, const float* dpred, const float* pre
     dim3 grid(bf_cdiv(GF, (NT / 64) * DL_GPW), frames);
     hipStream_t st = (hipStream_t)stream;
     static const int perm = []() { const char* v = getenv("BF_DL_PERM"); return v ? atoi(v) : 1; }();
+    const double P = (double)frames * h * w;
+    BfProfScope prof(st, "patch16", 2.0 * P * Ci * 16, P * (2.0 * Ci + 32.0 + 16.0 * Co * (dpred ? 1 : 2)));
 #define DLB(T) hipLaunchKernelGGL(debed_last_bwd_kernel<T>, grid, dim3(NT), 0, st, dpred, pred, y, coef, gscale, (const bf16*)wc, (bf16*)dpm, (bf16*)dact, Co, h, w, part, perm)
     switch (Ci / 32) { case 1: DLB(2); break; case 2: DLB(4); break; case 3: DLB(6); break; default: DLB(8); break; }
 #undef DLB
