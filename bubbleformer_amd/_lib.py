@@ -71,6 +71,8 @@ SIGNATURES = {
     "bf_prof_enable": (None, [C.c_int]),
     "bf_debug_force_generic_attn": (None, [C.c_int]),
     "bf_side_defer": (None, [C.c_int]),
+    "bf_prep_stages": (C.c_int, [C.POINTER(Dims), C.c_int, C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]),
+    "bf_stage_prepared": (None, [C.c_int]),
     "bf_side_join": (C.c_int, [vp]),
     "bf_prof_report": (C.c_int, [C.c_char_p, C.c_int]),
     "bf_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, P(Operand), P(Operand), P(Epilogue), C.c_int, vp]),

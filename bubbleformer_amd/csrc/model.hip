@@ -306,6 +306,35 @@ __global__ void __launch_bounds__(256) stage_prep_kernel(Cast4 j, int cnt, PrepA
         *reinterpret_cast<bf16x4*>(j.dst[w] + 4 * i) = o;
     }
 }
+// ... and the same for up to PREP_BATCH stages in one launch (blockIdx.z = stage): bf_prep_stages
+constexpr int PREP_BATCH = 12;
+struct PrepBatch { Cast4 j[PREP_BATCH]; PrepArgs a[PREP_BATCH]; int cnt[PREP_BATCH]; };
+__global__ void __launch_bounds__(256) stage_prep_multi_kernel(PrepBatch b) {
+    const int z = blockIdx.z, cnt = b.cnt[z];
+    const Cast4& j = b.j[z];
+    const PrepArgs& a = b.a[z];
+    if ((int)blockIdx.y == cnt + 1) {
+        if (!a.tab_out) return;
+        const long n = (long)a.tab_F * a.E;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) a.tab_out[i] = a.tab_m[i / a.E] * a.tab_v[i % a.E];
+        return;
+    }
+    if ((int)blockIdx.y > cnt + 1) return;
+    if ((int)blockIdx.y == cnt) {
+        if ((int)blockIdx.x < a.E) outproj_prep_row(a.W, a.bias, a.nb, a.gamma, a.lo, a.hi, a.alpha, a.beta, a.mc, a.E, blockIdx.x, a.wscaled, a.dtype);
+        return;
+    }
+    const int w = blockIdx.y;
+    const long n4 = j.n[w] / 4;
+    const float4* s4 = reinterpret_cast<const float4*>(j.src[w]);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = s4[i];
+        const bf16x4 o = {(bf16)v.x, (bf16)v.y, (bf16)v.z, (bf16)v.w};
+        *reinterpret_cast<bf16x4*>(j.dst[w] + 4 * i) = o;
+    }
+}
+// set by bf_stage_prepared(1): the next trunk stage forward finds its weights prepared in `saved` (bf_prep_stages) and skips its own launch
+bool g_stage_prepared = false;
 // weights[i] (fp32, count n[i], multiples of 4) -> compute-dtype operands: one cast launch in bf16 mode, aliases in f32 mode;
 // `prep` (optional): the out-projection fold of the stage, computed in the same launch
 int wviews(const D& d, int cnt, const float* const* src, void* const* dst, const long* n, const void** out, hipStream_t st, const PrepArgs* prep = nullptr) {
@@ -576,7 +605,10 @@ extern "C" int bf_temporal_fwd(const bf_dims* dims, const bf_temporal_params* p,
         const void* out[4];
         const PrepArgs prep{p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr, sv.alpha, sv.beta, sv.mc, d.E, sv.wout_s, d.dtype,
                             nullptr, nullptr, nullptr, 0};
-        TRY(wviews(d, 2, src, dst, n, out, st, &prep));
+        const bool ready = g_stage_prepared && d.dtype == BF_DTYPE_BF16;
+        g_stage_prepared = false;
+        if (ready) { out[0] = sv.win_c; out[1] = sv.wout_c; }
+        else TRY(wviews(d, 2, src, dst, n, out, st, &prep));
         win_c = out[0]; wout_c = out[1];
     }
     TRY(bf_in_stats_apply(d.dtype, x, (int)d.F, (int)d.S, d.E, p->norm1_w, p->norm1_b, nullptr, 1, nullptr, sv.mean1, sv.rstd1, sv.sc1, sv.sh1, sc.in_ws,
@@ -631,6 +663,55 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
     return fk.join();
 }
 
+// Parameter preparation of many trunk stages at once (what each stage forward otherwise launches for itself): bf16 weight copies, the
+// out-projection fold and the MLP branch's stochastic-depth table, written into each stage's `saved` record.  kinds[i]: 0 temporal
+// (params[i] = bf_temporal_params*), 1 spatial (bf_spatial_params*); drop_mlp[i]: the spatial stage's MLP-branch factors or NULL.
+// A stage forward consumes it when bf_stage_prepared(1) was called just before.  bf16 only (returns 1 in fp32 mode: nothing to cast).
+extern "C" int bf_prep_stages(const bf_dims* dims, int n, const int32_t* kinds, const void* const* params, void* const* saved,
+                              const float* const* drop_mlp, bf_stream_t s) {
+    D d; TRY(get_dims(dims, &d));
+    BF_REQUIRE(n >= 1 && kinds && params && saved, "bf_prep_stages: bad arguments");
+    if (d.dtype != BF_DTYPE_BF16) return 1;
+    hipStream_t st = (hipStream_t)s;
+    TRY(side_join_pending(st));
+    for (int i0 = 0; i0 < n; i0 += PREP_BATCH) {
+        PrepBatch b;
+        memset(&b, 0, sizeof(b));
+        const int m = std::min(PREP_BATCH, n - i0);
+        for (int i = 0; i < m; ++i) {
+            BF_REQUIRE(params[i0 + i] && saved[i0 + i] && (kinds[i0 + i] == 0 || kinds[i0 + i] == 1), "bf_prep_stages: bad stage entry");
+            Cast4& j = b.j[i];
+            if (kinds[i0 + i] == 0) {
+                const bf_temporal_params* p = (const bf_temporal_params*)params[i0 + i];
+                TemporalSaved sv(d, saved[i0 + i]);
+                const float* src[2] = {p->input_head_w, p->output_head_w};
+                void* dst[2] = {sv.win_c, sv.wout_c};
+                const long cn[2] = {3L * d.E * d.E, (long)d.E * d.E};
+                for (int q = 0; q < 4; ++q) { j.src[q] = src[q < 2 ? q : 0]; j.dst[q] = (bf16*)dst[q < 2 ? q : 0]; j.n[q] = q < 2 ? cn[q] : 0; }
+                b.cnt[i] = 2;
+                b.a[i] = PrepArgs{p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr, sv.alpha, sv.beta, sv.mc, d.E, sv.wout_s, d.dtype,
+                                  nullptr, nullptr, nullptr, 0};
+            } else {
+                const bf_spatial_params* p = (const bf_spatial_params*)params[i0 + i];
+                SpatialSaved sv(d, saved[i0 + i]);
+                const float* src[4] = {p->input_head_w, p->output_head_w, p->fc1_w, p->fc2_w};
+                void* dst[4] = {sv.win_c, sv.wout_c, sv.w1_c, sv.w2_c};
+                const long cn[4] = {3L * d.E * d.E, (long)d.E * d.E, 4L * d.E * d.E, 4L * d.E * d.E};
+                for (int q = 0; q < 4; ++q) { j.src[q] = src[q]; j.dst[q] = (bf16*)dst[q]; j.n[q] = cn[q]; }
+                b.cnt[i] = 4;
+                const float* dm = drop_mlp ? drop_mlp[i0 + i] : nullptr;
+                b.a[i] = PrepArgs{p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att, d.feat_scale ? p->low_freq_scalar : nullptr,
+                                  d.feat_scale ? p->high_freq_scalar : nullptr, sv.alpha, sv.beta, sv.mc, d.E, sv.wout_s, d.dtype,
+                                  dm, dm ? p->gamma_mlp : nullptr, dm ? sv.gtab : nullptr, (int)d.F};
+            }
+        }
+        hipLaunchKernelGGL(stage_prep_multi_kernel, dim3(std::max(64, d.E), 6, m), dim3(256), 0, st, b);
+        BF_CHECK_LAUNCH();
+    }
+    return 0;
+}
+extern "C" void bf_stage_prepared(int on) { g_stage_prepared = on != 0; }
+
 // ================================================================================================= axial (spatial) block
 extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, const void* x, void* out, void* saved, void* scratch,
                               const float* drop_att, const float* drop_mlp, bf_stream_t s) {
@@ -650,7 +731,10 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
         const PrepArgs prep{p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att, d.feat_scale ? p->low_freq_scalar : nullptr,
                             d.feat_scale ? p->high_freq_scalar : nullptr, sv.alpha, sv.beta, sv.mc, d.E, sv.wout_s, d.dtype,
                             tab ? drop_mlp : nullptr, tab ? p->gamma_mlp : nullptr, tab ? sv.gtab : nullptr, (int)d.F};
-        TRY(wviews(d, 4, src, dst, n, out, st, &prep));
+        const bool ready = g_stage_prepared && d.dtype == BF_DTYPE_BF16;
+        g_stage_prepared = false;
+        if (ready) { out[0] = sv.win_c; out[1] = sv.wout_c; out[2] = sv.w1_c; out[3] = sv.w2_c; }
+        else TRY(wviews(d, 4, src, dst, n, out, st, &prep));
         win_c = out[0]; wout_c = out[1]; w1_c = out[2]; w2_c = out[3];
     }
     TRY(bf_in_stats_apply(d.dtype, x, (int)d.F, (int)d.S, d.E, p->norm1_w, p->norm1_b, nullptr, 1, nullptr, sv.mean1, sv.rstd1, sv.sc1, sv.sh1, sc.in_ws,

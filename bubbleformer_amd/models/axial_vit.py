@@ -65,12 +65,23 @@ class _AxialBase(nn.Module):
                 cache[key] = torch.tensor([1.0 - r for r in rates], dtype=torch.float32, device=tok.device)[:, None]
             keep = cache[key]
             table = torch.bernoulli(keep.expand(len(rates), B + 2 * F)).div_(keep)      # two launches: Bernoulli(keep) / keep
-        for i, blk in enumerate(self.blocks):
-            if table is not None and rates[i] > 0.0:
-                row = table[i]
-                tok = blk.forward_tokens(tok, (row[:B], row[B:B + F], row[B + F:]))
-            else:
-                tok = blk.forward_tokens(tok)
+        drops = [None] * len(self.blocks)
+        if table is not None:
+            for i in range(len(self.blocks)):
+                if rates[i] > 0.0:
+                    drops[i] = (table[i, :B], table[i, B:B + F], table[i, B + F:])
+        if tok.is_cuda and self.blocks:      # every stage's parameter preparation in one launch per 12 stages (a no-op outside bf16)
+            b0 = self.blocks[0]
+            stages = []
+            for i, blk in enumerate(self.blocks):
+                stages.append(("temporal", blk.temporal.stage_params(), None))
+                stages.append(("spatial", blk.spatial.stage_params(), drops[i][2] if drops[i] is not None else None))
+            ops.prepare_stages(tok, b0.temporal.num_heads, b0.temporal.attn_scale, b0.spatial.feat_scale, stages)
+        try:
+            for i, blk in enumerate(self.blocks):
+                tok = blk.forward_tokens(tok, drops[i])
+        finally:
+            ops.discard_prepared()       # records nobody consumed (an exception above) must not meet a later call with newer weights
         return tok
 
 

@@ -9,6 +9,7 @@ parameter so autograd accumulation hooks (and therefore DDP bucket hooks) fire p
 """
 import collections
 import ctypes as C
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -165,6 +166,49 @@ def as_reference_layout(tok: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------------ processor blocks
+_PREPARED: dict = {}      # (kind, pointer of the stage's first parameter) -> (dims key, saved record with prepared weights)
+
+
+def _stage_key(kind: str, params) -> tuple:
+    return kind, next(p.data_ptr() for p in params if p is not None)
+
+
+def prepare_stages(tok: torch.Tensor, heads: int, attn_scale: bool, feat_scale: bool, stages) -> None:
+    """Parameter preparation of all trunk stages of one forward in one launch per 12 stages (bf_prep_stages) instead of one launch
+    inside every stage.  stages: [(kind, params, drop_mlp or None)] in call order; each stage's `saved` record is allocated here and
+    handed to the stage's forward, which must follow with the same tok shape / dtype.  bf16 on the GPU only; otherwise a no-op."""
+    _PREPARED.clear()
+    if not tok.is_cuda or tok.dtype != torch.bfloat16 or not stages or os.environ.get("BF_PREP_AHEAD", "1") == "0":
+        return
+    B, T, h, w, E = tok.shape
+    d = make_dims(tok.dtype, B, T, h, w, E, heads, attn_scale, feat_scale)
+    keys = {"temporal": _dims_key(make_dims(tok.dtype, B, T, h, w, E, heads, attn_scale, True)), "spatial": _dims_key(d)}
+    lib = L.lib()
+    n = len(stages)
+    nb = {"temporal": lib.bf_temporal_saved_bytes(C.byref(d)), "spatial": lib.bf_spatial_saved_bytes(C.byref(d))}
+    kinds = (C.c_int32 * n)()
+    pp, sp, dp = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+    keep = []
+    for i, (kind, params, drop_mlp) in enumerate(stages):
+        params = [_f32c(p) for p in params]
+        st = (L.TemporalParams if kind == "temporal" else L.SpatialParams)(*[_p(p) for p in params])
+        saved = _saved(nb[kind], tok.device, f"bf_{kind}_saved_bytes")
+        if drop_mlp is not None:
+            drop_mlp = drop_mlp.contiguous().float()
+        keep.append((st, params, drop_mlp))
+        kinds[i] = 0 if kind == "temporal" else 1
+        pp[i], sp[i], dp[i] = C.addressof(st), _p(saved), _p(drop_mlp)
+        _PREPARED[_stage_key(kind, params)] = (keys[kind], saved, drop_mlp)
+    rc = lib.bf_prep_stages(C.byref(d), n, kinds, pp, sp, dp, _stream())
+    if rc != 0:
+        _PREPARED.clear()
+        L.check(min(rc, 0), "bf_prep_stages")
+
+
+def discard_prepared() -> None:
+    _PREPARED.clear()
+
+
 class _BlockFn(torch.autograd.Function):
     """Shared driver for the temporal and the axial block."""
 
@@ -177,17 +221,22 @@ class _BlockFn(torch.autograd.Function):
         d = make_dims(x.dtype, B, T, h, w, E, heads, attn_scale, feat_scale)
         lib = L.lib()
         params = [_f32c(p) for p in params]
+        drop_a = None if drop_a is None else drop_a.contiguous().float()
+        drop_b = None if drop_b is None else drop_b.contiguous().float()
+        pre = _PREPARED.pop(_stage_key(kind, params), None) if _PREPARED else None
+        if pre is not None and (pre[0] != _dims_key(d) or (pre[2] is None) != (drop_b is None) or
+                                (drop_b is not None and pre[2].data_ptr() != drop_b.data_ptr())):
+            pre = None                                  # prepared for another shape or another stochastic-depth table: prepare here
         if kind == "temporal":
             st = L.TemporalParams(*[_p(p) for p in params])
-            saved = _saved(lib.bf_temporal_saved_bytes(C.byref(d)), x.device, "bf_temporal_saved_bytes")
+            saved = pre[1] if pre else _saved(lib.bf_temporal_saved_bytes(C.byref(d)), x.device, "bf_temporal_saved_bytes")
             fwd = lib.bf_temporal_fwd
         else:
             st = L.SpatialParams(*[_p(p) for p in params])
-            saved = _saved(lib.bf_spatial_saved_bytes(C.byref(d)), x.device, "bf_spatial_saved_bytes")
+            saved = pre[1] if pre else _saved(lib.bf_spatial_saved_bytes(C.byref(d)), x.device, "bf_spatial_saved_bytes")
             fwd = lib.bf_spatial_fwd
         out = torch.empty_like(x)
-        drop_a = None if drop_a is None else drop_a.contiguous().float()
-        drop_b = None if drop_b is None else drop_b.contiguous().float()
+        lib.bf_stage_prepared(1 if pre else 0)
         if kind == "temporal":
             rc = fwd(C.byref(d), C.byref(st), _p(x), _p(out), _p(saved), _p(scratch_for(d, x.device)), _p(drop_a), _stream())
         else:

@@ -261,6 +261,13 @@ int64_t bf_embed_saved_bytes(const bf_dims* d);
 int64_t bf_debed_saved_bytes(const bf_dims* d);
 int64_t bf_scratch_bytes(const bf_dims* d);
 
+/* Parameter preparation (bf16 weight copies, out-projection fold, MLP-branch stochastic-depth table) of n trunk stages in one launch per
+ * 12 stages, written into each stage's `saved` record; kinds[i] 0 = temporal (params[i]: bf_temporal_params*), 1 = spatial
+ * (bf_spatial_params*); drop_mlp[i]: that spatial stage's MLP-branch factors or NULL.  bf_stage_prepared(1) just before a stage forward
+ * tells it to use them instead of launching its own preparation (the flag is consumed by that call).  Returns 1 in fp32 mode. */
+int bf_prep_stages(const bf_dims* dims, int n, const int32_t* kinds, const void* const* params, void* const* saved,
+                   const float* const* drop_mlp, bf_stream_t stream);
+void bf_stage_prepared(int on);
 /* x, out, dout, dx: [N][E] activations.  Gradients ACCUMULATE into `g` (zero it first). */
 /* Stochastic depth (timm DropPath at layers/attention.py:123,309,317): `drop*` are the per-sample factors (0 or 1/keep) the
  * caller drew -- [B] for the temporal block (dim 0 = batch), [B*T] each for the two branches of the axial block -- or NULL. */

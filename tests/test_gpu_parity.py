@@ -321,3 +321,33 @@ def test_training_mode_draws_masks_and_eval_is_deterministic():
     torch.manual_seed(0)
     outs = [model(x, c) for _ in range(4)]
     assert any(rel_l2(o.cpu(), a.cpu()) > 1e-3 for o in outs)   # masks are active in training mode
+
+
+def test_batched_stage_preparation_is_bit_identical(monkeypatch):
+    """bf_prep_stages (all trunk stages' bf16 weight copies, out-projection folds and stochastic-depth tables in one launch per 12
+    stages) against the per-stage preparation launches it replaces: same prediction bit for bit in eval and in training mode under a
+    fixed seed, same loss, and the prepared records are consumed (nothing left for a later call)."""
+    from bubbleformer_amd import ops
+    spec, z, model = build_product_model("tiny_d64", torch.bfloat16)
+    from bubbleformer_amd.layers.attention import DropPath
+    for blk in model.blocks:
+        blk.temporal.drop_path = DropPath(0.3)
+        blk.spatial.drop_path = DropPath(0.3)
+    x = torch.from_numpy(z["x"]).cuda()
+    c = torch.from_numpy(z["cond"]).cuda()
+    y = torch.from_numpy(z["y"]).cuda()
+
+    def run(train):
+        model.train(train)
+        torch.manual_seed(5)
+        loss, pred = model.forward_loss(x, c, y)
+        assert not ops._PREPARED
+        return float(loss), pred.clone()
+
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("BF_PREP_AHEAD", mode)
+        got[mode] = (run(False), run(True))
+    for a, b in zip(got["1"], got["0"]):
+        assert a[0] == b[0] and torch.equal(a[1], b[1])
+    assert got["1"][0][0] != got["1"][1][0]          # the training-mode run really dropped something
