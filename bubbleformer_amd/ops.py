@@ -198,7 +198,7 @@ def prepare_stages(tok: torch.Tensor, heads: int, attn_scale: bool, feat_scale: 
         keep.append((st, params, drop_mlp))
         kinds[i] = 0 if kind == "temporal" else 1
         pp[i], sp[i], dp[i] = C.addressof(st), _p(saved), _p(drop_mlp)
-        _PREPARED[_stage_key(kind, params)] = (keys[kind], saved, drop_mlp)
+        _PREPARED[_stage_key(kind, params)] = (keys[kind], saved, drop_mlp, st)
     rc = lib.bf_prep_stages(C.byref(d), n, kinds, pp, sp, dp, _stream())
     if rc != 0:
         _PREPARED.clear()
@@ -228,11 +228,11 @@ class _BlockFn(torch.autograd.Function):
                                 (drop_b is not None and pre[2].data_ptr() != drop_b.data_ptr())):
             pre = None                                  # prepared for another shape or another stochastic-depth table: prepare here
         if kind == "temporal":
-            st = L.TemporalParams(*[_p(p) for p in params])
+            st = pre[3] if pre else L.TemporalParams(*[_p(p) for p in params])
             saved = pre[1] if pre else _saved(lib.bf_temporal_saved_bytes(C.byref(d)), x.device, "bf_temporal_saved_bytes")
             fwd = lib.bf_temporal_fwd
         else:
-            st = L.SpatialParams(*[_p(p) for p in params])
+            st = pre[3] if pre else L.SpatialParams(*[_p(p) for p in params])
             saved = pre[1] if pre else _saved(lib.bf_spatial_saved_bytes(C.byref(d)), x.device, "bf_spatial_saved_bytes")
             fwd = lib.bf_spatial_fwd
         out = torch.empty_like(x)

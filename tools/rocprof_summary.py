@@ -46,7 +46,7 @@ def normalise(name: str) -> str:
         if key in name:
             return key
     for key in ("attn_fwd_axial_mfma", "attn_bwd_mfma", "attn_fwd_mfma", "attn_ws_reduce", "in_bwd_kernel", "in_stats_kernel", "in_param_reduce_kernel", "affine_apply_kernel",
-                "colsum_kernel", "adamw_kernel", "wprep_multi_kernel", "wprep_kernel", "outproj_finalize_kernel", "outproj_prep_kernel", "debed_last_bwd_kernel", "debed_last_kernel", "pm2nchw_kernel", "nchw2pm_kernel",
+                "colsum_kernel", "adamw_kernel", "wprep_multi_kernel", "wprep_kernel", "outproj_finalize_kernel", "outproj_prep_kernel", "stage_prep_multi_kernel", "debed_last_bwd_kernel", "debed_last_kernel", "pm2nchw_kernel", "nchw2pm_kernel",
                 "im2col_kernel", "film_net_bwd_kernel", "film_net_fwd_kernel", "wgrad_unprep_kernel", "attn_fwd_kernel", "attn_bwd_kernel"):
         if key in name:
             return key

@@ -21,7 +21,7 @@ def short(n):
     if m:
         return "gemm<bf16,xc,%s,pro%s>" % ("xc" if m.group(1) == "true" else "kc", "A" if m.group(2) == "true" else "B" if m.group(3) == "true" else "0")
     for key in ("gemm_inbwd_frames", "attn_fwd_axial_mfma", "attn_bwd_mfma", "attn_fwd_mfma", "in_bwd_slice", "in_stats_slice", "in_stats_merge", "in_slice_sum", "in_bwd_kernel",
-                "in_stats_kernel", "in_param_reduce", "stage_param_reduce", "stage_prep", "frame_scale", "frame_table", "adamw", "outproj_finalize",
+                "in_stats_kernel", "in_param_reduce", "stage_param_reduce", "stage_prep_multi", "stage_prep", "frame_scale", "frame_table", "adamw", "outproj_finalize",
                 "wgrad_unprep", "wprep", "debed_last_bwd", "debed_last", "pm2nchw", "nchw2pm", "im2col", "film_net_bwd", "film_net_fwd", "fillBufferAligned", "copyBuffer", "lploss"):
         if key in n:
             return key
