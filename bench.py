@@ -216,7 +216,9 @@ def main():
         roofline.update({"traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": dom["calls"] / nprof,
                          "algorithmic_bytes_per_launch": nbytes, "algorithmic_flops_per_launch": flops, "tflops": tflops,
                          "mfma_frac": tflops / peak_tf, "share_of_gpu_time": dom["ms"] / tot_ms,
-                         "kernel_time_share": {k: round(v["ms"] / tot_ms, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:12]}})
+                         "kernel_time_share": {k: round(v["ms"] / tot_ms, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:12]},
+                         "kernel_avg_us": {k: [round(v["ms"] / v["calls"] * 1e3, 1), v["calls"] // nprof] for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:16]},
+                         "gpu_kernel_ms_per_step": tot_ms / nprof})
 
     if rank != 0:
         if world > 1:

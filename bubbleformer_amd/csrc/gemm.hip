@@ -417,8 +417,8 @@ int launch(int M, int N, int K, const bf_operand* A, const bf_operand* B, const 
 
 }  // namespace
 
-int bf_gemm_wide_try(int M, int N, int K, const bf_operand* A, const bf_operand* B, const bf_epilogue* E, int splitk, hipStream_t st);
-static bool g_no_wide = []() { const char* v = getenv("BF_GEMM_NO_WIDE"); return v && atoi(v) != 0; }();
+// gemm_stream.hip: weight-stationary persistent kernel for the short-K projections (0 = handled, 1 = not covered, < 0 = error)
+int bf_gemm_stream_try(int M, int N, int K, const bf_operand* A, const bf_operand* B, const bf_epilogue* E, hipStream_t st);
 
 extern "C" int bf_gemm(int dtype, int M, int N, int K, const bf_operand* A, const bf_operand* B, const bf_epilogue* E,
                        int splitk, bf_stream_t stream) {
@@ -445,9 +445,9 @@ extern "C" int bf_gemm(int dtype, int M, int N, int K, const bf_operand* A, cons
     if (E->aux_mode != BF_AUX_NONE) BF_REQUIRE(E->aux != nullptr, "bf_gemm: aux pointer missing");
     BF_REQUIRE(!E->colsum || A->layout == BF_LAY_XC, "bf_gemm: colsum is defined for the token-reduction form only");
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == BF_DTYPE_BF16 && !g_no_wide) {
-        const int rc = bf_gemm_wide_try(M, N, K, A, B, E, splitk, st);
-        if (rc <= 0) return rc;          // handled (0) or failed (< 0); 1 = not covered by the wide-tile kernel
+    if (dtype == BF_DTYPE_BF16) {
+        const int rc = bf_gemm_stream_try(M, N, K, A, B, E, st);
+        if (rc <= 0) return rc;          // handled (0) or failed (< 0); 1 = not covered by the streaming kernel
     }
     if (dtype == BF_DTYPE_BF16) return launch<bf16>(M, N, K, A, B, E, splitk, st);
     if (dtype == BF_DTYPE_F32) return launch<float>(M, N, K, A, B, E, splitk, st);

@@ -1,4 +1,4 @@
-// Device helpers shared by the GEMM kernels (gemm.hip: 128/64 x 128 tiles, 4 waves; gemm_wide.hip: 128/64 x 384 tiles, 8 waves).
+// Device helpers shared by the GEMM kernels (gemm.hip tile kernel, gemm_frame.hip whole-frame tiles, gemm_stream.hip / gemm_tokred.hip LDS-DMA kernels).
 #pragma once
 #include "bf_common.h"
 
@@ -104,6 +104,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg / 8, r = nwg % 8, x = bid % 8;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
 }
+
+// ----------------------------------------------------------------------------- LDS-DMA (global -> LDS, no staging registers)
+// One global_load_lds_dwordx4: lane l copies the 16 bytes at its OWN source address to LDS byte lds_dst + 16 * l (lds_dst wave-uniform).
+// Written as inline asm on purpose: hipcc models the builtin's LDS write and then drains vmcnt(0) before the next ds_read of the same
+// array, which serialises every K-step; hidden from it, the DMA is ordered for readers by the counted s_waitcnt vmcnt + s_barrier the
+// kernels place themselves (cdna_hip_programming.md section 5.7 item 1).  M0 (the DMA's LDS base) is saved and restored.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <typename T>
 __device__ __forceinline__ void store4(T* c, const float (&u)[4], bool full, int nleft) {

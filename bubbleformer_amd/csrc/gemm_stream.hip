@@ -1,0 +1,308 @@
+// Weight-stationary streaming GEMM for gfx950: C[M][N] = epi(A[M][K] @ W[N][K]^T) for the trunk's SHORT-K projections
+// (K = E = 256..384: QKV, out-projection, fc1 forward and the fc2 data gradient; layers/attention.py:78,121,210,299, linear_layers.py:18).
+//
+// These products have tens of thousands of token rows and a few hundred weight rows / reduction steps, so a tile-per-workgroup kernel
+// spends its life in prologues and epilogues (six K-steps between a cold start and an HBM-rate store burst).  Here instead:
+//  * ONE persistent workgroup per CU owns a 128-column block of W for a run of row tiles; that block (128 x K bf16, <= 96 KB) is
+//    loaded into LDS once and stays there -- the MI355X CU has 160 KB of LDS, which is what makes the block fit beside a ring;
+//  * the token rows stream through a 2-slot ring of 256 x 64 chunks, global -> LDS by DMA (global_load_lds_dwordx4, no staging
+//    registers), one chunk in flight while one is multiplied (a ~1 us step), across tile boundaries: the next tile's first chunk lands
+//    while this tile finishes.  256-row tiles with 64 x 64 per wave halve the LDS read bytes and the barriers per FLOP of a 128-row tile;
+//  * one raw s_barrier per K-step and a counted s_waitcnt vmcnt that never drains the DMA queue (stores and epilogue operand loads are
+//    counted in issue order, cdna_hip_programming.md section 5 "Pipelining across barriers");
+//  * the epilogue needs no LDS: two 16 x 16 accumulator tiles are exchanged between lane rows with v_permlane16_swap so that a lane
+//    owns 8 consecutive columns -- 16-byte residual / gelu' loads and 16-byte stores straight from registers;
+//  * only the token chunks are fetched per step: 32 KB per 4.2 MFLOP = 128 FLOP per DMA byte, the same as a 256 x 256 tile (a CU
+//    takes in ~70 GB/s from L2, MI355X_MICROARCH.md "Indexed rows", which caps a 128 x 128 two-operand tile at 46 % of the MFMA rate).
+// Workgroups form TEAMS of N/128 (one per column block) that sit on one XCD and sweep the same row tiles in step: a token chunk comes
+// from HBM once and the rest of the team reads it from that XCD's L2 (with runs cut from a column-block-major sequence instead, every
+// workgroup re-fetched its rows through the fabric: 36 us for the QKV projection, HBM-bound on re-reads).
+#include "gemm_common.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+
+namespace {
+using namespace bfgemm;
+
+constexpr int BM = 256, BNB = 128, BK = 64;
+constexpr int CHUNK = BNB * BK;         // elements of one [128][64] weight chunk (16 KB)
+constexpr int ACHUNK = BM * BK;         // elements of one [256][64] token chunk (32 KB)
+constexpr int NSLOT = 2;                // token ring: one chunk multiplied, one in flight
+
+struct StreamArgs {
+    const bf16* A; long lda; const bf16* W; long ldw; bf16* C; long ldc;
+    const float* bias; const float* colscale; const float* colshift; const float* rowscale; int rpg;
+    int aux_mode; const bf16* aux; long ld_aux; bf16* gelu_out;
+    int KS, mt, nb;
+    int dbg;      // timing experiments (BF_STREAM_DEBUG): 1 no DMA waits, 2 every tile reads the rows of tile 0, 4 no LDS reads / MFMA, 8 no stores
+};
+
+__device__ __forceinline__ void wait_vm_n(int n) {      // n is wave-uniform; a smaller count than asked for is always safe (in-order retirement)
+    if (n >= 16) { wait_vm<16>(); return; }
+    switch (n) {
+        case 0: wait_vm<0>(); break;   case 1: wait_vm<1>(); break;   case 2: wait_vm<2>(); break;   case 3: wait_vm<3>(); break;
+        case 4: wait_vm<4>(); break;   case 5: wait_vm<5>(); break;   case 6: wait_vm<6>(); break;   case 7: wait_vm<7>(); break;
+        case 8: wait_vm<8>(); break;   case 9: wait_vm<9>(); break;   case 10: wait_vm<10>(); break; case 11: wait_vm<11>(); break;
+        case 12: wait_vm<12>(); break; case 13: wait_vm<13>(); break; case 14: wait_vm<14>(); break; default: wait_vm<15>(); break;
+    }
+}
+// 16-byte load the compiler does not count (it would drain the DMA queue at the first use): completion by the caller's wait_vm_n
+__device__ __forceinline__ void gload16(uint4& dst, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory"); }
+
+__device__ __forceinline__ void gload4(float& dst, const void* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory"); }
+
+template <int AUX, bool GELU2, bool CS>        // AUX: BF_AUX_*; GELU2: second output gelu(value); CS: column scale / shift and per-row-group factor
+__global__ void __launch_bounds__(512) stream_gemm_kernel(StreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* Bres = reinterpret_cast<bf16*>(smem);                  // KS chunks [128 n][64 k], swizzled like every KC tile (lds_off)
+    bf16* ring = Bres + (size_t)a.KS * CHUNK;                    // NSLOT chunks [256 m][64 k]
+    const int KS = a.KS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                     // 4 x 2 waves, 64 x 64 outputs each
+
+    // ---- teams: the nb workgroups of a team hold the nb column blocks and sweep the SAME row tiles at the same time, all on one XCD
+    // (label = blockIdx % 8 under round-robin placement; speed only) -- a chunk of A is fetched from HBM once and the rest of the team
+    // finds it in that XCD's L2.  Row tiles are dealt evenly to the 8 * (workgroups per XCD / nb) teams.
+    const int xl = blockIdx.x & 7, j = blockIdx.x >> 3, wpx = gridDim.x >> 3;
+    const int tpx = wpx / a.nb;                       // teams per XCD (host guarantees >= 1)
+    if (j >= tpx * a.nb) return;
+    const int team = xl * tpx + j / a.nb, nteams = 8 * tpx;
+    const int c_nb = j % a.nb;
+    const int t_beg = (int)((long)a.mt * team / nteams), t_end = (int)((long)a.mt * (team + 1) / nteams);
+    if (t_beg >= t_end) return;
+    const int total_steps = (t_end - t_beg) * KS;
+
+    // ---- DMA geometry: piece p = rows 8p .. 8p+7 of a chunk; lane -> row 8p + (lane >> 3), LDS chunk (lane & 7) = global chunk
+    // (lane & 7) ^ ((row >> 1) & 7) of that row (lds_off<bf16, false, 64>).  A chunk: 32 pieces, 4 per wave; W chunk: 16, 2 per wave.
+    long roffA[4], roffB[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int r = 8 * (wave * 4 + t) + (lane >> 3);
+        roffA[t] = (long)r * a.lda + 8 * ((lane & 7) ^ ((r >> 1) & 7));
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int r = 8 * (wave * 2 + t) + (lane >> 3);
+        roffB[t] = (long)r * a.ldw + 8 * ((lane & 7) ^ ((r >> 1) & 7));
+    }
+    const unsigned lds0 = lds_addr(smem);
+    const unsigned ldsB = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 2048u);                                   // this wave's two pieces inside a W chunk
+    const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)KS * (unsigned)(CHUNK * 2) + (unsigned)wave * 4096u);   // ... four pieces inside an A chunk
+
+    int issued = 0;                                  // vector-memory operations this wave has issued so far (DMA, loads, stores)
+    {   // the resident column block
+        const bf16* w0 = a.W + (long)c_nb * BNB * a.ldw;
+        for (int kb = 0; kb < KS; ++kb) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) glds16(w0 + roffB[t] + kb * BK, ldsB + (unsigned)kb * (unsigned)(CHUNK * 2) + t * 1024u);
+        }
+        issued += 2 * KS;
+    }
+
+    // ---- DMA issue cursor (one chunk in front of the compute loop, across tile boundaries)
+    int i_ks = 0, i_left = total_steps, i_slot = 0;
+    const bf16* i_row = a.A + (long)((a.dbg & 2) ? 0 : t_beg) * BM * a.lda;
+    auto issue_A = [&]() {
+        const unsigned dst = ldsA + (unsigned)i_slot * (unsigned)(ACHUNK * 2);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) glds16(i_row + roffA[t] + i_ks * BK, dst + t * 1024u);
+        issued += 4;
+        i_slot ^= 1;
+        --i_left;
+        if (++i_ks == KS) { i_ks = 0; if (!(a.dbg & 2)) i_row += (long)BM * a.lda; }
+    };
+
+    // ---- epilogue constants: after the lane-row exchange a lane owns 8 consecutive columns of each of its two 32-column halves
+    const int li = lane & 15, lg = lane >> 4;
+    const int c8 = wn * 64 + (lg & 1) * 16 + (lg >> 1) * 8;       // + 32 * pp
+    float e_bias[2][8], e_cs[2][CS ? 8 : 1], e_ch[2][CS ? 8 : 1];
+    {   // plain loads, forced complete here: inside the tile loop a pending compiler-visible load would make hipcc drain the DMA queue at its use
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int n = c_nb * BNB + c8 + 32 * pp + q;
+                e_bias[pp][q] = a.bias ? a.bias[n] : 0.f;
+                if constexpr (CS) { e_cs[pp][q] = a.colscale ? a.colscale[n] : 1.f; e_ch[pp][q] = a.colscale ? a.colshift[n] : 0.f; }
+            }
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                asm volatile("" : "+v"(e_bias[pp][q]));
+                if constexpr (CS) { asm volatile("" : "+v"(e_cs[pp][q])); asm volatile("" : "+v"(e_ch[pp][q])); }
+            }
+    }
+
+    issue_A();
+    int mark = issued;                               // `issued` right after the chunk of the step being waited for went out
+
+    f32x4 acc[4][4];
+    uint4 auxr[4][2];
+    float rsr[4] = {1.f, 1.f, 1.f, 1.f};
+    const bool has_rs = CS && a.rowscale != nullptr;
+    int aux_mark = 0;
+    int slot = 0;
+    for (int t = t_beg; t < t_end; ++t) {
+        const int m0 = t * BM;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < KS; ++ks) {
+            if (!(a.dbg & 1)) wait_vm_n(issued - mark);      // chunk of this step (and everything older, the resident block included) has landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();            // ... for every wave; and nobody reads the previous step's slot any more
+            if (ks == 0) {                           // this tile's residual / gelu' operand and row factors: issued BEFORE the younger DMAs, in
+                if constexpr (AUX != BF_AUX_NONE) {  // flight for the whole tile (a load issued in the epilogue would wait for every older DMA)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int pp = 0; pp < 2; ++pp)
+                            gload16(auxr[i][pp], a.aux + (long)(m0 + wm * 64 + i * 16 + li) * a.ld_aux + c_nb * BNB + c8 + 32 * pp);
+                    issued += 8;
+                }
+                if (has_rs) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gload4(rsr[i], a.rowscale + (m0 + wm * 64 + i * 16 + li) / a.rpg);
+                    issued += 4;
+                }
+                aux_mark = issued;
+            }
+            if (i_left > 0 && !(a.dbg & 32)) issue_A();      // into the slot the previous step read
+            mark = issued;
+            const bf16* cA = ring + (size_t)slot * ACHUNK;
+            const bf16* cB = Bres + (size_t)ks * CHUNK;
+            if (!(a.dbg & 4))
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 32) {
+                bf16x8 fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i] = frag_bf16<false, BK>(cA, wm * 64 + i * 16, kk, lane);
+#pragma unroll
+                for (int jn = 0; jn < 4; ++jn) fb[jn] = frag_bf16<false, BK>(cB, wn * 64 + jn * 16, kk, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < 4; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[jn], fa[i], acc[i][jn], 0, 0, 0);
+            }
+            slot ^= 1;
+        }
+        // ---- epilogue of the tile, from registers.  acc[i][jn]: row 16i + li, columns 16jn + 4lg .. +3.  After exchanging the odd lane
+        // rows of tile 2pp with the even lane rows of tile 2pp + 1 a lane holds 8 consecutive columns at c8 + 32pp.
+        if (AUX != BF_AUX_NONE || has_rs) {
+            wait_vm_n(issued - aux_mark);
+            if constexpr (AUX != BF_AUX_NONE) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp) asm volatile("" : "+v"(auxr[i][pp].x), "+v"(auxr[i][pp].y), "+v"(auxr[i][pp].z), "+v"(auxr[i][pp].w));
+            }
+            if constexpr (CS) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(rsr[i]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + li;
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                    const u32x2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][2 * pp][r]), __float_as_uint(acc[i][2 * pp + 1][r]), false, false);
+                    v[r] = __uint_as_float(sw[0]); v[4 + r] = __uint_as_float(sw[1]);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    v[q] += e_bias[pp][q];
+                    if constexpr (CS) v[q] = (v[q] * e_cs[pp][q] + e_ch[pp][q]) * (has_rs ? rsr[i] : 1.f);
+                }
+                if constexpr (AUX != BF_AUX_NONE) {
+                    const bf16x8 ax = __builtin_bit_cast(bf16x8, auxr[i][pp]);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = AUX == BF_AUX_ADD ? v[q] + (float)ax[q] : v[q] * dgelu_f((float)ax[q]);
+                }
+                bf16x8 o;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o[q] = (bf16)v[q];
+                const long off = (long)m * a.ldc + c_nb * BNB + c8 + 32 * pp;
+                if (a.dbg & 16) asm volatile("" :: "v"(o)); else
+                if (!(a.dbg & 8)) *reinterpret_cast<bf16x8*>(a.C + off) = o;
+                if constexpr (GELU2) {
+                    bf16x8 g8;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) g8[q] = (bf16)gelu_f(v[q]);
+                    *reinterpret_cast<bf16x8*>(a.gelu_out + off) = g8;
+                }
+            }
+        }
+        issued += GELU2 ? 16 : 8;
+    }
+}
+
+int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+
+int num_cus() {
+    static const int n = []() {
+        int dev = 0; hipDeviceProp_t p;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess || p.multiProcessorCount < 8) return 256;
+        return p.multiProcessorCount;
+    }();
+    return n;
+}
+
+}  // namespace
+
+// 0 = handled, 1 = shape / feature not covered (the caller's tile kernel runs), < 0 = error
+int bf_gemm_stream_try(int M, int N, int K, const bf_operand* A, const bf_operand* B, const bf_epilogue* E, hipStream_t st) {
+    static const int enabled = env_int("BF_GEMM_STREAM", 1);
+    if (!enabled) return 1;
+    if (A->layout != BF_LAY_KC || B->layout != BF_LAY_KC || A->pro != BF_PRO_NONE || B->pro != BF_PRO_NONE) return 1;
+    if (A->gw > 0 || A->seglen > 0 || B->gw > 0 || B->seglen > 0 || E->gw > 0 || E->seglen > 0) return 1;
+    if (E->out_mode != BF_OUT_STORE || E->colsum) return 1;
+    if (M % BM || N % BNB || K % BK || K < 4 * BK || K > 6 * BK) return 1;
+    if (A->ld % 8 || B->ld % 8 || E->ldc % 8 || (E->aux_mode != BF_AUX_NONE && E->ld_aux % 8)) return 1;
+    if (((uintptr_t)A->p | (uintptr_t)B->p | (uintptr_t)E->c | (uintptr_t)E->aux | (uintptr_t)E->gelu_out) & 15) return 1;
+    if (E->gelu_out && E->aux_mode != BF_AUX_NONE) return 1;
+    if (E->colscale && !E->colshift) return 1;
+    StreamArgs a;
+    a.A = (const bf16*)A->p; a.lda = A->ld; a.W = (const bf16*)B->p; a.ldw = B->ld; a.C = (bf16*)E->c; a.ldc = E->ldc;
+    a.bias = E->bias; a.colscale = E->colscale; a.colshift = E->colshift; a.rowscale = E->rowscale; a.rpg = E->rows_per_group > 0 ? E->rows_per_group : 1;
+    a.aux_mode = E->aux_mode; a.aux = (const bf16*)E->aux; a.ld_aux = E->ld_aux; a.gelu_out = (bf16*)E->gelu_out;
+    a.KS = K / BK; a.mt = M / BM; a.nb = N / BNB;
+    static const int dbg = env_int("BF_STREAM_DEBUG", 0);
+    a.dbg = dbg;
+    const int grid = (num_cus() / 8) * 8;
+    if (a.nb > grid / 8) return 1;                    // a team (one workgroup per column block) must fit one XCD
+    const int lds_bytes = a.KS * CHUNK * 2 + NSLOT * ACHUNK * 2;
+    static thread_local char pname[64];
+    snprintf(pname, sizeof(pname), "stream_gemm<%s>", E->gelu_out ? "gelu2" : E->aux_mode == BF_AUX_ADD ? "add" : E->aux_mode == BF_AUX_DGELU ? "dgelu" : "plain");
+    BfProfScope prof(st, pname, 2.0 * M * N * K, ((double)M * K + (double)N * K + (double)M * N * (E->gelu_out ? 2 : 1) + (E->aux_mode != BF_AUX_NONE ? (double)M * N : 0.0)) * 2.0);
+#define BF_STREAM_GO(AUXM, G2, CSF)                                                                                                       \
+    do {                                                                                                                                \
+        static bool attr_done = false;                                                                                                  \
+        if (!attr_done) {                                                                                                               \
+            hipError_t e_ = hipFuncSetAttribute((const void*)stream_gemm_kernel<AUXM, G2, CSF>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * CHUNK * 2 + NSLOT * ACHUNK * 2); \
+            if (e_ != hipSuccess) return bf_fail(e_, __FILE__, __LINE__);                                                               \
+            attr_done = true;                                                                                                           \
+        }                                                                                                                               \
+        hipLaunchKernelGGL((stream_gemm_kernel<AUXM, G2, CSF>), dim3(grid), dim3(512), lds_bytes, st, a);                                    \
+    } while (0)
+    const bool cs = E->colscale != nullptr || E->rowscale != nullptr;
+    if (E->gelu_out && !cs) BF_STREAM_GO(BF_AUX_NONE, true, false);
+    else if (E->gelu_out) return 1;
+    else if (E->aux_mode == BF_AUX_ADD && cs) BF_STREAM_GO(BF_AUX_ADD, false, true);
+    else if (E->aux_mode == BF_AUX_ADD) BF_STREAM_GO(BF_AUX_ADD, false, false);
+    else if (E->aux_mode == BF_AUX_DGELU && !cs) BF_STREAM_GO(BF_AUX_DGELU, false, false);
+    else if (E->aux_mode == BF_AUX_DGELU) return 1;
+    else if (cs) return 1;
+    else BF_STREAM_GO(BF_AUX_NONE, false, false);
+#undef BF_STREAM_GO
+    BF_CHECK_LAUNCH();
+    return 0;
+}

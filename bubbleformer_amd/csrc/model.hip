@@ -405,6 +405,7 @@ struct SpatialSaved {
 // transient scratch (backward is the larger user)
 struct Scratch {
     float *G, *csum, *zeros, *ones, *wg, *attn_ws, *attn_ws2, *in_ws, *in_ws2, *in_ws3;   // wg: prepared-layout weight gradient scratch
+    float* tokred_ws; int64_t tokred_floats;      // slabs of the token-reduction (weight-gradient) GEMM
     static constexpr long ATTN_WS_FLOATS = 1024L * (4 * 128 + 32 * 16 + 16);
     void *t1, *t3, *t4, *t1b;
     void *s1, *e5, *e6, *e7;     // [N][E] each: s1 feeds side-stream GEMMs only; e5..e7 keep side-stream inputs from being recycled within a stage
@@ -420,6 +421,8 @@ struct Scratch {
         zeros = a.f32((size_t)4 * d.E);
         ones = a.f32((size_t)4 * d.E);
         wg = a.f32(wgn);
+        tokred_floats = bf_gemm_tokred_ws_floats(4 * d.E, d.E, d.N);
+        tokred_ws = a.f32((size_t)tokred_floats);
         attn_ws = a.f32(ATTN_WS_FLOATS);
         attn_ws2 = a.f32(ATTN_WS_FLOATS);       // second axial pass: both passes' rows are reduced together at the end of the stage
         {   // InstanceNorm workspace: the trunk (S tokens x E) and every embed / debed resolution (S * 4^i tokens x E/4)
@@ -523,8 +526,11 @@ int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on,
                 const float* alpha, const float* mc, float* dW, float* dbias, float* dnb, float* dgamma, float* dlo, float* dhi,
                 void* don, hipStream_t st, Fork& fk, const InFuse* fu = nullptr) {
     TRY(fk.run([=](hipStream_t ss) -> int {           // parameter-gradient side: memset, G GEMM, finalize
-        ZERO_ON(ss, sc.G, (size_t)((char*)sc.csum - (char*)sc.G) + (size_t)d.E * 4);     // G and csum are adjacent in the arena: one memset
-        {   // G[n][k] = sum_m dout[m][n] * on[m][k]; `on` is the normalised operand the forward saved
+        // G[n][k] = sum_m dout[m][n] * on[m][k]; `on` is the normalised operand the forward saved; dbeta = colsum(dout) from the same pass
+        const int trc = bf_gemm_tokred(d.dtype, d.E, d.E, d.N, dout, d.E, on, d.E, sc.G, 0, sc.csum, sc.tokred_ws, sc.tokred_floats, ss);
+        if (trc < 0) return trc;
+        if (trc == 1) {
+            ZERO_ON(ss, sc.G, (size_t)((char*)sc.csum - (char*)sc.G) + (size_t)d.E * 4);     // G and csum are adjacent in the arena: one memset
             bf_operand A = op_plain(dout, d.E, BF_LAY_XC);
             bf_operand Bo = op_plain(on, d.E, BF_LAY_XC);
             bf_epilogue e = epi_atomic(sc.G, d.E);
@@ -559,6 +565,10 @@ int linear_bwd(const D& d, const Scratch& sc, const void* dy, int Nout, const vo
             pro = BF_PRO_NONE;
         }
         bf_operand Bo = op_plain(xo, Kin, BF_LAY_XC);
+        if (pro == BF_PRO_NONE) {
+            const int trc = bf_gemm_tokred(d.dtype, Nout, Kin, d.N, dy, Nout, xo, Kin, dW, 1, db, sc.tokred_ws, sc.tokred_floats, ss);
+            if (trc <= 0) return trc;
+        }
         if (pro != BF_PRO_NONE) op_affine(Bo, pro, xsc, xsh, d.S, Kin);
         bf_epilogue e = epi_atomic(dW, Kin);
         e.colsum = db;                       // bias gradient = colsum(dy), fused into the same pass over dy

@@ -22,6 +22,20 @@ def gemm(dtype, M, N, K, A: L.Operand, B: L.Operand, E: L.Epilogue, splitk=1):
     L.check(L.lib().bf_gemm(_dt(dtype), M, N, K, C.byref(A), C.byref(B), C.byref(E), splitk, _stream()), "bf_gemm")
 
 
+def gemm_tokred(dy, x, out, accumulate=False, colsum=None):
+    """Weight-gradient GEMM out[Nout][Kin] (+)= dy^T x through bf_gemm_tokred; returns False when the shape is not covered."""
+    M, Nout = dy.shape
+    Kin = x.shape[1]
+    n = L.lib().bf_gemm_tokred_ws_floats(Nout, Kin, M)
+    ws = torch.empty(n, dtype=torch.float32, device=x.device)
+    rc = L.lib().bf_gemm_tokred(_dt(x.dtype), Nout, Kin, M, _p(dy), dy.stride(0), _p(x), x.stride(0), _p(out), int(accumulate), _p(colsum),
+                                _p(ws), n, _stream())
+    if rc == 1:
+        return False
+    L.check(rc, "bf_gemm_tokred")
+    return True
+
+
 def in_stats(x, frames, S, Cc, w, b, g=None, gdiv=1, gb=None):
     dev = x.device
     mean, rstd, sc, sh = (torch.empty(frames, Cc, dtype=torch.float32, device=dev) for _ in range(4))

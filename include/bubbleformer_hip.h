@@ -20,8 +20,9 @@
  *                              layers/attention.py:78,121,210,299; linear_layers.py:25;
  *                              layers/patching.py:36-44,92-100 (stages with C >= 8)
  *   bf_in_stats / bf_in_bwd .. nn.InstanceNorm2d(affine): layers/attention.py:77,120,208,298,316
- *   bf_attn_temporal_* ....... AttentionBlock.forward attention core: layers/attention.py:80-119
- *   bf_attn_axial_* .......... AxialAttentionBlock.forward attention core: layers/attention.py:212-297
+ *   bf_gemm_tokred ........... weight gradients of the same layers (autograd); bf_gemm_inbwd_frames: their data gradient + InstanceNorm backward
+ *   bf_attn_fwd / bf_attn_bwd  AttentionBlock.forward attention core: layers/attention.py:80-119 (and each axial pass)
+ *   bf_attn_axial_fwd / bf_attn_axial_norm_fwd  AxialAttentionBlock.forward attention core: layers/attention.py:212-297
  *   bf_embed_first_* ......... HMLPEmbed stage 0 (Conv2d k2s2 on NCHW input): layers/patching.py:36-44
  *   bf_debed_last_* .......... HMLPDebed last stage + LpLoss: layers/patching.py:92-100, utils/losses.py:67-94
  *   bf_film_* ................ FiLMMLP.forward: layers/linear_layers.py:63-77
@@ -103,6 +104,16 @@ int bf_gemm(int dtype, int M, int N, int K, const bf_operand* A, const bf_operan
 int bf_gemm_inbwd_frames(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, const void* x,
                          const void* add, void* out, int S, const float* mean, const float* rstd, const float* w, float* ws,
                          bf_stream_t stream);
+
+/* Token-reduction GEMM (weight gradient of a 1x1 conv / Linear: autograd of layers/attention.py:78,121,210,299, linear_layers.py:18-25):
+ *   out[Nout][Kin] = (accumulate ? out : 0) + sum_tok dy[tok][Nout] * x[tok][Kin],  colsum[Nout] likewise + sum_tok dy[tok][:]  (optional)
+ * dy [M][ldy], x [M][ldx] token-major bf16.  Few long token slices, one 128 x 128 tile x slice per workgroup, partial tiles to fp32
+ * slabs in `ws` (bf_gemm_tokred_ws_floats), summed in slice order by a second launch: bit-reproducible, no float atomics.
+ * Returns 0 when done, 1 when the shape is not covered (bf16, Nout % 128 = Kin % 128 = M % 64 = 0): the caller then uses bf_gemm's
+ * outer-contiguous form; < 0 on error. */
+int bf_gemm_tokred(int dtype, int Nout, int Kin, int64_t M, const void* dy, int64_t ldy, const void* x, int64_t ldx, float* out,
+                   int accumulate, float* colsum, float* ws, int64_t ws_floats, bf_stream_t stream);
+int64_t bf_gemm_tokred_ws_floats(int Nout, int Kin, int64_t M);
 
 /* ---------------------------------------------------------------- kernel-level entry points (unit-testable) */
 

@@ -75,6 +75,87 @@ def test_gemm_dW_layout_tn_splitk_prologue(K, dtype, splitk):
     assert _rel(out, ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("M,N,K_", [(256 * 3, 128 * 5, 384), (256 * 20, 1152, 384), (256 * 5, 384, 256), (256 * 9, 256, 320), (18432, 1536, 384)])
+@pytest.mark.parametrize("variant", ["plain", "gelu2", "add_cs", "add", "dgelu"])
+def test_gemm_stream_weight_stationary(K, M, N, K_, variant):
+    """The persistent weight-stationary LDS-DMA kernel (gemm_stream.hip) takes these bf16 shapes: every epilogue variant against fp32
+    torch on the same bf16 operands; runs that cross column blocks (block reload), 4 / 5 / 6 K-steps, one and many tiles per workgroup."""
+    from bubbleformer_amd import _lib as L
+    if variant != "plain" and M == 18432:
+        pytest.skip("full-size shape once")
+    dt = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(5)
+    a = torch.randn(M, K_, device="cuda", generator=g).to(dt)
+    w = (torch.randn(N, K_, device="cuda", generator=g) * 0.1).to(dt)
+    bias = torch.randn(N, device="cuda", generator=g)
+    aux = torch.randn(M, N, device="cuda", generator=g).to(dt)
+    c = torch.full((M, N), float("nan"), device="cuda", dtype=dt)
+    ref = a.float() @ w.float().t() + bias
+    import ctypes, json
+    h = L.lib()
+    h.bf_prof_enable(1)
+    if variant == "plain":
+        K.gemm(dt, M, N, K_, K.operand(a, K_), K.operand(w, K_), K.epilogue(c, N, bias=bias))
+    elif variant == "gelu2":
+        c2 = torch.full((M, N), float("nan"), device="cuda", dtype=dt)
+        K.gemm(dt, M, N, K_, K.operand(a, K_), K.operand(w, K_), K.epilogue(c, N, bias=bias, gelu_out=c2))
+        assert _rel(c2.float(), torch.nn.functional.gelu(c.float())) < 6e-3
+    elif variant == "add_cs":
+        cs = torch.randn(N, device="cuda", generator=g); ch = torch.randn(N, device="cuda", generator=g)
+        rpg = 48
+        rs = torch.randn((M + rpg - 1) // rpg, device="cuda", generator=g)
+        K.gemm(dt, M, N, K_, K.operand(a, K_), K.operand(w, K_),
+               K.epilogue(c, N, bias=bias, colscale=cs, colshift=ch, aux_mode=L.BF_AUX_ADD, aux=aux, ld_aux=N, rowscale=rs, rows_per_group=rpg))
+        ref = (ref * cs + ch) * rs.repeat_interleave(rpg)[:M, None] + aux.float()
+    elif variant == "add":
+        K.gemm(dt, M, N, K_, K.operand(a, K_), K.operand(w, K_), K.epilogue(c, N, bias=bias, aux_mode=L.BF_AUX_ADD, aux=aux, ld_aux=N))
+        ref = ref + aux.float()
+    else:
+        K.gemm(dt, M, N, K_, K.operand(a, K_), K.operand(w, K_), K.epilogue(c, N, bias=bias, aux_mode=L.BF_AUX_DGELU, aux=aux, ld_aux=N))
+        x = aux.float().requires_grad_(True)
+        torch.nn.functional.gelu(x).sum().backward()
+        ref = ref * x.grad
+    torch.cuda.synchronize()
+    buf = ctypes.create_string_buffer(1 << 14)
+    h.bf_prof_report(buf, len(buf))
+    h.bf_prof_enable(0)
+    assert any(k.startswith("stream_gemm") for k in json.loads(buf.value.decode())), "the streaming kernel did not take this shape"
+    assert torch.isfinite(c.float()).all()
+    assert _rel(c.float(), ref) < 4e-3            # bf16 output rounding (2^-9 relative per element)
+    # each output element against its own scale: a misplaced 8-column group or row shows up as O(1) errors somewhere
+    assert float(((c.float() - ref).abs() / (ref.abs() + 0.05 * ref.abs().mean())).max()) < 0.05
+
+
+@pytest.mark.parametrize("Nout,Kin,M,with_cs", [(128, 128, 64, True), (384, 128, 64 * 7, True), (256, 384, 64 * 13, False),
+                                                 (1152, 384, 2304, True)])
+def test_gemm_tokred_slabs_match_fp64_and_are_bit_reproducible(K, Nout, Kin, M, with_cs):
+    """Weight-gradient GEMM (LDS-DMA ring, token slices, slab reduction): out (+)= dy^T x and colsum(dy) against fp64; every slice
+    count that the environment can select is exercised through odd step counts; two runs are bit-identical (no float atomics)."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    dy = torch.randn(M, Nout, device="cuda", generator=g).bfloat16()
+    x = torch.randn(M, Kin, device="cuda", generator=g).bfloat16()
+    base = torch.randn(Nout, Kin, device="cuda", generator=g)
+    cs0 = torch.randn(Nout, device="cuda", generator=g)
+    outs = []
+    for rep in range(2):
+        out = base.clone()
+        cs = cs0.clone() if with_cs else None
+        assert K.gemm_tokred(dy, x, out, accumulate=True, colsum=cs)
+        outs.append((out, cs))
+    ref = base.double() + dy.double().t() @ x.double()
+    assert _rel(outs[0][0], ref) < 2e-6
+    assert torch.equal(outs[0][0], outs[1][0])
+    if with_cs:
+        assert _rel(outs[0][1], cs0.double() + dy.double().sum(0)) < 2e-6
+        assert torch.equal(outs[0][1], outs[1][1])
+    out = torch.full((Nout, Kin), 7.0, device="cuda")          # accumulate = 0 overwrites
+    cs = torch.full((Nout,), 7.0, device="cuda")
+    assert K.gemm_tokred(dy, x, out, accumulate=False, colsum=cs)
+    assert _rel(out, dy.double().t() @ x.double()) < 2e-6 and _rel(cs, dy.double().sum(0)) < 2e-6
+    # shapes it does not take are declined, not mangled
+    assert not K.gemm_tokred(dy[:, :120].contiguous(), x, torch.zeros(120, Kin, device="cuda"))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_patch_gather_and_scatter(K, dtype):
     """k2s2 conv as a patch-gather GEMM and k2s2 transposed conv as a scatter-store GEMM vs torch conv ops."""
