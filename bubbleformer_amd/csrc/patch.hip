@@ -60,9 +60,27 @@ __global__ void __launch_bounds__(NT) col2im_kernel(const T* __restrict__ g, flo
     }
 }
 
+// ---------------------------------------------------------------------------- loss partial sums, order-independent
+// The relative-L2 sums of a (frame, channel) come from dozens of workgroups.  Added as floats they depend on arrival order, and that
+// last-bit noise reaches coef = 1 / (F sqrt(num) sqrt(den)), i.e. EVERY element of the loss gradient: in bf16 mode a few rounding flips
+// there cascade through the K = 384 contractions of the backward until ~12 % of a gradient tensor's elements differ by an ulp between
+// two runs on identical inputs (1.3 % in d(clip); measured).  So the partial sums are added as 64-bit fixed-point integers (2^-32
+// resolution: exact, associative); lossbuf is [frames][Co][2] int64.  A non-finite partial poisons the sum (finalize returns NaN).
+constexpr double LOSS_FX = 4294967296.0;                 // 2^32
+constexpr long long LOSS_POISON = 1LL << 61;
+__device__ __forceinline__ void loss_accum(float* lossbuf, long slot, float v) {
+    const double d = (double)v * LOSS_FX;
+    const long long q = (d == d && fabs(d) < 4.0e18) ? __double2ll_rn(d) : LOSS_POISON;
+    atomicAdd(reinterpret_cast<unsigned long long*>(lossbuf) + slot, (unsigned long long)q);
+}
+__device__ __forceinline__ float loss_read(const float* lossbuf, long slot) {
+    const long long q = reinterpret_cast<const long long*>(lossbuf)[slot];
+    return (q >= LOSS_POISON / 2 || q < 0) ? __builtin_nanf("") : (float)((double)q / LOSS_FX);
+}
+
 // ---------------------------------------------------------------------------- pm2nchw + loss partials
 // pm: [P][Np] fp32, n = co*4 + ky*2 + kx; pred: [F][Co][H][W]; grid (blocks over h*w pixels, F)
-// lossbuf[f][co][0] += sum (pred - y)^2, [1] += sum y^2
+// lossbuf[f][co][0] += sum (pred - y)^2, [1] += sum y^2   (int64 fixed point, see loss_accum)
 __global__ void __launch_bounds__(NT) pm2nchw_kernel(const float* __restrict__ pm, float* __restrict__ pred, const float* __restrict__ y,
                                                     float* __restrict__ lossbuf, int Co, int h, int w, int Np) {
     __shared__ float red[NT / 64][2];
@@ -92,8 +110,8 @@ __global__ void __launch_bounds__(NT) pm2nchw_kernel(const float* __restrict__ p
             if (threadIdx.x == 0) {
                 float a = 0.f, b = 0.f;
                 for (int i = 0; i < NT / 64; ++i) { a += red[i][0]; b += red[i][1]; }
-                atomicAdd(lossbuf + ((long)f * Co + co) * 2, a);
-                atomicAdd(lossbuf + ((long)f * Co + co) * 2 + 1, b);
+                loss_accum(lossbuf, ((long)f * Co + co) * 2, a);
+                loss_accum(lossbuf, ((long)f * Co + co) * 2 + 1, b);
             }
         }
     }
@@ -170,8 +188,8 @@ __global__ void __launch_bounds__(NT) debed_last_kernel(const bf16* __restrict__
 #pragma unroll
         for (int m = 8; m >= 1; m >>= 1) { num += __shfl_xor(num, m, 64); den += __shfl_xor(den, m, 64); }
         if (li == 0 && live) {
-            atomicAdd(lossbuf + ((long)f * Co + lg) * 2, num);
-            atomicAdd(lossbuf + ((long)f * Co + lg) * 2 + 1, den);
+            loss_accum(lossbuf, ((long)f * Co + lg) * 2, num);
+            loss_accum(lossbuf, ((long)f * Co + lg) * 2 + 1, den);
         }
     }
 }
@@ -274,7 +292,7 @@ __global__ void lploss_finalize_kernel(const float* __restrict__ lossbuf, int F,
     __shared__ float red[NT];
     float acc = 0.f;
     for (int i = threadIdx.x; i < F * Co; i += NT) {
-        const float num = lossbuf[2 * i], den = lossbuf[2 * i + 1];
+        const float num = loss_read(lossbuf, 2 * i), den = loss_read(lossbuf, 2 * i + 1);
         acc += sqrtf(num) / sqrtf(den);
         if (coef) coef[i] = 1.0f / ((float)F * sqrtf(num) * sqrtf(den));
     }

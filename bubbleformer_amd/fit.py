@@ -63,7 +63,8 @@ def fit(model: torch.nn.Module, train_set, val_set=None, *, batch_size: int, max
     first_epoch = 0
     if resume_from is not None:
         ck = load_checkpoint(resume_from, model, step)
-        first_epoch = int(ck.get("epoch", -1)) + 1
+        # an epoch-less file (written by an older version, or by save_checkpoint outside fit) resumes at the epoch its step count implies
+        first_epoch = int(ck["epoch"]) + 1 if "epoch" in ck else int(ck.get("global_step", 0)) // max(per_epoch, 1)
     for epoch in range(first_epoch, max_epochs):
         model.train()
         losses = []
@@ -84,10 +85,7 @@ def fit(model: torch.nn.Module, train_set, val_set=None, *, batch_size: int, max
             if log is not None:
                 log({"epoch": epoch, "val_loss": hist["val_loss"][-1]})
         if checkpoint_path is not None and rank == 0:
-            save_checkpoint(checkpoint_path, model, hyper_parameters, norm, step)
-            ck = torch.load(checkpoint_path, weights_only=False)
-            ck["epoch"] = epoch
-            torch.save(ck, checkpoint_path)
+            save_checkpoint(checkpoint_path, model, hyper_parameters, norm, step, epoch=epoch)       # one atomic write
     return hist
 
 

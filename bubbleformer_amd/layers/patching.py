@@ -44,7 +44,7 @@ class HMLPEmbed(nn.Module):
     def tokens(self, x5: torch.Tensor, fluid=None, film_params=(), compute_dtype=None) -> torch.Tensor:
         """(B, T, C, H, W) -> (B, T, h, w, E) tokens, optionally FiLM-conditioned."""
         conv, inw, inb = self.stage_params()
-        dt = compute_dtype or self.compute_dtype or torch.bfloat16
+        dt = compute_dtype or self.compute_dtype or torch.float32
         return ops.embed(x5, fluid, dt, self.patch_size, self.embed_dim, conv, inw, inb, film_params)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

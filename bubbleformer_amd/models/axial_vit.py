@@ -1,8 +1,10 @@
 """SpaceTimeBlock, AViT and FiLMConditionedAViT (mirror of bubbleformer/models/axial_vit.py) on the HIP stages.
 
 Constructor signatures, sub-module names and ``state_dict`` keys are the reference's
-(axial_vit.py:23-46, 85-128, 173-215).  One extra keyword, ``compute_dtype`` (default torch.bfloat16; use
-torch.float32 for the exact-fp32 parity mode), selects the activation storage / MFMA type.
+(axial_vit.py:23-46, 85-128, 173-215).  One extra keyword, ``compute_dtype``, selects the activation storage / MFMA type: the default
+torch.float32 is the exact-fp32 parity mode (the reference trains in fp32: no ``precision=`` at scripts/train.py:158-172), so matching
+the reference is what a caller gets without asking; torch.bfloat16 is the opt-in throughput mode (what bench.py measures, as
+BASELINE configs[1] names bf16).
 """
 import numpy as np
 import torch
@@ -39,7 +41,7 @@ class SpaceTimeBlock(nn.Module):
 class _AxialBase(nn.Module):
     def _build(self, input_fields, output_fields, patch_size, embed_dim, num_heads, processor_blocks, drop_path, attn_scale,
                feat_scale, compute_dtype):
-        self.compute_dtype = compute_dtype if compute_dtype is not None else torch.bfloat16
+        self.compute_dtype = compute_dtype if compute_dtype is not None else torch.float32
         self.patch_size = patch_size
         self.embed = HMLPEmbed(patch_size=patch_size, in_channels=input_fields, embed_dim=embed_dim)
         self.dp = np.linspace(0, drop_path, processor_blocks)

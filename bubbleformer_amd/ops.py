@@ -49,17 +49,37 @@ def _dims_key(d: L.Dims):
     return tuple(getattr(d, n) for n, _ in L.Dims._fields_)
 
 
+_SCRATCH_BYTES = {}
+
+
 def scratch_for(d: L.Dims, device) -> torch.Tensor:
-    """One transient arena per (device, stream, problem shape); stage calls on a stream are ordered, so sharing is safe."""
-    key = (str(device), _stream(), _dims_key(d))
-    buf = _SCRATCH.get(key)
-    if buf is None:
+    """ONE transient arena per device, grown to the largest problem seen (a ragged last batch, a validation batch or another stream
+    do not pin further arenas): stage calls are stream-ordered and a stage never keeps scratch contents across calls, so every shape
+    can share it.  Two host threads driving two streams of one device concurrently must serialise their stage calls themselves, or set
+    BF_SCRATCH_PER_STREAM=1 (one arena per stream).  A HIP-graph capture finds the arena of its warm-up runs -- nothing is allocated
+    from the graph's private pool.  clear_scratch() releases everything."""
+    key = _dims_key(d)
+    n = _SCRATCH_BYTES.get(key)
+    if n is None:
         n = L.lib().bf_scratch_bytes(C.byref(d))
         if n < 0:
             L.check(-1, "bf_scratch_bytes")
+        _SCRATCH_BYTES[key] = n
+    slot = (str(device), _stream()) if os.environ.get("BF_SCRATCH_PER_STREAM") == "1" else str(device)
+    buf = _SCRATCH.get(slot)
+    if buf is None or buf.numel() < n:
+        if buf is not None:       # the library's side stream may still read the old arena: order it before the arena can be recycled
+            L.check(L.lib().bf_side_join(_stream()), "bf_side_join")
         buf = torch.empty(n, dtype=torch.uint8, device=device)
-        _SCRATCH[key] = buf
+        _SCRATCH[slot] = buf
     return buf
+
+
+def clear_scratch() -> None:
+    """Release the scratch arenas (after the work that used them has been synchronised)."""
+    if _SCRATCH:
+        L.check(L.lib().bf_side_join(_stream()), "bf_side_join")
+    _SCRATCH.clear()
 
 
 def _saved(nbytes: int, device, what: str) -> torch.Tensor:

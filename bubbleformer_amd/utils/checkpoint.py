@@ -7,6 +7,7 @@
 plus, for resuming the native training step, "optimizer_states" / "lr_schedulers" entries holding the flat AdamW / Lion moments
 and the scheduler position (Lightning stores its torch.optim state dicts under those keys; ours are flat buffers, so a checkpoint
 written here resumes here, while its "state_dict" loads anywhere the reference's does)."""
+import os
 from collections import OrderedDict
 from typing import Optional
 
@@ -30,7 +31,9 @@ def from_reference_state_dict(sd) -> "OrderedDict[str, torch.Tensor]":
 
 
 def save_checkpoint(path: str, model: torch.nn.Module, hyper_parameters: Optional[dict] = None, normalization_constants=None,
-                    train_step=None, global_step: Optional[int] = None) -> None:
+                    train_step=None, global_step: Optional[int] = None, epoch: Optional[int] = None) -> None:
+    """One torch.save into `path + ".tmp"`, then os.replace: a kill between two writes (the reference's use case is SLURM pre-emption,
+    scripts/train.py:36-67) can never leave a half-written or epoch-less file behind."""
     hp = dict(hyper_parameters or {})
     if normalization_constants is not None:
         hp["normalization_constants"] = normalization_constants
@@ -40,7 +43,11 @@ def save_checkpoint(path: str, model: torch.nn.Module, hyper_parameters: Optiona
         ckpt["optimizer_states"] = [{"name": train_step.optimizer, "step": train_step.step_no, "m": train_step.m.detach().cpu(),
                                      "v": None if train_step.v is None else train_step.v.detach().cpu()}]
         ckpt["lr_schedulers"] = [train_step.scheduler.state_dict()] if train_step.scheduler is not None else []
-    torch.save(ckpt, path)
+    if epoch is not None:
+        ckpt["epoch"] = int(epoch)
+    tmp = path + ".tmp"
+    torch.save(ckpt, tmp)
+    os.replace(tmp, path)
 
 
 def load_checkpoint(path: str, model: torch.nn.Module, train_step=None, map_location="cpu") -> dict:
@@ -65,4 +72,6 @@ def load_checkpoint(path: str, model: torch.nn.Module, train_step=None, map_loca
             train_step.v.copy_(st["v"])
         if train_step.scheduler is not None and ckpt.get("lr_schedulers"):
             train_step.scheduler.load_state_dict(ckpt["lr_schedulers"][0])
+    if train_step is not None and hasattr(train_step, "sync_from_rank0"):
+        train_step.sync_from_rank0()          # data parallel: every replica continues from rank 0's weights, moments and step count
     return ckpt

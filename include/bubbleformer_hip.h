@@ -176,6 +176,8 @@ void bf_debug_force_generic_attn(int on);
 
 int bf_im2col_nchw(int dtype, const float* x, void* out, int frames, int C, int H, int W, int Kp, bf_stream_t stream);
 int bf_col2im_nchw(int dtype, const void* g, float* dx, int frames, int C, int H, int W, int Kp, bf_stream_t stream);
+/* lossbuf (here, in bf_debed_last and bf_lploss_finalize): [frames][Co][2] 64-bit fixed-point sums (2^-32 units) of (pred - y)^2 and y^2,
+ * zeroed by the caller: integer adds are order independent, so the loss and its gradient are bit-reproducible run to run. */
 int bf_pm2nchw(const float* pm, float* pred, const float* y, float* lossbuf, int frames, int Co, int h, int w, int Np,
                bf_stream_t stream);
 /* Last HMLPDebed stage in one pass (layers/patching.py:92-104: InstanceNorm affine + GELU on the input rows, ConvTranspose2d(k=2,s=2)

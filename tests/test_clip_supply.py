@@ -160,7 +160,7 @@ def test_training_step_fed_from_the_device_store(tmp_path):
     d.normalize()
     store = d.device_store("cuda")
     model = get_model("filmavit", input_fields=4, output_fields=4, time_window=8, patch_size=16, embed_dim=96, num_heads=2, processor_blocks=2,
-                      num_fluid_params=9, drop_path=0.0).cuda().train()
+                      num_fluid_params=9, drop_path=0.0, compute_dtype=torch.bfloat16).cuda().train()
     step = TrainStep(model, lr=1e-3)
     x, y, c = store.gather([0, 30])
     assert x.shape == (2, 8, 4, 64, 64) and c.shape == (2, 9)

@@ -6,7 +6,8 @@ box's host cores on the same seeded inputs, plus size-independent properties at 
   configs[1]  16x192x192 clip (bench shape)           -> one full-resolution sample against the oracle (bf16 tolerances) and, in fp32
                                                          and bf16, against the reference's own statistics at that size;
                                                          bs 8: bit-identical reruns, per-sample independence of the batch
-  configs[3]  32x384x192 long-aspect clip (24x12 tokens, T = 32: the two-block attention paths at full width), bs 1, fp32
+  configs[3]  32x384x192 long-aspect clip (24x12 tokens, T = 32: the two-block attention paths at full width), bs 1, fp32 against the
+              oracle + reference statistics, bf16 (what BASELINE names) against the reference statistics; likewise transposed
   configs[4]  bs 1 inference: the forward captured in a HIP graph replays bit-identically; 3-step rollout on device
 fp32 tolerance: 1e-4 everywhere, as in tests/test_gpu_parity.py.  bf16 tolerances at FULL depth (12 blocks, E = 384): forward
 <= 8e-2, dx <= 2e-1, all parameter gradients together <= 1.5e-1, each family <= 0.9.  Yardstick (measured in the build
@@ -136,6 +137,42 @@ def test_config3_transposed_32x192x384_fp32():
     prod = _product(B, T, H, W, seed, torch.float32)
     _compare(prod, _oracle(B, T, H, W, seed, dtype=torch.float64), torch.float32)
     _against_reference("config3_32x192x384", prod, torch.float32)
+
+
+def test_config3_long_aspect_32x384x192_bf16():
+    """BASELINE names configs[3] "bf16": the throughput mode at 288-token frames takes paths no other full-width test touches -- the
+    two-kernel data gradient + sliced InstanceNorm backward inside the trunk (the whole-frame tile needs 144-token frames), the
+    two-block (L = 24, 32) MFMA attention at d = 64 x 6 heads, the streaming GEMMs at 9,216 tokens -- against the REFERENCE's own fp64
+    statistics at this size, bf16 tolerances of configs[0] / [1]."""
+    B, T, H, W, seed = 1, 32, 384, 192, 13
+    _against_reference("config3_32x384x192", _product(B, T, H, W, seed, torch.bfloat16), torch.bfloat16)
+
+
+def test_config3_transposed_32x192x384_bf16():
+    B, T, H, W, seed = 1, 32, 192, 384, 16
+    _against_reference("config3_32x192x384", _product(B, T, H, W, seed, torch.bfloat16), torch.bfloat16)
+
+
+def test_config1_weight_gradients_are_bit_reproducible():
+    """The weight-gradient GEMMs sum token slices into slabs and add the slabs in a fixed order (gemm_tokred.hip): two backward passes
+    on the same inputs give bit-identical gradients for every 1x1-conv / Linear weight and bias of the trunk (the split-K fp32 atomics
+    they replace did not), a bit-identical loss and d(clip) (the fused loss adds its partial sums as 64-bit integers: float adds there
+    used to flip ~12 % of every gradient tensor's bf16 elements between runs).  The remaining families (InstanceNorm / attention
+    parameter partial sums, patch-embedding weights through their atomic path) are compared to rounding."""
+    B, T, H, W, seed = 1, 16, 192, 192, 12
+    p1 = _product(B, T, H, W, seed, torch.bfloat16)
+    p2 = _product(B, T, H, W, seed, torch.bfloat16)
+    assert p1[1] == p2[1] and torch.equal(p1[0], p2[0]) and torch.equal(p1[2], p2[2])
+    g1, g2 = p1[3], p2[3]
+    exact = ("input_head.weight", "input_head.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
+    n_exact = 0
+    for k in g1:
+        if k.startswith("blocks.") and k.endswith(exact):
+            assert torch.equal(g1[k], g2[k]), k
+            n_exact += 1
+        elif not structurally_zero(k):
+            assert rel_l2(g1[k], g2[k]) < 1e-4, k
+    assert n_exact == 12 * (2 * 2 + 4)
 
 
 def test_config1_bench_size_properties():

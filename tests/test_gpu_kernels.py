@@ -366,6 +366,37 @@ def test_attention_mfma_matches_generic_and_fp32(L, d, heads, axis):
             assert float((a - b).norm()) / float(b.norm()) < (1e-1 if name == "dhscale" else 5e-2), (name, float((a - b).norm()) / float(b.norm()))
 
 
+@pytest.mark.parametrize("path", ["mfma_bf16", "generic_f32"])
+@pytest.mark.parametrize("L", [4, 6, 8, 12, 16, 24, 32])
+def test_attention_t5_buckets_bit_exact_on_device(K, path, L):
+    """The device copies of the T5 bucket function (csrc/attn_mfma.hip: t5b, csrc/attn.hip: t5_bucket) against the reference's integer
+    tables (tests/golden/relpos_tables.npz), read back through the attention forward itself: with q = k = 0 the scores are the bias
+    alone, with V = one-hot(key) the output row is the softmax row, and with emb[b] = log(1 + b) the ratio P[q][k] / P[q][q] is
+    1 + bucket(q - k) -- an integer, recovered exactly."""
+    import os
+    import numpy as np
+    from bubbleformer_amd import _lib as Lb
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "relpos_tables.npz"))
+    d, heads, nseq = 64, 1, 3
+    dt = torch.bfloat16 if path == "mfma_bf16" else torch.float32
+    qkv = torch.zeros(nseq * L, 3 * d, device="cuda", dtype=dt)
+    for s_ in range(nseq):
+        for l_ in range(L):
+            qkv[s_ * L + l_, 2 * d + l_] = 1.0                      # v[key l] = e_l
+    out = torch.empty(nseq * L, d, device="cuda", dtype=dt)
+    ones, zeros = torch.ones(d, device="cuda"), torch.zeros(d, device="cuda")
+    emb = torch.log1p(torch.arange(32, device="cuda", dtype=torch.float32)).view(32, 1).contiguous()
+    Lb.lib().bf_debug_force_generic_attn(0 if path == "mfma_bf16" else 1)
+    try:
+        K.attn_fwd(qkv, out, nseq, L, 1, L, 0, 1, heads, d, ones, zeros, ones, zeros, emb, None)
+    finally:
+        Lb.lib().bf_debug_force_generic_attn(0)
+    P = out.float().view(nseq, L, d)[:, :, :L]
+    got = torch.round(P / torch.diagonal(P, dim1=1, dim2=2).unsqueeze(-1) - 1.0).long().cpu().numpy()
+    for s_ in range(nseq):
+        assert np.array_equal(got[s_], z[f"bucket_{L}"]), (L, s_)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gelu_mlp_layer_standalone(dtype):
     """layers.GeluMLP used on its own (linear_layers.py:5-25): forward and every gradient vs torch in fp64."""
@@ -497,7 +528,7 @@ def test_debed_last_stage_one_pass(Ci, Co, h, w):
     wc = wc.bfloat16()
     y = torch.randn(Fr, Co, 2 * h, 2 * w, device="cuda", generator=g)
     pred = torch.full((Fr, Co, 2 * h, 2 * w), float("nan"), device="cuda")
-    lossbuf = torch.zeros(Fr, Co, 2, device="cuda")
+    lossbuf = torch.zeros(Fr, Co, 2, device="cuda", dtype=torch.int64)      # 64-bit fixed-point sums, 2^-32 units
     L.check(lib.bf_debed_last(1, _p(act), _p(sc), _p(sh), _p(wc), _p(pred), _p(y), _p(lossbuf), Fr, Ci, Co, h, w, 16, _stream()), "debed_last")
     a = torch.nn.functional.gelu(act.float().view(Fr, h * w, Ci) * sc[:, None] + sh[:, None]).bfloat16().float()
     a = a.view(Fr, h, w, Ci).permute(0, 3, 1, 2)
@@ -506,6 +537,7 @@ def test_debed_last_stage_one_pass(Ci, Co, h, w):
     assert _rel(pred, ref) < 2e-3
     num = (pred.double() - y.double()).pow(2).sum(dim=(-1, -2))
     den = y.double().pow(2).sum(dim=(-1, -2))
+    lossbuf = lossbuf.double() / 2.0 ** 32
     assert _rel(lossbuf[..., 0], num) < 1e-5 and _rel(lossbuf[..., 1], den) < 1e-5
     # without a target: prediction only
     pred2 = torch.zeros_like(pred)

@@ -82,6 +82,58 @@ def test_model_matches_reference_golden(name, dtype, fused_loss):
     assert (num / den) ** 0.5 < (1e-4 if dtype == torch.float32 else 8e-2), (num / den) ** 0.5
 
 
+@pytest.mark.parametrize("name", NAMES)
+def test_bf16_gradients_track_the_fp32_mode_per_family(name):
+    """The throughput mode (bf16 activations, bf16 residual stream) against the parity mode of the SAME kernels on the same inputs:
+    every parameter family must point the same way and have the same size -- cosine similarity > 0.99 and relative error < 0.25 per
+    family (a mis-scaled or sign-flipped small family -- rel_pos_emb, attn_scale_factor, q/k-norm -- fails this even when its norm is
+    tiny next to the projection weights').  Measured on the MI355X: cosine >= 0.9918, error <= 0.225 everywhere except the FiLM
+    network of the E = 96 / 18-tokens-per-sample model, whose gradient is a sum of 18 bf16-rounded per-token terms (cosine 0.94-0.97,
+    error 0.25-0.42): that family is held to 0.93 / 0.45."""
+    _, _, _, dx32, g32 = run_product(name, torch.float32, True)
+    _, _, _, dx16, g16 = run_product(name, torch.bfloat16, True)
+    bad = []
+    for k, a in g32.items():
+        if structurally_zero(k):
+            continue
+        a, b = a.double().flatten(), g16[k].double().flatten()
+        cos = float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-300))
+        err = float((a - b).norm() / a.norm().clamp_min(1e-300))
+        film = k.startswith("film_embed.")
+        if cos < (0.93 if film else 0.99) or err > (0.45 if film else 0.25):
+            bad.append((k, a.numel(), round(cos, 4), round(err, 3)))
+    assert not bad, bad
+    a, b = dx32.double().flatten(), dx16.double().flatten()
+    assert float((a @ b) / (a.norm() * b.norm())) > 0.995
+
+
+def test_bf16_training_trajectory_tracks_the_fp32_mode():
+    """Eight optimizer steps (fresh input each step, AdamW, cosine warm-up) in the throughput mode against the parity mode from the
+    same initial weights: the loss sequences stay within 2 % of each other and the weights within 2 % per large tensor -- the bf16
+    residual stream does not drift the optimisation (layer scales at the golden models' O(1) values)."""
+    from bubbleformer_amd.trainer import TrainStep
+    from bubbleformer_amd.utils import CosineWarmupLR
+    from oracle import weights as W
+    runs = {}
+    for dt in (torch.float32, torch.bfloat16):
+        spec, z, model = build_product_model("tiny_d64", dt)
+        model.train()
+        step = TrainStep(model, lr=1e-3, weight_decay=1e-2, scheduler=CosineWarmupLR(1e-3, 2, 20, 1e-6))
+        cfg = spec["cfg"]
+        losses = []
+        for i in range(8):
+            x = W.synthetic_clip(spec["B"], spec["T"], cfg["input_fields"], spec["H"], spec["W"], 1000 + i).cuda()
+            y = W.synthetic_clip(spec["B"], spec["T"], cfg["output_fields"], spec["H"], spec["W"], 2000 + i).cuda()
+            c = W.synthetic_fluid_params(spec["B"], cfg["num_fluid_params"], 3000 + i).cuda()
+            losses.append(float(step(x, c, y)))
+        runs[dt] = (losses, {k: p.detach().float().cpu().clone() for k, p in model.named_parameters()})
+    l32, l16 = runs[torch.float32][0], runs[torch.bfloat16][0]
+    assert max(abs(a - b) / abs(a) for a, b in zip(l32, l16)) < 2e-2, (l32, l16)
+    for k, p in runs[torch.float32][1].items():
+        if p.numel() >= 1024:
+            assert rel_l2(runs[torch.bfloat16][1][k], p) < 2e-2, k
+
+
 @pytest.mark.parametrize("name", ["tiny_d64", "tiny_p16"])
 def test_model_matches_oracle_run_on_this_box(name):
     """Same check against the oracle executed here (fp32, CPU) rather than against stored vectors."""

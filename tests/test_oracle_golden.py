@@ -64,6 +64,20 @@ def test_bucket_tables_bit_exact():
                                                13, 13, 13, 14, 14, 14, 14, 15, 15, 15, 15, 15]
 
 
+def test_product_layer_bucket_tables_bit_exact():
+    """The PRODUCT's host-side copy of the T5 table (bubbleformer_amd/layers/positional_encoding.py: bucket_matrix / forward) against the
+    reference's own integer tables and bias tensors (tests/golden/relpos_tables.npz) -- integer work: bit-exact.  The device copies
+    are checked the same way in tests/test_gpu_kernels.py::test_attention_t5_buckets_bit_exact_on_device."""
+    from bubbleformer_amd.layers import RelativePositionBias
+    z = np.load(f"{GOLDEN}/relpos_tables.npz")
+    rpb = RelativePositionBias(n_heads=z["emb"].shape[1])
+    with torch.no_grad():
+        rpb.relative_attention_bias.weight.copy_(torch.from_numpy(z["emb"]))
+    for L in (1, 2, 4, 6, 8, 12, 16, 24, 32, 40):
+        assert np.array_equal(rpb.bucket_matrix(L, L).numpy(), z[f"bucket_{L}"]), L
+        assert np.array_equal(rpb(L, L).detach().numpy(), z[f"bias_{L}"]), L
+
+
 def test_lploss_known_answer():
     z = np.load(f"{GOLDEN}/lploss.npz")
     a = torch.from_numpy(z["pred"]).requires_grad_(True)

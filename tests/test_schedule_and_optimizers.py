@@ -68,7 +68,7 @@ def test_train_step_with_lion_and_schedule_reduces_loss():
     from bubbleformer_amd.utils import CosineWarmupLR
     torch.manual_seed(0)
     cfg = dict(input_fields=4, output_fields=4, patch_size=4, embed_dim=64, num_heads=2, processor_blocks=2, num_fluid_params=9)
-    model = get_model("filmavit", time_window=4, drop_path=0.0, **cfg).cuda().train()
+    model = get_model("filmavit", time_window=4, drop_path=0.0, compute_dtype=torch.bfloat16, **cfg).cuda().train()
     sch = CosineWarmupLR(3e-4, warmup_iters=3, max_iters=40, eta_min=1e-6)
     step = TrainStep(model, lr=3e-4, weight_decay=0.1, optimizer="lion", scheduler=sch)
     x = torch.randn(2, 4, 4, 16, 16, device="cuda")

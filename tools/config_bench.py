@@ -18,7 +18,7 @@ dev = torch.device("cuda")
 
 def train_rate(B, T, H, W, steps=10, warm=3, cfg=CFG):
     torch.manual_seed(0)
-    m = get_model("filmavit", time_window=T, drop_path=0.2, **cfg).to(dev).train()
+    m = get_model("filmavit", time_window=T, drop_path=0.2, compute_dtype=torch.bfloat16, **cfg).to(dev).train()
     step = TrainStep(m)
     x = torch.randn(B, T, 4, H, W, device=dev)
     y = torch.randn(B, T, 4, H, W, device=dev)
@@ -36,7 +36,7 @@ def train_rate(B, T, H, W, steps=10, warm=3, cfg=CFG):
 
 def rollout_ms(T=16, H=192, W=192, steps=50):
     torch.manual_seed(0)
-    m = get_model("filmavit", time_window=T, drop_path=0.0, **CFG).to(dev).eval()
+    m = get_model("filmavit", time_window=T, drop_path=0.0, compute_dtype=torch.bfloat16, **CFG).to(dev).eval()
     x = torch.randn(1, T, 4, H, W, device=dev)
     c = torch.randn(1, 9, device=dev)
     out = {}
