@@ -135,13 +135,14 @@ def cpu_baseline(w, threads):
             while n < nmin or (time.perf_counter() - t0 < budget and n < nmax):
                 step()
                 n += 1
+                log(f"cpu baseline batch {bs}: step {n} at {time.perf_counter() - t0:.1f} s")
             dt = time.perf_counter() - t0
         return bs * n / dt, n
 
     unit = "samples/s" if w["kind"] == "train" else "steps/s"
     what = "fwd+loss+bwd+AdamW steps" if w["kind"] == "train" else "eval forward steps"
     v1, n1 = run(1, 3, 12, 8.0)
-    out = {"value": v1, "unit": unit, "cores": threads, "kind": "port", "cpu": cpu_model_name(),
+    out = {"value": v1, "unit": unit, "cores": threads, "host_threads_visible": os.cpu_count(), "kind": "port", "cpu": cpu_model_name(),
            "sample": f"batch 1 clip {T}x{H}x{W}x4ch fp32, 1 warm-up + {n1} timed {what} of the oracle (torch CPU, {threads} threads)"}
     if w["batch"] > 1 and os.environ.get("BENCH_CPU_FULL_BATCH", "1") == "1":
         vb, nb = run(w["batch"], 2, 3, 20.0)
@@ -180,7 +181,21 @@ def eager_gpu_baseline(w, dev, autocast):
 
 
 def host_threads():
+    """Cores this process may actually use: the affinity mask, cut to the cgroup CPU quota (a GPU box shows all 256 host threads in the
+    mask but grants a 16-CPU share; 256 torch threads on 16 CPUs take minutes per step), or BENCH_CPU_THREADS."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = max(1, min(n, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
     cap = os.environ.get("BENCH_CPU_THREADS")
     return max(1, min(n, int(cap)) if cap else n)
 

@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(512) stream_gemm_kernel(StreamArgs a) {
                 if constexpr (AUX != BF_AUX_NONE) {
                     const bf16x8 ax = __builtin_bit_cast(bf16x8, auxr[i][pp]);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = AUX == BF_AUX_ADD ? v[q] + (float)ax[q] : v[q] * dgelu_f((float)ax[q]);
+                    for (int q = 0; q < 8; ++q) v[q] = AUX == BF_AUX_ADD ? v[q] + (float)ax[q] : v[q] * dgelu_fast((float)ax[q]);
                 }
                 bf16x8 o;
 #pragma unroll
@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(512) stream_gemm_kernel(StreamArgs a) {
                 if constexpr (GELU2) {
                     bf16x8 g8;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) g8[q] = (bf16)gelu_f(v[q]);
+                    for (int q = 0; q < 8; ++q) g8[q] = (bf16)gelu_fast(v[q]);
                     *reinterpret_cast<bf16x8*>(a.gelu_out + off) = g8;
                 }
             }

@@ -5,8 +5,8 @@
 //
 // The reduction runs over tens of thousands of tokens and the result is a few hundred KB, so the split over workgroups is a split
 // of the TOKENS.  What that costs is the partial results: (#workgroups) x (tile bytes) of fp32 leave the chip whatever the tile
-// shape.  This kernel therefore uses FEW, LONG slices (4 by default): one workgroup = one 128 x 128 output tile x one token slice,
-// 36-144 workgroups per launch -- the launch deliberately does not fill the chip; it runs beside the data-gradient kernels of the
+// shape.  This kernel therefore uses FEW, LONG slices (4-8): one workgroup = one 384 x 128 (or 128 x 128) output tile x one token slice,
+// 24-144 workgroups per launch -- the launch deliberately does not fill the chip; it runs beside the data-gradient kernels of the
 // caller's stream -- and its partial tile goes to a slab with plain 16-byte stores.  A second tiny kernel adds the slabs in slice
 // order: the result is bit-reproducible run to run (no float atomics anywhere) and the slab traffic is 2 x 4 x |out| instead of
 // the split-K atomics' 9-19 x |out|.
@@ -27,17 +27,22 @@ using namespace bfgemm;
 
 constexpr int TB = 128;            // output tile edge
 constexpr int BK = 64;             // tokens per K-step
-constexpr int CHUNK = BK * TB;     // elements of one operand chunk (16 KB)
 
-// WN = waves along the Kin axis: 4 -> 8 waves (2 x 4), 64 x 32 per wave; 2 -> 4 waves (2 x 2), 64 x 64 per wave
-template <int NSLOT, int WN>
-__global__ void __launch_bounds__(128 * WN) tokred_kernel(const bf16* __restrict__ A, long lda, const bf16* __restrict__ B, long ldb,
-                                                         float* __restrict__ slab, float* __restrict__ cslab, int Nout, int Kin,
-                                                         int steps_total, int steps_per, int tiles_k, int ntiles, int nslice, int mode) {
-    constexpr int NW = 2 * WN, NT = 64 * NW;
-    constexpr int TN = 8 / WN;                 // 16-column MFMA tiles per wave along Kin
-    constexpr int PPW = 16 / NW;               // 1-KiB DMA pieces per wave per operand chunk
-    constexpr int G = 2 * PPW;                 // DMA instructions per thread per K-step
+// MT = 128-row sub-chunks of the Nout side of a tile: 1 -> 128 x 128 tile, 2 x 4 waves of 64 x 32; 3 -> 384 x 128 tile, 4 x 2 waves of
+// 96 x 64 (one and a half times the FLOPs per DMA byte: a CU takes in ~55 GB/s from L2, which is what bounds a step -- measured: the
+// 128 x 128 form ran 0.6 us per 32 KB step whatever the ring depth).  8 waves either way.
+template <int NSLOT, int MT, int BKT>      // BKT: tokens per K-step (64, or 32 so that four 32 KB slots of the tall tile fit the LDS)
+__global__ void __launch_bounds__(512) tokred_kernel(const bf16* __restrict__ A, long lda, const bf16* __restrict__ B, long ldb,
+                                                   float* __restrict__ slab, float* __restrict__ cslab, int Nout, int Kin,
+                                                   int steps_total, int steps_per, int tiles_k, int ntiles, int nslice, int mode) {
+    constexpr int TM = 128 * MT;                       // tile rows (Nout side)
+    constexpr int WM = MT == 1 ? 2 : 4, WN = 8 / WM;   // waves along Nout / Kin
+    constexpr int TMI = TM / WM / 16, TNI = TB / WN / 16;      // 16 x 16 MFMA tiles per wave: 4 x 2 or 6 x 4
+    constexpr int CHUNK = BKT * TB;                    // elements of one [BKT][128] sub-chunk
+    constexpr int PPC = BKT / 4;                       // 1-KiB DMA pieces per sub-chunk
+    constexpr int PA = PPC * MT / 8, PB = PPC / 8;     // pieces per wave per step: Nout side, Kin side
+    constexpr int G = PA + PB;                         // DMA instructions per thread per K-step
+    constexpr int SLOT = (MT + 1) * CHUNK;             // elements of one ring slot: MT sub-chunks [64][128] of dy, one of x
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* ring = reinterpret_cast<bf16*>(smem);
 
@@ -52,45 +57,51 @@ __global__ void __launch_bounds__(128 * WN) tokred_kernel(const bf16* __restrict
         const int seq = xcd_remap(blockIdx.x, gridDim.x);
         slice = seq / ntiles; tile = seq - slice * ntiles;
     }
-    const int n0 = (tile / tiles_k) * TB, c0 = (tile % tiles_k) * TB;
+    const int n0 = (tile / tiles_k) * TM, c0 = (tile % tiles_k) * TB;
     const int s_beg = slice * steps_per;
     const int steps = min(steps_per, steps_total - s_beg);
 
-    // DMA source addresses: piece p = rows 4p .. 4p+3 of the chunk; lane -> row 4p + (lane >> 4), LDS 16-byte chunk (lane & 15),
-    // which holds global chunk (lane & 15) ^ (2 * key(row)) of that row (lds_off<bf16, true, 128>)
-    const bf16* pa[PPW];
-    const bf16* pb[PPW];
+    // DMA source addresses: piece p of a [64][128] sub-chunk = its rows 4p .. 4p+3; lane -> row 4p + (lane >> 4), LDS 16-byte chunk
+    // (lane & 15), which holds global chunk (lane & 15) ^ (2 * key(row)) of that row (lds_off<bf16, true, 128>)
+    const bf16* pa[PA];
+    const bf16* pb[PB];
+    unsigned la[PA];                                   // LDS byte offset of each Nout-side piece inside the slot
 #pragma unroll
-    for (int t = 0; t < PPW; ++t) {
-        const int p = wave * PPW + t, r = 4 * p + (lane >> 4);
+    for (int t = 0; t < PA; ++t) {
+        const int pg = wave * PA + t, sub = pg / PPC, p = pg % PPC, r = 4 * p + (lane >> 4);
         const int key = (r & 3) | ((r >> 1) & 4);
-        const int ch = (lane & 15) ^ (key << 1);
-        pa[t] = A + ((long)s_beg * BK + r) * lda + n0 + 8 * ch;
-        pb[t] = B + ((long)s_beg * BK + r) * ldb + c0 + 8 * ch;
+        pa[t] = A + ((long)s_beg * BKT + r) * lda + n0 + sub * TB + 8 * ((lane & 15) ^ (key << 1));
+        la[t] = (unsigned)(sub * CHUNK * 2 + p * 1024);
     }
-    const long stepa = (long)BK * lda, stepb = (long)BK * ldb;
-    const unsigned ring_lds = __builtin_amdgcn_readfirstlane(lds_addr(ring) + (unsigned)(wave * PPW) * 1024u);      // this wave's first piece
-    auto issue = [&](int slot) {
-        const unsigned sa = ring_lds + (unsigned)slot * (unsigned)(2 * CHUNK * 2);
 #pragma unroll
-        for (int t = 0; t < PPW; ++t) {
-            glds16(pa[t], sa + t * 1024u);
+    for (int t = 0; t < PB; ++t) {
+        const int p = wave * PB + t, r = 4 * p + (lane >> 4);
+        const int key = (r & 3) | ((r >> 1) & 4);
+        pb[t] = B + ((long)s_beg * BKT + r) * ldb + c0 + 8 * ((lane & 15) ^ (key << 1));
+    }
+    const long stepa = (long)BKT * lda, stepb = (long)BKT * ldb;
+    const unsigned ring_lds = lds_addr(ring);
+    auto issue = [&](int slot) {
+        const unsigned sa = ring_lds + (unsigned)slot * (unsigned)(SLOT * 2);
+#pragma unroll
+        for (int t = 0; t < PA; ++t) {
+            glds16(pa[t], __builtin_amdgcn_readfirstlane(sa + la[t]));
             pa[t] += stepa;
         }
 #pragma unroll
-        for (int t = 0; t < PPW; ++t) {
-            glds16(pb[t], sa + (unsigned)(CHUNK * 2) + t * 1024u);
+        for (int t = 0; t < PB; ++t) {
+            glds16(pb[t], __builtin_amdgcn_readfirstlane(sa + (unsigned)(MT * CHUNK * 2) + (unsigned)(wave * PB + t) * 1024u));
             pb[t] += stepb;
         }
     };
 
     const int wm = wave / WN, wn = wave % WN;
-    f32x4 acc[4][TN];
+    f32x4 acc[TMI][TNI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TMI; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int CSN = 4 / WN;               // column-sum accumulators per wave
+        for (int j = 0; j < TNI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int CSN = TMI / WN;             // column-sum accumulators per wave: row tiles wn, wn + WN, ...
     f32x4 cs[CSN];
 #pragma unroll
     for (int q = 0; q < CSN; ++q) cs[q] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -108,31 +119,33 @@ __global__ void __launch_bounds__(128 * WN) tokred_kernel(const bf16* __restrict
     for (int s = 0; s < steps; ++s) {
         // chunk s has landed once at most the younger chunks' DMAs are outstanding (vmcnt counts in issue order)
         const int younger = min(NSLOT - 2, steps - 1 - s);
-        if (younger == NSLOT - 2) wait_vm<(NSLOT - 2) * G>();
+        if (NSLOT > 2 && younger == NSLOT - 2) wait_vm<(NSLOT > 2 ? NSLOT - 2 : 0) * G>();
         else if (NSLOT > 3 && younger == 1) wait_vm<G>();
-        else if (NSLOT > 4 && younger == 2) wait_vm<2 * G>();
         else wait_vm<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();            // every wave's pieces of chunk s are visible; nobody reads slot (s-1) % NSLOT any more
         if (s + NSLOT - 1 < steps) issue(nxt);
-        const bf16* cA = ring + (size_t)cur * (2 * CHUNK);
-        const bf16* cB = cA + CHUNK;
+        const bf16* cA = ring + (size_t)cur * SLOT;
+        const bf16* cB = cA + MT * CHUNK;
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 32) {
-            bf16x8 fa[4], fb[TN];
+        for (int kk = 0; kk < BKT; kk += 32) {
+            bf16x8 fa[TMI], fb[TNI];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = frag_bf16<true, TB>(cA, wm * 64 + i * 16, kk, lane);
+            for (int i = 0; i < TMI; ++i) {
+                const int r = wm * (16 * TMI) + i * 16;                       // row of the tile: sub-chunk r / 128, row r % 128 inside it
+                fa[i] = frag_bf16<true, TB>(cA + (r >> 7) * CHUNK, r & 127, kk, lane);
+            }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = frag_bf16<true, TB>(cB, wn * (16 * TN) + j * 16, kk, lane);
+            for (int j = 0; j < TNI; ++j) fb[j] = frag_bf16<true, TB>(cB, wn * (16 * TNI) + j * 16, kk, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TMI; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-            if (do_cs) {          // column sums of dy (bias gradient): row groups wn, wn + WN, .. of this wave's 64 rows against an all-ones operand
+                for (int j = 0; j < TNI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            if (do_cs) {          // column sums of dy (bias gradient): row tiles wn, wn + WN, .. of this wave against an all-ones operand
 #pragma unroll
                 for (int q = 0; q < CSN; ++q)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < TMI; ++i)
                         if (wn + q * WN == i) cs[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[i], cs[q], 0, 0, 0);
             }
         }
@@ -142,15 +155,15 @@ __global__ void __launch_bounds__(128 * WN) tokred_kernel(const bf16* __restrict
 
     // partial tile -> slab[slice][Nout][Kin] (plain 16-byte stores; lane = one row, 4 consecutive columns per MFMA tile)
     const int li = lane & 15, lg = lane >> 4;
-    float* so = slab + ((size_t)slice * Nout + n0 + wm * 64 + li) * Kin + c0 + wn * (16 * TN) + 4 * lg;
+    float* so = slab + ((size_t)slice * Nout + n0 + wm * (16 * TMI) + li) * Kin + c0 + wn * (16 * TNI) + 4 * lg;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TMI; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TNI; ++j)
             *reinterpret_cast<float4*>(so + (size_t)(i * 16) * Kin + j * 16) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
     if (do_cs && lg == 0) {
 #pragma unroll
-        for (int q = 0; q < CSN; ++q) cslab[(size_t)slice * Nout + n0 + wm * 64 + (wn + q * WN) * 16 + li] = cs[q][0];
+        for (int q = 0; q < CSN; ++q) cslab[(size_t)slice * Nout + n0 + wm * (16 * TMI) + (wn + q * WN) * 16 + li] = cs[q][0];
     }
 }
 
@@ -177,9 +190,10 @@ __global__ void __launch_bounds__(256) tokred_reduce_kernel(const float* __restr
 
 int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 
-int pick_slices(int Nout, int Kin, long steps) {
-    static const int max_slices = env_int("BF_TOKRED_SLICES", 4);
-    int ns = max_slices < 1 ? 1 : max_slices > 8 ? 8 : max_slices;
+int pick_slices(long steps, int dflt) {
+    static const int env = env_int("BF_TOKRED_SLICES", 0);
+    int ns = env > 0 ? env : dflt;
+    ns = ns < 1 ? 1 : ns > 8 ? 8 : ns;
     if (ns > steps) ns = (int)steps;
     return ns;
 }
@@ -200,39 +214,49 @@ extern "C" int bf_gemm_tokred(int dtype, int Nout, int Kin, int64_t M, const voi
     BF_REQUIRE(dy && x && out && ws, "bf_gemm_tokred: null pointer");
     BF_REQUIRE(((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)ws & 15) == 0,
                "bf_gemm_tokred: operands must be 16-byte aligned");
-    const long steps = M / BK;
-    const int nslice = pick_slices(Nout, Kin, steps);
+    // BF_TOKRED_TALL=1: 384 x 128 tiles (1.5 x the FLOPs per DMA byte, a third as many tiles), 32-token steps so that FOUR 32 KB slots
+    // fit the LDS.  Measured and NOT the default: a workgroup reaches 49 % MFMA utilisation instead of 40 %, not 1.5 x (both forms
+    // sit at ~45 GB/s of DMA per CU behind one barrier per step), so on a third as many workgroups a launch takes 82-88 us instead of
+    // 57 alone; in the training step the side stream then outlasts the backward's critical path: 558 (6 slices) / 581 (8) samples/s
+    // against 632 with 128 x 128 tiles, although the caller's own kernels run faster beside it (data gradient 54 us instead of 66).
+    static const int tall_env = env_int("BF_TOKRED_TALL", 0);
+    const bool tall = tall_env != 0 && Nout % 384 == 0;
+    const int tm = tall ? 384 : TB, bkt = tall ? 32 : BK;
+    const long steps = M / bkt;
+    const int nslice = pick_slices(steps, tall ? (Nout / 384 >= 3 ? 6 : 8) : 4);
     const long n = (long)Nout * Kin;
     BF_REQUIRE(ws_floats >= (int64_t)nslice * (n + Nout), "bf_gemm_tokred: workspace too small (bf_gemm_tokred_ws_floats)");
     const int steps_per = bf_cdiv(steps, nslice);
     const int ns = bf_cdiv(steps, steps_per);                  // slices that actually have tokens
-    const int tiles_k = Kin / TB, ntiles = (Nout / TB) * tiles_k;
+    const int tiles_k = Kin / TB, ntiles = (Nout / tm) * tiles_k;
     float* slab = ws;
     float* cslab = colsum ? ws + (size_t)ns * n : nullptr;
     hipStream_t st = (hipStream_t)stream;
     static const int mode_env = env_int("BF_TOKRED_MODE", 0);
     const int mode = (mode_env == 1 && ntiles <= 32 && ns <= 4) ? 1 : 0;
     const unsigned grid = mode == 1 ? 8u * (unsigned)ntiles : (unsigned)(ns * ntiles);
-    static const int nslot_env = env_int("BF_TOKRED_SLOTS", 3);
+    static const int nslot_env = env_int("BF_TOKRED_SLOTS", 0);
+    const int nslot = tall ? 4 : (nslot_env >= 2 && nslot_env <= 4 ? nslot_env : 3);
     {
         static thread_local char pname[64];
-        snprintf(pname, sizeof(pname), "tokred_kernel<slots%d>", nslot_env);
+        snprintf(pname, sizeof(pname), "tokred_kernel<%dx128,bk%d,slots%d>", tm, bkt, nslot);
         BfProfScope prof(st, pname, 2.0 * Nout * Kin * (double)M, (double)M * (Nout + Kin) * 2.0 + (double)n * 4.0);
-#define BF_TOKRED_GO(NSLOT)                                                                                                               \
+#define BF_TOKRED_GO(NSLOT, MTV, BKV)                                                                                                     \
         do {                                                                                                                              \
             static bool attr_done = false;                                                                                                \
-            constexpr int lds_bytes = NSLOT * 2 * CHUNK * 2;                                                                              \
+            constexpr int lds_bytes = NSLOT * (MTV + 1) * BKV * TB * 2;                                                                   \
             if (!attr_done) {                                                                                                             \
-                hipError_t e_ = hipFuncSetAttribute((const void*)tokred_kernel<NSLOT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+                hipError_t e_ = hipFuncSetAttribute((const void*)tokred_kernel<NSLOT, MTV, BKV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
                 if (e_ != hipSuccess) return bf_fail(e_, __FILE__, __LINE__);                                                             \
                 attr_done = true;                                                                                                         \
             }                                                                                                                             \
-            hipLaunchKernelGGL((tokred_kernel<NSLOT, 4>), dim3(grid), dim3(512), lds_bytes, st, (const bf16*)dy, (long)ldy, (const bf16*)x,  \
+            hipLaunchKernelGGL((tokred_kernel<NSLOT, MTV, BKV>), dim3(grid), dim3(512), lds_bytes, st, (const bf16*)dy, (long)ldy, (const bf16*)x,  \
                                (long)ldx, slab, cslab, Nout, Kin, (int)steps, steps_per, tiles_k, ntiles, ns, mode);                      \
         } while (0)
-        if (nslot_env == 2) BF_TOKRED_GO(2);
-        else if (nslot_env == 4) BF_TOKRED_GO(4);
-        else BF_TOKRED_GO(3);
+        if (tall) BF_TOKRED_GO(4, 3, 32);
+        else if (nslot == 2) BF_TOKRED_GO(2, 1, 64);
+        else if (nslot == 4) BF_TOKRED_GO(4, 1, 64);
+        else BF_TOKRED_GO(3, 1, 64);
 #undef BF_TOKRED_GO
         BF_CHECK_LAUNCH();
     }

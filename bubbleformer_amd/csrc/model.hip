@@ -193,7 +193,8 @@ struct Fork {
 // ------------------------------------------------------------------------------------------------ small param kernels
 // out-projection fold.  mc[n] = <W[n,:], nb> + bias[n]; alpha = gamma*(1+hi); beta = gamma*(bias*(1+hi) + mc*(lo-hi))
 struct PrepArgs { const float *W, *bias, *nb, *gamma, *lo, *hi; float *alpha, *beta, *mc; int E; void* wscaled; int dtype;
-                  const float *tab_m, *tab_v; float* tab_out; int tab_F; };     // optional stochastic-depth table tab_out[f][c] = tab_m[f] * tab_v[c] (E columns)      // wscaled[n][k] = alpha[n] * W[n][k] (compute dtype): the data-gradient GEMM's weight
+                  const float *tab_m, *tab_v; float* tab_out; int tab_F;
+                  const float* tr_src; void* tr_dst; int tr_R, tr_C; };     // optional transposed bf16 copy tr_dst[c][r] = tr_src[r][c] (fc2 weight: the data gradient's K-contiguous operand)     // optional stochastic-depth table tab_out[f][c] = tab_m[f] * tab_v[c] (E columns)      // wscaled[n][k] = alpha[n] * W[n][k] (compute dtype): the data-gradient GEMM's weight
 __device__ __forceinline__ void outproj_prep_row(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ nb,
                                                  const float* __restrict__ gamma, const float* __restrict__ lo, const float* __restrict__ hi,
                                                  float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ mc, int E, int n,
@@ -274,6 +275,17 @@ __global__ void frame_table_kernel(const float* __restrict__ m, int fdiv, const 
     out[i] = m[f / fdiv] * (v ? v[c] : 1.f);
 }
 
+// dst[c][r] = (bf16) src[r][c]: 8 consecutive r per thread (strided reads of a small weight, 16-byte stores)
+__device__ __forceinline__ void transpose_cast(const float* __restrict__ src, bf16* __restrict__ dst, int R, int C, long first, long stride) {
+    const long n8 = (long)C * (R / 8);
+    for (long i = first; i < n8; i += stride) {
+        const int c = (int)(i / (R / 8)), r0 = (int)(i % (R / 8)) * 8;
+        bf16x8 o;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = (bf16)src[(long)(r0 + q) * C + c];
+        *reinterpret_cast<bf16x8*>(dst + (long)c * R + r0) = o;
+    }
+}
 // up to four plain fp32 -> bf16 weight casts in ONE launch (a stage's projection weights)
 struct Cast4 { const float* src[4]; bf16* dst[4]; long n[4]; };
 __global__ void __launch_bounds__(256) cast4_kernel(Cast4 j) {
@@ -288,7 +300,12 @@ __global__ void __launch_bounds__(256) cast4_kernel(Cast4 j) {
 }
 // the same casts plus the out-projection fold (grid row cnt, one workgroup per output channel): a stage's parameter-only work in ONE launch
 __global__ void __launch_bounds__(256) stage_prep_kernel(Cast4 j, int cnt, PrepArgs a) {
-    if ((int)blockIdx.y == cnt + 1) {          // the stage's stochastic-depth table (frame_table_kernel's work, no launch of its own)
+    if ((int)blockIdx.y == cnt + 2) {          // transposed copy
+        if (a.tr_dst) transpose_cast(a.tr_src, (bf16*)a.tr_dst, a.tr_R, a.tr_C, (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256);
+        return;
+    }
+    if ((int)blockIdx.y == cnt + 1) {
+        if (!a.tab_out) return;          // the stage's stochastic-depth table (frame_table_kernel's work, no launch of its own)
         const long n = (long)a.tab_F * a.E;
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) a.tab_out[i] = a.tab_m[i / a.E] * a.tab_v[i % a.E];
         return;
@@ -313,13 +330,17 @@ __global__ void __launch_bounds__(256) stage_prep_multi_kernel(PrepBatch b) {
     const int z = blockIdx.z, cnt = b.cnt[z];
     const Cast4& j = b.j[z];
     const PrepArgs& a = b.a[z];
+    if ((int)blockIdx.y == cnt + 2) {
+        if (a.tr_dst) transpose_cast(a.tr_src, (bf16*)a.tr_dst, a.tr_R, a.tr_C, (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256);
+        return;
+    }
     if ((int)blockIdx.y == cnt + 1) {
         if (!a.tab_out) return;
         const long n = (long)a.tab_F * a.E;
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) a.tab_out[i] = a.tab_m[i / a.E] * a.tab_v[i % a.E];
         return;
     }
-    if ((int)blockIdx.y > cnt + 1) return;
+    if ((int)blockIdx.y > cnt + 2) return;
     if ((int)blockIdx.y == cnt) {
         if ((int)blockIdx.x < a.E) outproj_prep_row(a.W, a.bias, a.nb, a.gamma, a.lo, a.hi, a.alpha, a.beta, a.mc, a.E, blockIdx.x, a.wscaled, a.dtype);
         return;
@@ -346,7 +367,7 @@ int wviews(const D& d, int cnt, const float* const* src, void* const* dst, const
     Cast4 j;
     for (int i = 0; i < 4; ++i) { j.src[i] = src[i < cnt ? i : 0]; j.dst[i] = (bf16*)dst[i < cnt ? i : 0]; j.n[i] = i < cnt ? n[i] : 0; out[i < cnt ? i : 0] = dst[i < cnt ? i : 0]; }
     for (int i = 0; i < cnt; ++i) out[i] = dst[i];
-    if (prep) hipLaunchKernelGGL(stage_prep_kernel, dim3(std::max(64, prep->E), cnt + (prep->tab_out ? 2 : 1)), dim3(256), 0, st, j, cnt, *prep);
+    if (prep) hipLaunchKernelGGL(stage_prep_kernel, dim3(std::max(64, prep->E), cnt + (prep->tr_dst ? 3 : prep->tab_out ? 2 : 1)), dim3(256), 0, st, j, cnt, *prep);
     else hipLaunchKernelGGL(cast4_kernel, dim3(64, cnt), dim3(256), 0, st, j);
     BF_CHECK_LAUNCH();
     return 0;
@@ -376,7 +397,7 @@ struct TemporalSaved {
 };
 struct SpatialSaved {
     float *mean1, *rstd1, *sc1, *sh1, *mean2, *rstd2, *sc2, *sh2, *mean3, *rstd3, *sc3, *sh3, *alpha, *beta, *mc, *gtab;
-    void *qkv, *o, *xn, *on, *x1, *pre, *hid, *z, *win_c, *wout_c, *wout_s, *w1_c, *w2_c;
+    void *qkv, *o, *xn, *on, *x1, *pre, *hid, *z, *win_c, *wout_c, *wout_s, *w1_c, *w2_c, *w2t_c;      // w2t_c = fc2.weight^T [4E][E]: K-contiguous operand of the fc2 data gradient
     size_t bytes;
     SpatialSaved(const D& d, void* base) {
         Arena a(base);
@@ -398,6 +419,7 @@ struct SpatialSaved {
         wout_s = a.take((size_t)d.E * d.E * d.es);
         w1_c = a.take((size_t)4 * d.E * d.E * d.es);
         w2_c = a.take((size_t)4 * d.E * d.E * d.es);
+        w2t_c = a.take((size_t)4 * d.E * d.E * d.es);
         bytes = a.off;
     }
 };
@@ -554,7 +576,7 @@ int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on,
 // backward of y = affine(x) @ W^T + b:  dW += dy^T affine(x), db += colsum(dy), dxn = dy @ W
 int linear_bwd(const D& d, const Scratch& sc, const void* dy, int Nout, const void* x, int Kin, int xpro, const float* xsc, const float* xsh,
                const void* w_c, float* dW, float* db, void* dxn, const bf_epilogue* dx_epi, hipStream_t st, Fork& fk, const InFuse* fu = nullptr,
-               bool last = false) {
+               bool last = false, const void* w_t = nullptr) {      // w_t: the weight transposed ([Kin][Nout], K-contiguous for the data gradient)
     TRY(fk.run([=](hipStream_t ss) -> int {      // weight gradient: side stream
         const void* xo = x;
         int pro = xpro;
@@ -578,7 +600,7 @@ int linear_bwd(const D& d, const Scratch& sc, const void* dy, int Nout, const vo
     if (fu) return dgrad_inbwd(d, dy, Nout, w_c, Kin, dxn, *fu, st);
     {
         bf_operand A = op_plain(dy, Nout, BF_LAY_KC);
-        bf_operand Bo = op_plain(w_c, Kin, BF_LAY_XC);
+        bf_operand Bo = w_t ? op_plain(w_t, Nout, BF_LAY_KC) : op_plain(w_c, Kin, BF_LAY_XC);      // K-contiguous: the streaming kernel's form
         bf_epilogue e = dx_epi ? *dx_epi : epi_store(dxn, Kin);
         e.c = dxn; e.ldc = Kin;
         TRY(bf_gemm(d.dtype, (int)d.N, Kin, Nout, &A, &Bo, &e, 1, st));
@@ -614,7 +636,7 @@ extern "C" int bf_temporal_fwd(const bf_dims* dims, const bf_temporal_params* p,
         const long n[2] = {3L * d.E * d.E, (long)d.E * d.E};
         const void* out[4];
         const PrepArgs prep{p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr, sv.alpha, sv.beta, sv.mc, d.E, sv.wout_s, d.dtype,
-                            nullptr, nullptr, nullptr, 0};
+                            nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0};
         const bool ready = g_stage_prepared && d.dtype == BF_DTYPE_BF16;
         g_stage_prepared = false;
         if (ready) { out[0] = sv.win_c; out[1] = sv.wout_c; }
@@ -700,7 +722,7 @@ extern "C" int bf_prep_stages(const bf_dims* dims, int n, const int32_t* kinds, 
                 for (int q = 0; q < 4; ++q) { j.src[q] = src[q < 2 ? q : 0]; j.dst[q] = (bf16*)dst[q < 2 ? q : 0]; j.n[q] = q < 2 ? cn[q] : 0; }
                 b.cnt[i] = 2;
                 b.a[i] = PrepArgs{p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr, sv.alpha, sv.beta, sv.mc, d.E, sv.wout_s, d.dtype,
-                                  nullptr, nullptr, nullptr, 0};
+                                  nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0};
             } else {
                 const bf_spatial_params* p = (const bf_spatial_params*)params[i0 + i];
                 SpatialSaved sv(d, saved[i0 + i]);
@@ -712,10 +734,11 @@ extern "C" int bf_prep_stages(const bf_dims* dims, int n, const int32_t* kinds, 
                 const float* dm = drop_mlp ? drop_mlp[i0 + i] : nullptr;
                 b.a[i] = PrepArgs{p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att, d.feat_scale ? p->low_freq_scalar : nullptr,
                                   d.feat_scale ? p->high_freq_scalar : nullptr, sv.alpha, sv.beta, sv.mc, d.E, sv.wout_s, d.dtype,
-                                  dm, dm ? p->gamma_mlp : nullptr, dm ? sv.gtab : nullptr, (int)d.F};
+                                  dm, dm ? p->gamma_mlp : nullptr, dm ? sv.gtab : nullptr, (int)d.F,
+                                  p->fc2_w, sv.w2t_c, d.E, 4 * d.E};
             }
         }
-        hipLaunchKernelGGL(stage_prep_multi_kernel, dim3(std::max(64, d.E), 6, m), dim3(256), 0, st, b);
+        hipLaunchKernelGGL(stage_prep_multi_kernel, dim3(std::max(64, d.E), 7, m), dim3(256), 0, st, b);
         BF_CHECK_LAUNCH();
     }
     return 0;
@@ -740,7 +763,8 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
         const bool tab = drop_mlp && d.dtype != BF_DTYPE_F32;      // gtab[f][c] = drop_mlp[f] * gamma_mlp[c], in the same launch
         const PrepArgs prep{p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att, d.feat_scale ? p->low_freq_scalar : nullptr,
                             d.feat_scale ? p->high_freq_scalar : nullptr, sv.alpha, sv.beta, sv.mc, d.E, sv.wout_s, d.dtype,
-                            tab ? drop_mlp : nullptr, tab ? p->gamma_mlp : nullptr, tab ? sv.gtab : nullptr, (int)d.F};
+                            tab ? drop_mlp : nullptr, tab ? p->gamma_mlp : nullptr, tab ? sv.gtab : nullptr, (int)d.F,
+                            d.dtype == BF_DTYPE_BF16 ? p->fc2_w : nullptr, d.dtype == BF_DTYPE_BF16 ? sv.w2t_c : nullptr, d.E, 4 * d.E};
         const bool ready = g_stage_prepared && d.dtype == BF_DTYPE_BF16;
         g_stage_prepared = false;
         if (ready) { out[0] = sv.win_c; out[1] = sv.wout_c; out[2] = sv.w1_c; out[3] = sv.w2_c; }
@@ -828,7 +852,9 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     {
         bf_epilogue e; memset(&e, 0, sizeof(e));
         e.aux_mode = BF_AUX_DGELU; e.aux = sv.pre; e.ld_aux = 4L * d.E; e.out_mode = BF_OUT_STORE;
-        TRY(linear_bwd(d, sc, dz, d.E, sv.hid, 4 * d.E, BF_PRO_NONE, nullptr, nullptr, w2_c, g->fc2_w, g->fc2_b, dpre, &e, st, fk));
+        static const bool use_t = []() { const char* v = getenv("BF_FC2_DGRAD_T"); return !(v && v[0] == '0'); }();
+        TRY(linear_bwd(d, sc, dz, d.E, sv.hid, 4 * d.E, BF_PRO_NONE, nullptr, nullptr, w2_c, g->fc2_w, g->fc2_b, dpre, &e, st, fk, nullptr, false,
+                       (!f32 && use_t) ? sv.w2t_c : nullptr));
     }
     // fc1: pre = x1 @ W1^T + b1 ; dx1 = dout + dpre @ W1
     void* dx1 = sc.t1b;

@@ -248,6 +248,8 @@ FULLSIZE = OrderedDict(      # BASELINE.json configs at full `film_avit_small` w
     config1_16x192x192=dict(B=1, T=16, H=192, W=192, seed=12),
     config3_32x384x192=dict(B=1, T=32, H=384, W=192, seed=13),
     config3_32x192x384=dict(B=1, T=32, H=192, W=384, seed=16),
+    # config/model_cfg/film_avit_big.yaml at FULL depth (E = 768, 12 heads, 12 blocks; 115,314,882 parameters), one bench-shape sample
+    big_16x192x192=dict(B=1, T=16, H=192, W=192, seed=17, cfg=dict(embed_dim=768, num_heads=12)),
 )
 FULLSIZE_CFG = dict(input_fields=4, output_fields=4, patch_size=16, embed_dim=384, num_heads=6, processor_blocks=12, num_fluid_params=9)
 NSAMP, NSAMP_PARAM = 2048, 16
@@ -285,8 +287,9 @@ def gen_fullsize(gold, ref_models, LpLoss, only=None):
         if only and name not in only:
             continue
         t0 = time.time()
-        model = ref_models.get_model("filmavit", time_window=c["T"], drop_path=0.0, **FULLSIZE_CFG).double()
-        model.load_state_dict({k: v.double() for k, v in W.generate(W.param_shapes(**FULLSIZE_CFG), seed=c["seed"]).items()})
+        cfg = dict(FULLSIZE_CFG, **c.get("cfg", {}))
+        model = ref_models.get_model("filmavit", time_window=c["T"], drop_path=0.0, **cfg).double()
+        model.load_state_dict({k: v.double() for k, v in W.generate(W.param_shapes(**cfg), seed=c["seed"]).items()})
         model.train()
         x = W.synthetic_clip(c["B"], c["T"], 4, c["H"], c["W"], 100 + c["seed"]).double().requires_grad_(True)
         y = W.synthetic_clip(c["B"], c["T"], 4, c["H"], c["W"], 200 + c["seed"]).double()

@@ -175,6 +175,26 @@ def test_config1_weight_gradients_are_bit_reproducible():
     assert n_exact == 12 * (2 * 2 + 4)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_film_avit_big_full_depth_sample(dtype):
+    """config/model_cfg/film_avit_big.yaml at FULL depth (E = 768, 12 heads, 12 blocks, 115,314,882 parameters), one 16x192x192 sample,
+    against the reference's own fp64 statistics at that size (tests/golden/fullsize_big_16x192x192.npz, oracle/gen_golden.py --fullsize):
+    fp32 1e-4, bf16 the full-depth bounds of configs[0] / [1]."""
+    from bubbleformer_amd.models import get_model
+    big = dict(SMALL, embed_dim=768, num_heads=12)
+    B, T, H, W, seed = 1, 16, 192, 192, 17
+    m = get_model("filmavit", time_window=T, drop_path=0.0, compute_dtype=dtype, **big)
+    assert sum(p.numel() for p in m.parameters()) == 115314882          # SURVEY.md section 8a
+    m.load_state_dict(_weights(seed, big))
+    m = m.cuda()
+    x, y, c = (t.cuda() for t in _inputs(B, T, H, W, seed))
+    x.requires_grad_(True)
+    loss, pred = m.forward_loss(x, c, y)
+    loss.backward()
+    prod = (pred.detach().cpu(), float(loss.detach()), x.grad.detach().cpu(), {k: p.grad.detach().cpu() for k, p in m.named_parameters()})
+    _against_reference("big_16x192x192", prod, dtype)
+
+
 def test_config1_bench_size_properties():
     """bs 8 x 16x192x192, bf16, eval: reruns are bit-identical; a sample's prediction does not depend on its batch mates
     (InstanceNorm is per frame, attention per sequence) beyond bf16 GEMM tiling noise."""

@@ -38,6 +38,16 @@ def normalise(name: str) -> str:
         ax, bx, ap, bp, tm = m.groups()
         return "gemm_wide_kernel<bf16,%s,%s,pro%s,tm%s>" % ("xc" if ax == "true" else "kc", "xc" if bx == "true" else "kc",
                                                            "A" if ap == "true" else "B" if bp == "true" else "0", tm)
+    m = re.search(r"stream_gemm_kernel<(\d), (true|false), (true|false)>", name) or re.search(r"stream_gemm_kernelILi(\d)ELb([01])ELb([01])E", name)
+    if m:
+        aux, g2, _ = m.groups()
+        return "stream_gemm<%s>" % ("gelu2" if g2 in ("true", "1") else {"0": "plain", "1": "add", "2": "dgelu"}[aux])
+    m = re.search(r"tokred_kernel<(\d), (\d), (\d+)>", name) or re.search(r"tokred_kernelILi(\d)ELi(\d)ELi(\d+)E", name)
+    if m:
+        ns, mt, bk = m.groups()
+        return "tokred_kernel<%dx128,bk%s,slots%s>" % (128 * int(mt), bk, ns)
+    if "tokred_reduce_kernel" in name:
+        return "tokred_reduce_kernel"
     if "gemm_inbwd_frames_kernel" in name:
         return "gemm_inbwd_frames<bf16>"
     for key in ("frame_scale_kernel", "stage_param_reduce_kernel", "stage_prep_kernel", "clip_gather_kernel", "eikonal_kernel", "heatflux_kernel",
