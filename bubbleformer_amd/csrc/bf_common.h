@@ -125,6 +125,10 @@ __device__ __forceinline__ float dgelu_fast(float x) {
     return 0.5f + xc * r;
 }
 
+// storage-type dispatch: bf16 kernels take the polynomial forms, the exact-fp32 parity mode the exact ones
+template <typename T> __device__ __forceinline__ float gelu_t(float x) { if constexpr (sizeof(T) == 2) return gelu_fast(x); else return gelu_f(x); }
+template <typename T> __device__ __forceinline__ float dgelu_t(float x) { if constexpr (sizeof(T) == 2) return dgelu_fast(x); else return dgelu_f(x); }
+
 // ---------------------------------------------------------------- wave / block reductions (64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -156,7 +156,7 @@ struct StagerFixed {
                 for (int j = 0; j < CH; ++j) {
                     float v = s.data[i].get(j);
                     if (op.pro != BF_PRO_GELU) v = v * sc[j] + sh[j];
-                    if (op.pro != BF_PRO_AFFINE) v = gelu_f(v);
+                    if (op.pro != BF_PRO_AFFINE) v = gelu_t<T>(v);
                     s.data[i].set(j, v);
                 }
             }

@@ -211,7 +211,7 @@ __device__ __forceinline__ void epilogue_rows(const f32x4 (&acc)[TM][TN], const 
                         for (int q = 0; q < G; ++q) a[q] = (n + q < N) ? to_f(aux[q]) : 0.f;
                     }
 #pragma unroll
-                    for (int q = 0; q < G; ++q) v[q] = (E.aux_mode == BF_AUX_ADD) ? (v[q] + a[q]) : (v[q] * dgelu_f(a[q]));
+                    for (int q = 0; q < G; ++q) v[q] = (E.aux_mode == BF_AUX_ADD) ? (v[q] + a[q]) : (v[q] * dgelu_t<T>(a[q]));
                 }
                 // scatter geometry keeps 4-column groups whole (host-checked), so address the two halves separately
                 const long rb = row_base(m, E.ldc, E.gw, E.gh, E.gc);
@@ -244,7 +244,7 @@ __device__ __forceinline__ void epilogue_rows(const f32x4 (&acc)[TM][TN], const 
                     if (E.gelu_out) {
                         float u[G];
 #pragma unroll
-                        for (int q = 0; q < G; ++q) u[q] = gelu_f(v[q]);
+                        for (int q = 0; q < G; ++q) u[q] = gelu_t<T>(v[q]);
                         put(reinterpret_cast<T*>(E.gelu_out), u);
                     }
                 }

@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(NT) in_bwd_kernel(const T* __restrict__ dy, co
         for (int j = 0; j < CH; ++j) {
             const float xh = (v.get(j) - mu[j]) * rs[j];
             float dd = d.get(j);
-            if (GELU) dd *= dgelu_f(xh * ww[j] + bb[j]);
+            if (GELU) dd *= dgelu_t<T>(xh * ww[j] + bb[j]);
             acc[0][j] += dd;
             acc[1][j] += dd * xh;
         }
@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(NT) in_bwd_kernel(const T* __restrict__ dy, co
         for (int j = 0; j < CH; ++j) {
             const float xh = (v.get(j) - mu[j]) * rs[j];
             float dd = d.get(j);
-            if (GELU) dd *= dgelu_f(xh * ww[j] + bb[j]);
+            if (GELU) dd *= dgelu_t<T>(xh * ww[j] + bb[j]);
             float t = rs[j] * ww[j] * gg[j] * (dd - (acc[0][j] + xh * acc[1][j]) / (float)S);
             if (add) t += a.get(j);
             o.set(j, t);
@@ -477,7 +477,7 @@ __global__ void __launch_bounds__(NT_) in_bwd_slice_kernel(const T* __restrict__
                 for (int j = 0; j < CH; ++j) {
                     const float xh = (kx[q].get(j) - mu[j]) * rs[j];
                     float dd = kd[q].get(j);
-                    if (GELU) dd *= dgelu_f(xh * ww[j] + bb[j]);
+                    if (GELU) dd *= dgelu_t<T>(xh * ww[j] + bb[j]);
                     if (PHASE == 0) { acc[0][j] += dd; acc[1][j] += dd * xh; }
                     else {
                         float t = rs[j] * ww[j] * gg[j] * (dd - t1[j] - xh * t2[j]);

@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(NT) debed_last_kernel(const bf16* __restrict__
         for (int s = 0; s < KS; ++s) {
             bf16x8 a;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] = (bf16)gelu_f((float)cur[s][j] * a_sc[s][j] + a_sh[s][j]);
+            for (int j = 0; j < 8; ++j) a[j] = (bf16)gelu_fast((float)cur[s][j] * a_sc[s][j] + a_sh[s][j]);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], a, acc, 0, 0, 0);      // acc[j] = out[n = 4 lg + j][pixel li]
         }
         if (live) {
