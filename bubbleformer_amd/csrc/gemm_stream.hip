@@ -35,6 +35,7 @@ struct StreamArgs {
     const float* bias; const float* colscale; const float* colshift; const float* rowscale; int rpg;
     int aux_mode; const bf16* aux; long ld_aux; bf16* gelu_out;
     int KS, mt, nb;
+    int stagger;
     int dbg;      // timing experiments (BF_STREAM_DEBUG): 1 no DMA waits, 2 every tile reads the rows of tile 0, 4 no LDS reads / MFMA, 8 no stores
 };
 
@@ -170,13 +171,17 @@ __global__ void __launch_bounds__(512) stream_gemm_kernel(StreamArgs a) {
                 }
                 aux_mark = issued;
             }
-            if (i_left > 0 && !(a.dbg & 32)) issue_A();      // into the slot the previous step read
-            mark = issued;
+            // the next chunk's DMA goes into the slot the previous step read.  Waves 0-3 issue it here, waves 4-7 after their first
+            // K-half (BF_STREAM_STAGGER, default on): the two waves of a SIMD then do not both spend the same ~400 cycles issuing DMA
+            // while the matrix pipe idles (MI355X_MICROARCH.md "Two waves per SIMD", item 9: split roles by wave >= 4)
+            const bool late = a.stagger && wave >= 4;
+            if (!late) { if (i_left > 0 && !(a.dbg & 32)) issue_A(); mark = issued; }
             const bf16* cA = ring + (size_t)slot * ACHUNK;
             const bf16* cB = Bres + (size_t)ks * CHUNK;
             if (!(a.dbg & 4))
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 32) {
+                if (kk == 32 && late) { if (i_left > 0 && !(a.dbg & 32)) issue_A(); mark = issued; }
                 bf16x8 fa[4], fb[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) fa[i] = frag_bf16<false, BK>(cA, wm * 64 + i * 16, kk, lane);
@@ -277,6 +282,8 @@ int bf_gemm_stream_try(int M, int N, int K, const bf_operand* A, const bf_operan
     a.KS = K / BK; a.mt = M / BM; a.nb = N / BNB;
     static const int dbg = env_int("BF_STREAM_DEBUG", 0);
     a.dbg = dbg;
+    static const int stagger = env_int("BF_STREAM_STAGGER", 1);
+    a.stagger = stagger;
     const int grid = (num_cus() / 8) * 8;
     if (a.nb > grid / 8) return 1;                    // a team (one workgroup per column block) must fit one XCD
     const int lds_bytes = a.KS * CHUNK * 2 + NSLOT * ACHUNK * 2;
