@@ -78,7 +78,7 @@ SIGNATURES = {
     "bf_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, P(Operand), P(Operand), P(Epilogue), C.c_int, vp]),
     "bf_gemm_tokred": (C.c_int, [C.c_int, C.c_int, C.c_int, i64, vp, i64, vp, i64, fp, C.c_int, fp, fp, i64, vp]),
     "bf_gemm_tokred_ws_floats": (i64, [C.c_int, C.c_int, i64]),
-    "bf_gemm_inbwd_frames": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, vp, vp, vp, C.c_int, fp, fp, fp, fp, vp]),
+    "bf_gemm_inbwd_frames": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, vp, vp, vp, C.c_int, fp, fp, fp, fp, fp, C.c_int, vp]),
     "bf_in_stats": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, fp, fp, fp, C.c_int, fp, fp, fp, fp, fp, fp, vp]),
     "bf_in_ws_floats": (i64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "bf_affine_apply": (C.c_int, [C.c_int, vp, vp, fp, fp, vp, i64, C.c_int, C.c_int, vp]),

@@ -31,6 +31,7 @@ struct FrameArgs {
     const bf16* A; long lda; const bf16* B; long ldb; int N, nk, nt;
     const bf16* x; const bf16* add; bf16* out; long ldx;
     const float* mean; const float* rstd; const float* w; float* ws;
+    const float* fscale; int fdiv;      // optional per-frame-group factor on dy (stochastic depth: the branch gradient of frame f is scaled by fscale[f / fdiv])
 };
 
 __device__ __forceinline__ float row16_sum(float v) {
@@ -144,6 +145,15 @@ __global__ void __launch_bounds__(FNT, 3) gemm_inbwd_frames_kernel(FrameArgs a) 
     }
     __syncthreads();
 
+    if (a.fscale) {                              // dy of this frame carries its stochastic-depth factor (one frame = one tile)
+        const float m = a.fscale[fidx / a.fdiv];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] *= m;
+    }
     // ---- column sums over the frame.  Lane (li, lg) holds row li, columns 4 lg .. 4 lg + 3 of each 16 x 16 tile.
     float* red = reinterpret_cast<float*>(smem + RED_OFF);            // [wm][s1 | s2][128]
     const int colw = wn * 64 + 4 * lg;
@@ -229,7 +239,7 @@ __global__ void __launch_bounds__(FNT, 3) gemm_inbwd_frames_kernel(FrameArgs a) 
 
 extern "C" int bf_gemm_inbwd_frames(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, const void* x,
                                     const void* add, void* out, int S, const float* mean, const float* rstd, const float* w, float* ws,
-                                    bf_stream_t stream) {
+                                    const float* fscale, int fdiv, bf_stream_t stream) {
     BF_REQUIRE(A && B && x && out && mean && rstd && w, "bf_gemm_inbwd_frames: null pointer");
     static const bool off = []() { const char* v = getenv("BF_FUSE_INBWD"); return v && atoi(v) == 0; }();
     if (off || dtype != BF_DTYPE_BF16 || S != FM || M <= 0 || M % FM || N <= 0 || N % FN || K < FK || K % FK || lda % 8 || ldb % 8) return 1;
@@ -241,6 +251,7 @@ extern "C" int bf_gemm_inbwd_frames(int dtype, int M, int N, int K, const void* 
     a.A = (const bf16*)A; a.lda = lda; a.B = (const bf16*)B; a.ldb = ldb; a.N = N; a.nk = K / FK; a.nt = N / FN;
     a.x = (const bf16*)x; a.add = (const bf16*)add; a.out = (bf16*)out; a.ldx = N;
     a.mean = mean; a.rstd = rstd; a.w = w; a.ws = ws;
+    a.fscale = fscale; a.fdiv = fdiv > 0 ? fdiv : 1;
     BfProfScope prof(st, "gemm_inbwd_frames<bf16>", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * N * (add ? 3 : 2)));
     hipLaunchKernelGGL(gemm_inbwd_frames_kernel, dim3((unsigned)((M / FM) * a.nt)), dim3(FNT), LDS_BYTES, st, a);
     BF_CHECK_LAUNCH();

@@ -532,28 +532,37 @@ void* bwd_scratch(const D& d, void* scratch) {
 }
 // A data gradient dy @ W whose consumer is the backward of the InstanceNorm that fed the projection: when a frame is one
 // 144-row GEMM tile the two run as ONE kernel (gemm_frame.hip); otherwise GEMM into `tmp`, then the InstanceNorm backward.
-struct InFuse { const void* x; const void* add; void* dx; const float* mean; const float* rstd; const float* w; const float* b; float* ws; };
+struct InFuse { const void* x; const void* add; void* dx; const float* mean; const float* rstd; const float* w; const float* b; float* ws;
+                const float* fscale = nullptr; int fdiv = 1; };      // fscale: optional per-frame-group factor on dy (stochastic depth)
 int dgrad_inbwd(const D& d, const void* dy, int Kdim, const void* w_xc, int Nout, void* tmp, const InFuse& f, hipStream_t st) {
-    const int rc = bf_gemm_inbwd_frames(d.dtype, (int)d.N, Nout, Kdim, dy, Kdim, w_xc, Nout, f.x, f.add, f.dx, (int)d.S, f.mean, f.rstd, f.w, f.ws, st);
+    const int rc = bf_gemm_inbwd_frames(d.dtype, (int)d.N, Nout, Kdim, dy, Kdim, w_xc, Nout, f.x, f.add, f.dx, (int)d.S, f.mean, f.rstd, f.w, f.ws,
+                                        f.fscale, f.fdiv, st);
     if (rc <= 0) return rc;
     bf_operand A = op_plain(dy, Kdim, BF_LAY_KC);
     bf_operand Bo = op_plain(w_xc, Nout, BF_LAY_XC);
     bf_epilogue e = epi_store(tmp, Nout);
+    if (f.fscale) { e.rowscale = f.fscale; e.rows_per_group = (int)(d.S * f.fdiv); }
     TRY(bf_gemm(d.dtype, (int)d.N, Nout, Kdim, &A, &Bo, &e, 1, st));
     return bf_in_bwd_partials(d.dtype, tmp, f.x, f.add, f.dx, (int)d.F, (int)d.S, Nout, f.mean, f.rstd, f.w, f.b, nullptr, 1, 0, f.ws, st);
 }
+bool side_frame_scale() { static const bool on = []() { const char* v = getenv("BF_SIDE_FRAME_SCALE"); return v && atoi(v) != 0; }(); return on; }
 // backward of the folded out-projection: param grads + don = (dout * alpha) @ W
 int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on, const void* w_s,
                 const float* W, const float* bias, const float* nb, const float* gamma, const float* lo, const float* hi,
                 const float* alpha, const float* mc, float* dW, float* dbias, float* dnb, float* dgamma, float* dlo, float* dhi,
-                void* don, hipStream_t st, Fork& fk, const InFuse* fu = nullptr) {
-    TRY(fk.run([=](hipStream_t ss) -> int {           // parameter-gradient side: memset, G GEMM, finalize
+                void* don, hipStream_t st, Fork& fk, const InFuse* fu = nullptr, const float* drop = nullptr, int fdiv = 1, void* dbr = nullptr) {
+    // drop (stochastic depth): the branch gradient is drop[f / fdiv] * dout.  The data-gradient path applies the factor inside its own
+    // kernel (fu->fscale / the GEMM epilogue's row factor); the parameter-gradient side needs the scaled tensor itself and makes it, on
+    // the SIDE stream, into `dbr` -- the caller's stream no longer pays a 2U pass and a fork bubble per stage for it.
+    TRY(fk.run([=](hipStream_t ss) -> int {           // parameter-gradient side: (scale,) G GEMM, finalize
+        const void* dsrc = dout;
+        if (drop) { TRY(bf_frame_scale(d.dtype, dout, drop, fdiv, dbr, d.N, (int)d.S, d.E, ss)); dsrc = dbr; }
         // G[n][k] = sum_m dout[m][n] * on[m][k]; `on` is the normalised operand the forward saved; dbeta = colsum(dout) from the same pass
-        const int trc = bf_gemm_tokred(d.dtype, d.E, d.E, d.N, dout, d.E, on, d.E, sc.G, 0, sc.csum, sc.tokred_ws, sc.tokred_floats, ss);
+        const int trc = bf_gemm_tokred(d.dtype, d.E, d.E, d.N, dsrc, d.E, on, d.E, sc.G, 0, sc.csum, sc.tokred_ws, sc.tokred_floats, ss);
         if (trc < 0) return trc;
         if (trc == 1) {
             ZERO_ON(ss, sc.G, (size_t)((char*)sc.csum - (char*)sc.G) + (size_t)d.E * 4);     // G and csum are adjacent in the arena: one memset
-            bf_operand A = op_plain(dout, d.E, BF_LAY_XC);
+            bf_operand A = op_plain(dsrc, d.E, BF_LAY_XC);
             bf_operand Bo = op_plain(on, d.E, BF_LAY_XC);
             bf_epilogue e = epi_atomic(sc.G, d.E);
             e.colsum = sc.csum;                  // dbeta = colsum(dout), fused into the same pass over dout
@@ -564,11 +573,12 @@ int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on,
         BF_CHECK_LAUNCH();
         return 0;
     }));
-    if (fu) return dgrad_inbwd(d, dout, d.E, w_s, d.E, don, *fu, st);      // ... followed by norm2's backward
+    if (fu) { InFuse f2 = *fu; f2.fscale = drop; f2.fdiv = fdiv; return dgrad_inbwd(d, dout, d.E, w_s, d.E, don, f2, st); }      // ... followed by norm2's backward
     {   // don = (dout * alpha) @ W = dout @ (diag(alpha) W): the scaled weight was written by the forward's parameter prep
         bf_operand A = op_plain(dout, d.E, BF_LAY_KC);
         bf_operand Bo = op_plain(w_s, d.E, BF_LAY_XC);
         bf_epilogue e = epi_store(don, d.E);
+        if (drop) { e.rowscale = drop; e.rows_per_group = (int)(d.S * fdiv); }
         TRY(bf_gemm(d.dtype, (int)d.N, d.E, d.E, &A, &Bo, &e, 1, st));
     }
     return 0;
@@ -668,14 +678,20 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
     void* don = sc.t1;      // [N][E]
     void* dO = sc.t1b;      // [N][E]
     void* dqkv = sc.t3;     // [N][3E]
-    const void* dbr = dout; // gradient entering the attention branch
-    if (drop) {             // branch = drop[b] * (...): scale the incoming gradient once (2U pass), the rest is unchanged
+    // branch = drop[b] * (...): scale the incoming gradient once (2U pass), the rest is unchanged.  BF_SIDE_FRAME_SCALE=1 applies the
+    // factor inside the out-projection's backward kernels instead and makes the scaled tensor on the side stream (see outproj_bwd):
+    // 22 launches and fork bubbles fewer on the caller's stream, and SLOWER end to end (632 vs 649 samples/s: the side work of the stage
+    // starts a kernel earlier and lands on the fc2 / whole-frame data-gradient kernels, 65 -> 80 us and 41 -> 47 us) -- not the default.
+    const void* dbr = dout;
+    const bool side_fs = side_frame_scale();
+    if (drop && !side_fs) {
         TRY(bf_frame_scale(d.dtype, dout, drop, d.T, sc.t4, d.N, (int)d.S, d.E, st));
         dbr = sc.t4;
     }
     const InFuse fu2{sv.o, nullptr, dO, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, sc.in_ws2};      // don @ ... then norm2's backward -> dO
     TRY(outproj_bwd(d, sc, dbr, sv.on, sv.wout_s, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr,
-                    sv.alpha, sv.mc, g->output_head_w, g->output_head_b, nullptr, g->gamma, nullptr, nullptr, don, st, fk, &fu2));
+                    sv.alpha, sv.mc, g->output_head_w, g->output_head_b, nullptr, g->gamma, nullptr, nullptr, don, st, fk, &fu2,
+                    side_fs ? drop : nullptr, d.T, sc.t4));
     ReduceJobs jobs;        // parameter-gradient reductions, all launched together at the end
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws2, (int)d.F, d.E, p->norm2_w, p->norm2_b, nullptr, 1, g->norm2_w, g->norm2_b, nullptr, nullptr, nullptr, nullptr};
     {
@@ -866,7 +882,8 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     // folded out-projection
     void* don = sc.e6;
     const void* dbr = dx1;  // gradient entering the attention branch (dx1 itself continues down the residual)
-    if (drop_att) {
+    const bool side_fs = side_frame_scale();
+    if (drop_att && !side_fs) {
         TRY(bf_frame_scale(d.dtype, dx1, drop_att, 1, sc.e5, d.N, (int)d.S, d.E, st));
         dbr = sc.e5;
     }
@@ -875,7 +892,7 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     TRY(outproj_bwd(d, sc, dbr, sv.on, sv.wout_s, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att,
                     d.feat_scale ? p->low_freq_scalar : nullptr, d.feat_scale ? p->high_freq_scalar : nullptr, sv.alpha, sv.mc,
                     g->output_head_w, g->output_head_b, g->norm2_b, g->gamma_att, d.feat_scale ? g->low_freq_scalar : nullptr,
-                    d.feat_scale ? g->high_freq_scalar : nullptr, don, st, fk, &fu2));
+                    d.feat_scale ? g->high_freq_scalar : nullptr, don, st, fk, &fu2, side_fs ? drop_att : nullptr, 1, sc.e5));
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws2, (int)d.F, d.E, p->norm2_w, p->norm2_b, nullptr, 1, g->norm2_w, g->norm2_b, nullptr, nullptr, nullptr, nullptr};
     void* dqkv = sc.t3;
     {

@@ -57,14 +57,14 @@ def in_bwd(dy, x, frames, S, Cc, mean, rstd, w, b, add=None, g=None, gdiv=1, gel
     return dx, dw, db
 
 
-def gemm_inbwd_frames(A, B, x, S, mean, rstd, w, add=None):
+def gemm_inbwd_frames(A, B, x, S, mean, rstd, w, add=None, fscale=None, fdiv=1):
     """Fused data-gradient GEMM + InstanceNorm backward (whole-frame tiles): returns (dx, ws) or None when the shape is not covered."""
     M, K = A.shape
     N = B.shape[1]
     out = torch.empty(M, N, dtype=x.dtype, device=x.device)
     ws = torch.zeros((M // S) * N * 2, dtype=torch.float32, device=x.device)
     rc = L.lib().bf_gemm_inbwd_frames(_dt(x.dtype), M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(x), _p(add), _p(out), S, _p(mean),
-                                      _p(rstd), _p(w), _p(ws), _stream())
+                                      _p(rstd), _p(w), _p(ws), _p(fscale), fdiv, _stream())
     if rc == 1:
         return None
     L.check(rc, "bf_gemm_inbwd_frames")

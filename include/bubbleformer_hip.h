@@ -103,6 +103,7 @@ int bf_gemm(int dtype, int M, int N, int K, const bf_operand* A, const bf_operan
  * bf_gemm + bf_in_bwd; < 0 on error. */
 int bf_gemm_inbwd_frames(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, const void* x,
                          const void* add, void* out, int S, const float* mean, const float* rstd, const float* w, float* ws,
+                         const float* fscale /* optional: dy of frame f is multiplied by fscale[f / fdiv] (stochastic depth) */, int fdiv,
                          bf_stream_t stream);
 
 /* Token-reduction GEMM (weight gradient of a 1x1 conv / Linear: autograd of layers/attention.py:78,121,210,299, linear_layers.py:18-25):

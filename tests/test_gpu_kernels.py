@@ -303,6 +303,15 @@ def _check_gemm_inbwd_frames(K, Fr, Kd, N, with_add):
     K.gemm(torch.bfloat16, M, N, Kd, K.operand(A, Kd, K.L.BF_LAY_KC), K.operand(W, N, K.L.BF_LAY_XC), K.epilogue(dyb, N))
     dx2, dw2, db2 = K.in_bwd(dyb.view(Fr, S, N), x, Fr, S, N, mean, rstd, w, b, add=add.view(Fr, S, N) if with_add else None)
     assert _rel(dx.double(), dx2.view(M, N).double()) < 1.5e-2
+    # per-frame-group factor on dy (stochastic depth: the branch gradient of frame f is fscale[f / fdiv] * dy), applied to the accumulators
+    fdiv = 2
+    m = torch.tensor([0.0, 1.25, 1.25, 0.0, 1.25][:(Fr + fdiv - 1) // fdiv] * ((Fr + 9) // 10 + 1), device="cuda")[:(Fr + fdiv - 1) // fdiv].contiguous()
+    dx3, ws3 = K.gemm_inbwd_frames(A, W, x.view(M, N), S, mean, rstd, w, add=add, fscale=m, fdiv=fdiv)
+    mrow = m.repeat_interleave(fdiv)[:Fr].repeat_interleave(S)[:, None].double()
+    xr2 = x.double().requires_grad_(True)
+    y2 = torch.nn.functional.instance_norm(xr2.permute(0, 2, 1), weight=w.double(), bias=b.double(), eps=1e-5).permute(0, 2, 1)
+    (y2 * (dy * mrow).view(Fr, S, N)).sum().backward()
+    assert _rel(dx3.double(), xr2.grad.view(M, N) + (add.double() if with_add else 0.0)) < 6e-3
     # shapes outside the whole-frame form are refused, not mis-computed
     assert K.gemm_inbwd_frames(A[:S * 2], W, x.view(M, N)[:S * 2], 72, mean, rstd, w) is None
     assert K.gemm_inbwd_frames(A.float(), W.float(), x.view(M, N).float(), S, mean, rstd, w) is None
