@@ -92,15 +92,6 @@ __global__ void __launch_bounds__(512) stream_gemm_kernel(StreamArgs a) {
     const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)KS * (unsigned)(CHUNK * 2) + (unsigned)wave * 4096u);   // ... four pieces inside an A chunk
 
     int issued = 0;                                  // vector-memory operations this wave has issued so far (DMA, loads, stores)
-    {   // the resident column block
-        const bf16* w0 = a.W + (long)c_nb * BNB * a.ldw;
-        for (int kb = 0; kb < KS; ++kb) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) glds16(w0 + roffB[t] + kb * BK, ldsB + (unsigned)kb * (unsigned)(CHUNK * 2) + t * 1024u);
-        }
-        issued += 2 * KS;
-    }
-
     // ---- DMA issue cursor (one chunk in front of the compute loop, across tile boundaries)
     int i_ks = 0, i_left = total_steps, i_slot = 0;
     const bf16* i_row = a.A + (long)((a.dbg & 2) ? 0 : t_beg) * BM * a.lda;
@@ -136,8 +127,26 @@ __global__ void __launch_bounds__(512) stream_gemm_kernel(StreamArgs a) {
             }
     }
 
+    // ---- prologue: the resident column block and the first two token chunks, interleaved so that step 0 needs only {W chunk 0, A
+    // chunk 0} and step 1 only {W chunk 1, A chunk 1}: the rest of the block (80 KB) lands under the first two steps instead of in
+    // front of them.  bmark[kb] / mark: `issued` right after W chunk kb / the A chunk of the step being waited for went out.
+    int bmark[6];
+    const bf16* w0 = a.W + (long)c_nb * BNB * a.ldw;
+    auto load_W = [&](int kb) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) glds16(w0 + roffB[t] + kb * BK, ldsB + (unsigned)kb * (unsigned)(CHUNK * 2) + t * 1024u);
+        issued += 2;
+        return issued;
+    };
+    bmark[0] = load_W(0);
     issue_A();
-    int mark = issued;                               // `issued` right after the chunk of the step being waited for went out
+    int mark = issued, mark_next = issued;
+    bmark[1] = load_W(1);
+    const bool pre1 = i_left > 0;                    // the second chunk goes out here too (its slot is free): step 0 then issues nothing
+    if (pre1) { issue_A(); mark_next = issued; }
+#pragma unroll
+    for (int kb = 2; kb < 6; ++kb) bmark[kb] = kb < KS ? load_W(kb) : issued;
+    bool first_tile = true;
 
     f32x4 acc[4][4];
     uint4 auxr[4][2];
@@ -152,7 +161,9 @@ __global__ void __launch_bounds__(512) stream_gemm_kernel(StreamArgs a) {
 #pragma unroll
             for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int ks = 0; ks < KS; ++ks) {
-            if (!(a.dbg & 1)) wait_vm_n(issued - mark);      // chunk of this step (and everything older, the resident block included) has landed
+            int need = mark;                         // this step's A chunk and, during the first tile, its W chunk (everything older included)
+            if (first_tile) { const int bm = ks == 0 ? bmark[0] : ks == 1 ? bmark[1] : ks == 2 ? bmark[2] : ks == 3 ? bmark[3] : ks == 4 ? bmark[4] : bmark[5]; need = max(need, bm); }
+            if (!(a.dbg & 1)) wait_vm_n(issued - need);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();            // ... for every wave; and nobody reads the previous step's slot any more
             if (ks == 0) {                           // this tile's residual / gelu' operand and row factors: issued BEFORE the younger DMAs, in
@@ -175,13 +186,14 @@ __global__ void __launch_bounds__(512) stream_gemm_kernel(StreamArgs a) {
             // K-half (BF_STREAM_STAGGER, default on): the two waves of a SIMD then do not both spend the same ~400 cycles issuing DMA
             // while the matrix pipe idles (MI355X_MICROARCH.md "Two waves per SIMD", item 9: split roles by wave >= 4)
             const bool late = a.stagger && wave >= 4;
-            if (!late) { if (i_left > 0 && !(a.dbg & 32)) issue_A(); mark = issued; }
+            const bool skip = first_tile && ks == 0 && pre1;      // the prologue already sent this step's look-ahead chunk
+            if (!late && !skip) { if (i_left > 0 && !(a.dbg & 32)) issue_A(); mark_next = issued; }
             const bf16* cA = ring + (size_t)slot * ACHUNK;
             const bf16* cB = Bres + (size_t)ks * CHUNK;
             if (!(a.dbg & 4))
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 32) {
-                if (kk == 32 && late) { if (i_left > 0 && !(a.dbg & 32)) issue_A(); mark = issued; }
+                if (kk == 32 && late && !skip) { if (i_left > 0 && !(a.dbg & 32)) issue_A(); mark_next = issued; }
                 bf16x8 fa[4], fb[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) fa[i] = frag_bf16<false, BK>(cA, wm * 64 + i * 16, kk, lane);
@@ -193,7 +205,9 @@ __global__ void __launch_bounds__(512) stream_gemm_kernel(StreamArgs a) {
                     for (int jn = 0; jn < 4; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[jn], fa[i], acc[i][jn], 0, 0, 0);
             }
             slot ^= 1;
+            mark = mark_next;
         }
+        first_tile = false;
         // ---- epilogue of the tile, from registers.  acc[i][jn]: row 16i + li, columns 16jn + 4lg .. +3.  After exchanging the odd lane
         // rows of tile 2pp with the even lane rows of tile 2pp + 1 a lane holds 8 consecutive columns at c8 + 32pp.
         if (AUX != BF_AUX_NONE || has_rs) {
