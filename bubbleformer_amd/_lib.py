@@ -73,6 +73,11 @@ SIGNATURES = {
     "bf_side_defer": (None, [C.c_int]),
     "bf_prep_stages": (C.c_int, [C.POINTER(Dims), C.c_int, C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]),
     "bf_stage_prepared": (None, [C.c_int]),
+    "bf_trunk_eval_weights_bytes": (i64, [C.POINTER(Dims), C.c_int, C.POINTER(C.c_int32)]),
+    "bf_trunk_eval_prepare": (C.c_int, [C.POINTER(Dims), C.c_int, C.POINTER(C.c_int32), C.POINTER(vp), vp, vp]),
+    "bf_trunk_eval_fwd": (C.c_int, [C.POINTER(Dims), C.c_int, C.POINTER(C.c_int32), C.POINTER(vp), vp, vp, vp, vp, vp]),
+    "bf_frame_linear": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, fp, fp, fp, fp, fp, vp, i64, C.c_int, fp, fp, fp,
+                                  vp, i64, vp]),
     "bf_side_join": (C.c_int, [vp]),
     "bf_prof_report": (C.c_int, [C.c_char_p, C.c_int]),
     "bf_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, P(Operand), P(Operand), P(Epilogue), C.c_int, vp]),

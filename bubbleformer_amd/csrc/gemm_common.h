@@ -169,8 +169,8 @@ __device__ __forceinline__ void epilogue_rows(const f32x4 (&acc)[TM][TN], const 
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const f32x4 a = acc[p * SUB + ii][j];
-                const float4 v = make_float4((a[0] + cb[j][0]) * cs[j][0] + ch[j][0], (a[1] + cb[j][1]) * cs[j][1] + ch[j][1],
-                                             (a[2] + cb[j][2]) * cs[j][2] + ch[j][2], (a[3] + cb[j][3]) * cs[j][3] + ch[j][3]);
+                const float4 v = make_float4(fmaf(a[0] + cb[j][0], cs[j][0], ch[j][0]), fmaf(a[1] + cb[j][1], cs[j][1], ch[j][1]),
+                                             fmaf(a[2] + cb[j][2], cs[j][2], ch[j][2]), fmaf(a[3] + cb[j][3], cs[j][3], ch[j][3]));      // explicit fma: the kernels agree bit for bit
                 *reinterpret_cast<float4*>(stg + ((wm * SUB + ii) * 16 + li) * LDS_ + wn * (16 * TN) + j * 16 + 4 * lg) = v;
             }
         __syncthreads();

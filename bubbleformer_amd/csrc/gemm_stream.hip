@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(512) stream_gemm_kernel(StreamArgs a) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     v[q] += e_bias[pp][q];
-                    if constexpr (CS) v[q] = (v[q] * e_cs[pp][q] + e_ch[pp][q]) * (has_rs ? rsr[i] : 1.f);
+                    if constexpr (CS) v[q] = fmaf(v[q], e_cs[pp][q], e_ch[pp][q]) * (has_rs ? rsr[i] : 1.f);
                 }
                 if constexpr (AUX != BF_AUX_NONE) {
                     const bf16x8 ax = __builtin_bit_cast(bf16x8, auxr[i][pp]);

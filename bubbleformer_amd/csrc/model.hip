@@ -916,6 +916,135 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     return fk.join();
 }
 
+// ================================================================================================= inference forward of the trunk
+// Eval forward of n trunk stages in one call (scripts/inference.py:239-252: FiLMConditionedAViT.forward under torch.no_grad, one clip at a
+// time): nothing is saved for a backward, the InstanceNorms ride inside the whole-frame projection kernels (frame_fwd.hip) and the bf16
+// weight copies / out-projection folds live in a caller-owned arena that is prepared ONCE per set of weights, not once per forward.
+namespace {
+struct EvalStage {       // one stage's slice of the arena
+    void *win_c, *wout_c, *w1_c, *w2_c; float *alpha, *beta, *mc;
+    size_t bytes;
+    EvalStage(const D& d, int kind, void* base) {
+        Arena a(base);
+        alpha = a.f32(d.E); beta = a.f32(d.E); mc = a.f32(d.E);
+        win_c = a.take((size_t)3 * d.E * d.E * 2);
+        wout_c = a.take((size_t)d.E * d.E * 2);
+        w1_c = kind == 1 ? a.take((size_t)4 * d.E * d.E * 2) : nullptr;
+        w2_c = kind == 1 ? a.take((size_t)4 * d.E * d.E * 2) : nullptr;
+        bytes = a.off;
+    }
+};
+bool trunk_eval_covers(const D& d) { return d.dtype == BF_DTYPE_BF16 && d.S == 144 && d.E == 384 && d.h <= 16 && d.w <= 16 && d.T <= 32; }
+}  // namespace
+
+extern "C" int64_t bf_trunk_eval_weights_bytes(const bf_dims* dims, int n, const int32_t* kinds) {
+    D d; if (get_dims(dims, &d) || n < 1 || !kinds) return -1;
+    int64_t t = 0;
+    for (int i = 0; i < n; ++i) t += (int64_t)EvalStage(d, kinds[i], nullptr).bytes;
+    return t;
+}
+
+extern "C" int bf_trunk_eval_prepare(const bf_dims* dims, int n, const int32_t* kinds, const void* const* params, void* weights, bf_stream_t s) {
+    D d; TRY(get_dims(dims, &d));
+    BF_REQUIRE(n >= 1 && kinds && params && weights, "bf_trunk_eval_prepare: bad arguments");
+    if (!trunk_eval_covers(d)) return 1;
+    hipStream_t st = (hipStream_t)s;
+    char* base = (char*)weights;
+    for (int i0 = 0; i0 < n; i0 += PREP_BATCH) {
+        PrepBatch b;
+        memset(&b, 0, sizeof(b));
+        const int m = std::min(PREP_BATCH, n - i0);
+        for (int i = 0; i < m; ++i) {
+            BF_REQUIRE(params[i0 + i] && (kinds[i0 + i] == 0 || kinds[i0 + i] == 1), "bf_trunk_eval_prepare: bad stage entry");
+            EvalStage ev(d, kinds[i0 + i], base);
+            base += ev.bytes;
+            Cast4& j = b.j[i];
+            if (kinds[i0 + i] == 0) {
+                const bf_temporal_params* p = (const bf_temporal_params*)params[i0 + i];
+                const float* src[2] = {p->input_head_w, p->output_head_w};
+                void* dst[2] = {ev.win_c, ev.wout_c};
+                const long cn[2] = {3L * d.E * d.E, (long)d.E * d.E};
+                for (int q = 0; q < 4; ++q) { j.src[q] = src[q < 2 ? q : 0]; j.dst[q] = (bf16*)dst[q < 2 ? q : 0]; j.n[q] = q < 2 ? cn[q] : 0; }
+                b.cnt[i] = 2;
+                b.a[i] = PrepArgs{p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr, ev.alpha, ev.beta, ev.mc, d.E, nullptr, d.dtype,
+                                  nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0};
+            } else {
+                const bf_spatial_params* p = (const bf_spatial_params*)params[i0 + i];
+                const float* src[4] = {p->input_head_w, p->output_head_w, p->fc1_w, p->fc2_w};
+                void* dst[4] = {ev.win_c, ev.wout_c, ev.w1_c, ev.w2_c};
+                const long cn[4] = {3L * d.E * d.E, (long)d.E * d.E, 4L * d.E * d.E, 4L * d.E * d.E};
+                for (int q = 0; q < 4; ++q) { j.src[q] = src[q]; j.dst[q] = (bf16*)dst[q]; j.n[q] = cn[q]; }
+                b.cnt[i] = 4;
+                b.a[i] = PrepArgs{p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att, d.feat_scale ? p->low_freq_scalar : nullptr,
+                                  d.feat_scale ? p->high_freq_scalar : nullptr, ev.alpha, ev.beta, ev.mc, d.E, nullptr, d.dtype,
+                                  nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0};
+            }
+        }
+        hipLaunchKernelGGL(stage_prep_multi_kernel, dim3(std::max(64, d.E), 5, m), dim3(256), 0, st, b);
+        BF_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+// x, out: [N][E] tokens.  `weights`: the arena bf_trunk_eval_prepare filled for exactly these stages; `scratch`: bf_scratch_bytes.
+// Returns 0 when done, 1 when the shape is not covered (bf16, 144-token frames, E = 384): the caller then runs the stage forwards.
+extern "C" int bf_trunk_eval_fwd(const bf_dims* dims, int n, const int32_t* kinds, const void* const* params, const void* weights,
+                                 const void* x, void* out, void* scratch, bf_stream_t s) {
+    D d; TRY(get_dims(dims, &d));
+    BF_REQUIRE(n >= 1 && kinds && params && weights && x && out && scratch, "bf_trunk_eval_fwd: bad arguments");
+    if (!trunk_eval_covers(d)) return 1;
+    hipStream_t st = (hipStream_t)s;
+    TRY(side_join_pending(st));
+    Scratch sc(d, scratch);
+    const int F = (int)d.F, E = d.E;
+    void *qkv = sc.t3, *o = sc.t1, *on = sc.t1b, *x1 = sc.e5, *hid = sc.t4;
+    float* stat = sc.tokred_ws;                           // mean | rstd | sc | sh of the axial block's norm2, [F][E] each
+    BF_REQUIRE(sc.tokred_floats >= (int64_t)4 * F * E, "bf_trunk_eval_fwd: scratch too small");
+    const char* base = (const char*)weights;
+    const void* cur = x;
+    for (int i = 0; i < n; ++i) {
+        BF_REQUIRE(params[i] && (kinds[i] == 0 || kinds[i] == 1), "bf_trunk_eval_fwd: bad stage entry");
+        EvalStage ev(d, kinds[i], (void*)base);
+        base += ev.bytes;
+        void* nxt = i == n - 1 ? out : ((i & 1) ? sc.e7 : sc.e6);
+#define FRL(...) do { const int rc_ = bf_frame_linear(__VA_ARGS__); if (rc_ != 0) return rc_ < 0 ? rc_ : bf_fail_msg("bf_trunk_eval_fwd: frame kernel refused a covered shape", __FILE__, __LINE__); } while (0)
+        if (kinds[i] == 0) {
+            const bf_temporal_params* p = (const bf_temporal_params*)params[i];
+            FRL(d.dtype, F, 144, E, 3 * E, cur, E, ev.win_c, E, p->norm1_w, p->norm1_b, p->input_head_b, nullptr, nullptr, nullptr, 0, 0,
+                nullptr, nullptr, nullptr, qkv, 3L * E, s);
+            TRY(bf_attn_fwd(d.dtype, qkv, o, (long)d.B * d.S, d.T, d.S, (long)d.T * d.S, 1, d.S, d.heads, d.d, p->qnorm_w, p->qnorm_b,
+                            p->knorm_w, p->knorm_b, p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor : nullptr, 1.f, 0, st));
+            FRL(d.dtype, F, 144, E, E, o, E, ev.wout_c, E, p->norm2_w, p->norm2_b, nullptr, ev.alpha, ev.beta, cur, E, 0,
+                nullptr, nullptr, nullptr, nxt, E, s);
+        } else {
+            const bf_spatial_params* p = (const bf_spatial_params*)params[i];
+            FRL(d.dtype, F, 144, E, 3 * E, cur, E, ev.win_c, E, p->norm1_w, p->norm1_b, p->input_head_b, nullptr, nullptr, nullptr, 0, 0,
+                nullptr, nullptr, nullptr, qkv, 3L * E, s);
+            const int rc = bf_attn_axial_norm_fwd(d.dtype, qkv, o, on, d.F, (int)d.h, (int)d.w, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w,
+                                                  p->knorm_b, p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_x : nullptr,
+                                                  d.attn_scale ? p->attn_scale_factor_y : nullptr, p->norm2_w, p->norm2_b, stat, stat + (size_t)F * E,
+                                                  stat + (size_t)2 * F * E, stat + (size_t)3 * F * E, st);
+            if (rc < 0) return rc;
+            if (rc == 1) {      // the one-launch attention + norm2 form refused: attention, then norm2 inside the out-projection
+                TRY(bf_attn_axial_fwd(d.dtype, qkv, o, d.F, (int)d.h, (int)d.w, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
+                                      p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_x : nullptr, d.attn_scale ? p->attn_scale_factor_y : nullptr, st));
+                FRL(d.dtype, F, 144, E, E, o, E, ev.wout_c, E, p->norm2_w, p->norm2_b, nullptr, ev.alpha, ev.beta, cur, E, 0,
+                    nullptr, nullptr, nullptr, x1, E, s);
+            } else {
+                FRL(d.dtype, F, 144, E, E, on, E, ev.wout_c, E, nullptr, nullptr, nullptr, ev.alpha, ev.beta, cur, E, 0,
+                    nullptr, nullptr, nullptr, x1, E, s);
+            }
+            FRL(d.dtype, F, 144, E, 4 * E, x1, E, ev.w1_c, E, nullptr, nullptr, p->fc1_b, nullptr, nullptr, nullptr, 0, 1,
+                nullptr, nullptr, nullptr, hid, 4L * E, s);
+            FRL(d.dtype, F, 144, 4 * E, E, hid, 4L * E, ev.w2_c, 4L * E, nullptr, nullptr, p->fc2_b, nullptr, nullptr, x1, E, 0,
+                p->mlp_norm_w, p->mlp_norm_b, p->gamma_mlp, nxt, E, s);
+        }
+#undef FRL
+        cur = nxt;
+    }
+    return 0;
+}
+
 // ================================================================================================= patch embed (+ FiLM)
 namespace {
 inline int roundup(int v, int m) { return (v + m - 1) / m * m; }

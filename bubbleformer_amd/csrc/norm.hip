@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(NT) in_stats_kernel(const T* __restrict__ x, i
         for (int q = 0; q < MAXR; ++q) {
             if (cv && rg + RG * q < S) {
 #pragma unroll
-                for (int j = 0; j < CH; ++j) { const float d = keep[q].get(j) - mu[j]; acc[0][j] += d * d; }
+                for (int j = 0; j < CH; ++j) { const float d = keep[q].get(j) - mu[j]; acc[0][j] = fmaf(d, d, acc[0][j]); }      // explicit fma: frame_fwd.hip sums the same way, bit for bit
             }
         }
     } else if (cv) {
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(NT) in_stats_kernel(const T* __restrict__ x, i
             Chunk<T> v;
             v.load(xf + (long)s * C);
 #pragma unroll
-            for (int j = 0; j < CH; ++j) { const float d = v.get(j) - mu[j]; acc[0][j] += d * d; }
+            for (int j = 0; j < CH; ++j) { const float d = v.get(j) - mu[j]; acc[0][j] = fmaf(d, d, acc[0][j]); }
         }
     }
     reduce_rows<T, 1>(acc, sm);
@@ -148,12 +148,12 @@ __global__ void __launch_bounds__(NT) in_stats_kernel(const T* __restrict__ x, i
             const float r = rsqrtf(acc[0][j] / (float)S + BF_IN_EPS);
             const long o = (long)f * C + c + j;
             float a = r * w[c + j];
-            float s0 = b[c + j] - mu[j] * a;
+            float s0 = fmaf(-mu[j], a, b[c + j]);
             if (g) {                      // optional per-(frame group, channel) post scale/shift (FiLM, layer scale)
                 const long gi = (long)(f / gdiv) * C + c + j;
                 const float gg = g[gi];
                 a *= gg;
-                s0 = s0 * gg + (gb ? gb[gi] : 0.f);
+                s0 = fmaf(s0, gg, gb ? gb[gi] : 0.f);
             }
             aa[j] = a; ss[j] = s0;
             if (rg == 0) { mean[o] = mu[j]; rstd[o] = r; sc[o] = a; sh[o] = s0; }
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(NT) in_stats_kernel(const T* __restrict__ x, i
                     Chunk<T> rr, oo;
                     if (resid) rr.load(resid + off);
 #pragma unroll
-                    for (int j = 0; j < CH; ++j) oo.set(j, keep[q].get(j) * aa[j] + ss[j] + (resid ? rr.get(j) : 0.f));
+                    for (int j = 0; j < CH; ++j) oo.set(j, fmaf(keep[q].get(j), aa[j], ss[j]) + (resid ? rr.get(j) : 0.f));
                     oo.store(out + off);
                 }
             }
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(NT) affine_apply_kernel(const T* __restrict__ 
         }
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            float t = v.get(j) * a[j] + b[j];
+            float t = fmaf(v.get(j), a[j], b[j]);
             if (resid) t += r.get(j);
             o.set(j, t);
         }

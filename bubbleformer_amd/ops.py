@@ -229,6 +229,62 @@ def discard_prepared() -> None:
     _PREPARED.clear()
 
 
+# ------------------------------------------------------------------------------------------------ inference forward of the trunk
+_EVAL_ARENAS: dict = {}     # (device, parameter pointers, dims) -> [weights stamp, arena]: bf16 weight copies + out-projection folds
+_WEIGHTS_EPOCH = [0]        # bumped by this package's own in-place optimizer kernels (they write parameters behind torch's version counters)
+
+
+def _weights_changed() -> None:
+    _WEIGHTS_EPOCH[0] += 1
+
+
+def clear_eval_weights() -> None:
+    """Drop the prepared inference weights (they are re-made on the next eval forward).  Needed only after parameters were rewritten
+    through raw pointers by code outside this package; torch in-place ops and ops.adamw_ / ops.lion_ are noticed by themselves."""
+    _EVAL_ARENAS.clear()
+
+
+def trunk_eval(tok: torch.Tensor, heads: int, attn_scale: bool, feat_scale: bool, stages) -> Optional[torch.Tensor]:
+    """Eval forward of all trunk stages in ONE native call (bf_trunk_eval_fwd: whole-frame projection kernels with the InstanceNorms
+    inside, nothing saved for a backward).  stages: [(kind, params)] in call order.  The bf16 weight copies and out-projection folds
+    are prepared once per set of weights (torch version counters + this package's optimizer epoch) and kept per model.
+    Returns None when the path does not apply (not bf16 on the GPU, shape not covered, BF_TRUNK_EVAL=0): the caller then runs the
+    stage forwards.  Under HIP-graph capture the preparation must already have happened (utils/rollout.py warms up first)."""
+    if not tok.is_cuda or tok.dtype != torch.bfloat16 or not stages or os.environ.get("BF_TRUNK_EVAL", "1") == "0":
+        return None
+    tok = tok.contiguous()
+    B, T, h, w, E = tok.shape
+    d = make_dims(tok.dtype, B, T, h, w, E, heads, attn_scale, feat_scale)
+    lib = L.lib()
+    n = len(stages)
+    kinds = (C.c_int32 * n)(*[0 if kind == "temporal" else 1 for kind, _ in stages])
+    plist = [[_f32c(p) for p in params] for _, params in stages]
+    structs = [(L.TemporalParams if kind == "temporal" else L.SpatialParams)(*[_p(p) for p in ps]) for (kind, _), ps in zip(stages, plist)]
+    pp = (C.c_void_p * n)(*[C.addressof(s) for s in structs])
+    flat = [p for ps in plist for p in ps if p is not None]
+    key = (str(tok.device), tuple(p.data_ptr() for p in flat), h, w, E, heads, bool(attn_scale), bool(feat_scale))
+    stamp = (_WEIGHTS_EPOCH[0], tuple(p._version for p in flat))
+    ent = _EVAL_ARENAS.get(key)
+    if ent is None or ent[0] != stamp:
+        if torch.cuda.is_current_stream_capturing() and ent is None:
+            raise L.BubbleformerHipError("trunk_eval: run one eval forward before capturing it in a HIP graph (the weights are prepared on the first call)")
+        nbytes = lib.bf_trunk_eval_weights_bytes(C.byref(d), n, kinds)
+        arena = ent[1] if ent is not None else _saved(nbytes, tok.device, "bf_trunk_eval_weights_bytes")
+        rc = lib.bf_trunk_eval_prepare(C.byref(d), n, kinds, pp, _p(arena), _stream())
+        if rc == 1:
+            return None
+        L.check(rc, "bf_trunk_eval_prepare")
+        if len(_EVAL_ARENAS) > 8:
+            _EVAL_ARENAS.clear()
+        ent = _EVAL_ARENAS[key] = [stamp, arena]
+    out = torch.empty_like(tok)
+    rc = lib.bf_trunk_eval_fwd(C.byref(d), n, kinds, pp, _p(ent[1]), _p(tok), _p(out), _p(scratch_for(d, tok.device)), _stream())
+    if rc == 1:
+        return None
+    L.check(rc, "bf_trunk_eval_fwd")
+    return out
+
+
 class _BlockFn(torch.autograd.Function):
     """Shared driver for the temporal and the axial block."""
 
@@ -578,6 +634,7 @@ def lion_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, lr: float, betas=(0
     _require_gpu(p)
     L.check(L.lib().bf_lion(_p(p), _p(g), _p(m), p.numel(), float(lr), float(betas[0]), float(betas[1]), float(weight_decay),
                             float(grad_scale), _stream()), "bf_lion")
+    _weights_changed()
 
 
 def adamw_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float, betas=(0.9, 0.999),
@@ -586,3 +643,4 @@ def adamw_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, s
     _require_gpu(p)
     L.check(L.lib().bf_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), int(step), float(lr), float(betas[0]), float(betas[1]), float(eps),
                              float(weight_decay), float(grad_scale), _stream()), "bf_adamw")
+    _weights_changed()

@@ -20,6 +20,7 @@
  *                              layers/attention.py:78,121,210,299; linear_layers.py:25;
  *                              layers/patching.py:36-44,92-100 (stages with C >= 8)
  *   bf_in_stats / bf_in_bwd .. nn.InstanceNorm2d(affine): layers/attention.py:77,120,208,298,316
+ *   bf_frame_linear / bf_trunk_eval_*  the same layers' forward in eval mode, whole-frame tiles (scripts/inference.py:239-252)
  *   bf_gemm_tokred ........... weight gradients of the same layers (autograd); bf_gemm_inbwd_frames: their data gradient + InstanceNorm backward
  *   bf_attn_fwd / bf_attn_bwd  AttentionBlock.forward attention core: layers/attention.py:80-119 (and each axial pass)
  *   bf_attn_axial_fwd / bf_attn_axial_norm_fwd  AxialAttentionBlock.forward attention core: layers/attention.py:212-297
@@ -115,6 +116,21 @@ int bf_gemm_inbwd_frames(int dtype, int M, int N, int K, const void* A, int64_t 
 int bf_gemm_tokred(int dtype, int Nout, int Kin, int64_t M, const void* dy, int64_t ldy, const void* x, int64_t ldx, float* out,
                    int accumulate, float* colsum, float* ws, int64_t ws_floats, bf_stream_t stream);
 int64_t bf_gemm_tokred_ws_floats(int Nout, int Kin, int64_t M);
+
+/* Whole-frame forward projection for inference (frame_fwd.hip): out[f*S + s][:] = epi( IN(A)[f*S + s][:K] @ W[:N][:K]^T ), one workgroup
+ * per (frame of S = 144 tokens, block of output columns).  Replaces, in ONE launch each, the pairs the reference runs as separate modules:
+ *   norm_w/norm_b != NULL: nn.InstanceNorm2d(affine) in front of the 1x1 conv (layers/attention.py:77-78 / 208-210 norm1 + input_head,
+ *     120-121 norm2 + output_head); K = 384 only (the frame's operand is LDS-resident);
+ *   en_w/en_b/en_g != NULL: the InstanceNorm behind fc2 with layer scale and residual, out = resid + en_g * IN(A @ W^T + bias)
+ *     (layers/attention.py:316-322);
+ *   otherwise v = acc + bias; v = v * colscale + colshift (if given); v += resid (if given); v = gelu(v) (if gelu).
+ * A [frames*S][lda], W [N][ldw] (K-contiguous), resid / out [frames*S][ld*], all bf16.  Statistics are summed in bf_in_stats' order and
+ * the products in bf_gemm's: results equal the separate launches bit for bit.  Returns 0 when done, 1 when the shape is not covered
+ * (bf16, S = 144, N % 32 = 0, K = 384 or (no norm in front) K % 64 = 0), < 0 on error. */
+int bf_frame_linear(int dtype, int frames, int S, int K, int N, const void* A, int64_t lda, const void* W, int64_t ldw,
+                    const float* norm_w, const float* norm_b, const float* bias, const float* colscale, const float* colshift,
+                    const void* resid, int64_t ldr, int gelu, const float* en_w, const float* en_b, const float* en_g,
+                    void* out, int64_t ldo, bf_stream_t stream);
 
 /* ---------------------------------------------------------------- kernel-level entry points (unit-testable) */
 
@@ -282,6 +298,17 @@ int64_t bf_scratch_bytes(const bf_dims* d);
 int bf_prep_stages(const bf_dims* dims, int n, const int32_t* kinds, const void* const* params, void* const* saved,
                    const float* const* drop_mlp, bf_stream_t stream);
 void bf_stage_prepared(int on);
+/* Inference forward of n trunk stages in one call (scripts/inference.py:239-252 runs FiLMConditionedAViT.forward under no_grad, one clip
+ * at a time; the stages are SpaceTimeBlock's temporal and axial blocks, models/axial_vit.py:18-60).  Nothing is saved for a backward, the
+ * InstanceNorms run inside the whole-frame projection kernels (bf_frame_linear) and the bf16 weight copies / out-projection folds live in
+ * a caller-owned arena (bf_trunk_eval_weights_bytes) that bf_trunk_eval_prepare fills once per set of weights: call it again after the
+ * parameters change.  kinds / params as bf_prep_stages; x, out [N][E]; scratch: bf_scratch_bytes.  No stochastic depth (eval).
+ * bf_trunk_eval_prepare / _fwd return 0 when done, 1 when the shape is not covered (bf16, 12 x 12-token frames, E = 384: the caller then
+ * runs the stage forwards), < 0 on error. */
+int64_t bf_trunk_eval_weights_bytes(const bf_dims* dims, int n, const int32_t* kinds);
+int bf_trunk_eval_prepare(const bf_dims* dims, int n, const int32_t* kinds, const void* const* params, void* weights, bf_stream_t stream);
+int bf_trunk_eval_fwd(const bf_dims* dims, int n, const int32_t* kinds, const void* const* params, const void* weights, const void* x,
+                      void* out, void* scratch, bf_stream_t stream);
 /* x, out, dout, dx: [N][E] activations.  Gradients ACCUMULATE into `g` (zero it first). */
 /* Stochastic depth (timm DropPath at layers/attention.py:123,309,317): `drop*` are the per-sample factors (0 or 1/keep) the
  * caller drew -- [B] for the temporal block (dim 0 = batch), [B*T] each for the two branches of the axial block -- or NULL. */

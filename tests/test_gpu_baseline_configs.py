@@ -249,6 +249,50 @@ def test_config4_forward_in_hip_graph_and_rollout():
         assert torch.equal(cur, ref)
 
 
+@pytest.mark.parametrize("B", [1, 2])
+def test_config4_inference_trunk_equals_the_stage_forwards(B, monkeypatch):
+    """bs 1 inference takes the whole-trunk inference path (bf_trunk_eval_fwd: whole-frame projection kernels with the InstanceNorms
+    inside, weights prepared once): the prediction equals the stage-by-stage forward BIT FOR BIT (statistics are summed in
+    bf_in_stats' order, products in bf_gemm's), follows a parameter update (torch in-place op and this package's optimizer kernel),
+    and matches the oracle at the bf16 full-depth bound."""
+    import ctypes, json
+    from bubbleformer_amd import _lib as L, ops
+    T, H, W, seed = 16, 192, 192, 15
+    m = _model(seed, torch.bfloat16, T).eval()
+    x, _, c = (t.cuda() for t in _inputs(B, T, H, W, seed))
+    h = L.lib()
+    with torch.no_grad():
+        h.bf_prof_enable(1)
+        fast = m(x, c)
+        torch.cuda.synchronize()
+        buf = ctypes.create_string_buffer(1 << 14)
+        h.bf_prof_report(buf, len(buf))
+        h.bf_prof_enable(0)
+        names = json.loads(buf.value.decode())
+        assert any(k.startswith("frame_linear") for k in names) and not any(k.startswith("in_stats") and names[k]["calls"] > 12 for k in names), names.keys()
+        monkeypatch.setenv("BF_TRUNK_EVAL", "0")
+        slow = m(x, c)
+        monkeypatch.delenv("BF_TRUNK_EVAL")
+        assert torch.equal(fast, slow), "fraction of differing elements: %g" % float((fast != slow).float().mean())
+        if B == 1:
+            pred_o, _, _, _ = _oracle(B, T, H, W, seed, grads=False)
+            assert rel_l2(fast.cpu(), pred_o) < 8e-2
+        # the prepared weights follow the parameters
+        p = m.blocks[3].spatial.mlp.fc1.weight
+        p.mul_(1.5)
+        f2 = m(x, c)
+        monkeypatch.setenv("BF_TRUNK_EVAL", "0")
+        s2 = m(x, c)
+        monkeypatch.delenv("BF_TRUNK_EVAL")
+        assert torch.equal(f2, s2) and not torch.equal(f2, fast)
+        q = m.blocks[5].temporal.output_head.weight
+        ops.adamw_(q.view(-1), torch.ones_like(q).view(-1), torch.zeros_like(q).view(-1), torch.zeros_like(q).view(-1), 1, 0.05)
+        f3 = m(x, c)
+        monkeypatch.setenv("BF_TRUNK_EVAL", "0")
+        s3 = m(x, c)
+        assert torch.equal(f3, s3) and not torch.equal(f3, f2)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_film_avit_big_width(dtype):
     """`film_avit_big` width (E = 768, 12 heads of 64; config/model_cfg/film_avit_big.yaml) through the same kernels: 3 blocks,

@@ -127,6 +127,92 @@ def test_gemm_stream_weight_stationary(K, M, N, K_, variant):
     assert float(((c.float() - ref).abs() / (ref.abs() + 0.05 * ref.abs().mean())).max()) < (0.1 if variant == "dgelu" else 0.05)
 
 
+@pytest.mark.parametrize("frames,N", [(16, 1152), (3, 1152), (12, 1024), (16, 384), (128, 1536)])
+@pytest.mark.parametrize("variant", ["norm_bias", "norm_fold_resid", "plain_fold_resid", "gelu"])
+def test_frame_linear_equals_the_separate_launches(K, frames, N, variant):
+    """Whole-frame inference projection (frame_fwd.hip, K = 384 resident form; column blocks of 96 / 64 / 32): the InstanceNorm in front,
+    bias, out-projection fold + residual and GELU against fp32 torch on the same bf16 operands, and BIT FOR BIT against the launches it
+    replaces (bf_in_stats + bf_affine_apply, then bf_gemm with the same epilogue)."""
+    from bubbleformer_amd import _lib as L
+    if frames == 128 and variant != "gelu":
+        pytest.skip("large batch once")
+    dt = torch.bfloat16
+    S, E = 144, 384
+    M = frames * S
+    g = torch.Generator(device="cuda").manual_seed(21)
+    a = (torch.randn(M, E, device="cuda", generator=g) * 1.5 + 0.7 * torch.randn(1, E, device="cuda", generator=g)).to(dt)
+    w = (torch.randn(N, E, device="cuda", generator=g) * 0.1).to(dt)
+    nw = 1 + 0.3 * torch.randn(E, device="cuda", generator=g); nb = 0.3 * torch.randn(E, device="cuda", generator=g)
+    bias = torch.randn(N, device="cuda", generator=g)
+    cs = torch.randn(N, device="cuda", generator=g); ch = torch.randn(N, device="cuda", generator=g)
+    resid = torch.randn(M, N, device="cuda", generator=g).to(dt)
+    norm = variant.startswith("norm")
+    if norm:
+        mean, rstd, sc, sh = K.in_stats(a, frames, S, E, nw, nb)
+        xn = torch.empty_like(a)
+        L.check(L.lib().bf_affine_apply(L.BF_DTYPE_BF16, a.data_ptr(), None, sc.data_ptr(), sh.data_ptr(), xn.data_ptr(), M, S, E, torch.cuda.current_stream().cuda_stream), "affine")
+        af = a.float().view(frames, S, E)
+        ref_in = ((af - af.mean(1, keepdim=True)) * torch.rsqrt(af.var(1, unbiased=False, keepdim=True) + 1e-5) * nw + nb).view(M, E)
+    else:
+        xn, ref_in = a, a.float()
+    sep = torch.full((M, N), float("nan"), device="cuda", dtype=dt)
+    ref = ref_in @ w.float().t()
+    if variant == "norm_bias":
+        got = K.frame_linear(a, w, frames, S, norm=(nw, nb), bias=bias)
+        K.gemm(dt, M, N, E, K.operand(xn, E), K.operand(w, E), K.epilogue(sep, N, bias=bias))
+        ref = ref + bias
+    elif variant in ("norm_fold_resid", "plain_fold_resid"):
+        got = K.frame_linear(a, w, frames, S, norm=(nw, nb) if norm else None, colscale=cs, colshift=ch, resid=resid)
+        K.gemm(dt, M, N, E, K.operand(xn, E), K.operand(w, E), K.epilogue(sep, N, colscale=cs, colshift=ch, aux_mode=L.BF_AUX_ADD, aux=resid, ld_aux=N))
+        ref = ref * cs + ch + resid.float()
+    else:
+        got = K.frame_linear(a, w, frames, S, bias=bias, gelu=True)
+        pre = torch.empty_like(sep)
+        K.gemm(dt, M, N, E, K.operand(xn, E), K.operand(w, E), K.epilogue(pre, N, bias=bias, gelu_out=sep))
+        ref = torch.nn.functional.gelu(ref + bias)
+    assert got is not None, "bf_frame_linear refused a covered shape"
+    torch.cuda.synchronize()
+    assert torch.isfinite(got.float()).all()
+    assert _rel(got.float(), ref) < 6e-3
+    if "fold" not in variant:     # (the fold rescales and shifts the product: its element-wise check is the bit-equality below)
+        assert float(((got.float() - ref).abs() / (ref.abs() + 0.05 * ref.abs().mean())).max()) < 0.3      # the bf16 rounding of the normalised operand included
+    assert torch.equal(got, sep), "differs from the separate launches: %g of the elements" % float((got != sep).float().mean())
+
+
+@pytest.mark.parametrize("frames,N", [(16, 384), (3, 384), (64, 384), (24, 512)])
+def test_frame_linear_fc2_with_the_instance_norm_behind(K, frames, N):
+    """Streamed form (K = 4E = 1536, ring of operand slots) with the InstanceNorm of its own output in the epilogue:
+    out = resid + gamma * IN(hid @ W2^T + b2) against fp32 torch and bit for bit against bf_gemm -> bf_in_stats(g = gamma) -> bf_affine_apply."""
+    from bubbleformer_amd import _lib as L
+    dt = torch.bfloat16
+    S, Kd = 144, 1536
+    M = frames * S
+    g = torch.Generator(device="cuda").manual_seed(22)
+    hid = torch.randn(M, Kd, device="cuda", generator=g).to(dt)
+    w = (torch.randn(N, Kd, device="cuda", generator=g) * 0.05).to(dt)
+    bias = torch.randn(N, device="cuda", generator=g)
+    ew = 1 + 0.3 * torch.randn(N, device="cuda", generator=g); eb = 0.3 * torch.randn(N, device="cuda", generator=g)
+    eg = 0.5 * torch.randn(N, device="cuda", generator=g)
+    resid = torch.randn(M, N, device="cuda", generator=g).to(dt)
+    got = K.frame_linear(hid, w, frames, S, bias=bias, resid=resid, out_norm=(ew, eb, eg))
+    assert got is not None
+    z = torch.empty(M, N, device="cuda", dtype=dt)
+    K.gemm(dt, M, N, Kd, K.operand(hid, Kd), K.operand(w, Kd), K.epilogue(z, N, bias=bias))
+    mean, rstd, sc, sh = K.in_stats(z, frames, S, N, ew, eb, g=eg.view(1, N).contiguous(), gdiv=frames)
+    sep = torch.empty_like(z)
+    L.check(L.lib().bf_affine_apply(L.BF_DTYPE_BF16, z.data_ptr(), resid.data_ptr(), sc.data_ptr(), sh.data_ptr(), sep.data_ptr(), M, S, N, torch.cuda.current_stream().cuda_stream), "affine")
+    zf = (hid.float() @ w.float().t() + bias).view(frames, S, N)
+    ref = (resid.float().view(frames, S, N) + eg * ((zf - zf.mean(1, keepdim=True)) * torch.rsqrt(zf.var(1, unbiased=False, keepdim=True) + 1e-5) * ew + eb)).view(M, N)
+    torch.cuda.synchronize()
+    assert _rel(got.float(), ref) < 6e-3
+    assert torch.equal(got, sep), "differs from the separate launches: %g of the elements" % float((got != sep).float().mean())
+    # plain streamed form (no norm): bias + residual
+    got2 = K.frame_linear(hid, w, frames, S, bias=bias, resid=resid)
+    sep2 = torch.empty_like(z)
+    K.gemm(dt, M, N, Kd, K.operand(hid, Kd), K.operand(w, Kd), K.epilogue(sep2, N, bias=bias, aux_mode=L.BF_AUX_ADD, aux=resid, ld_aux=N))
+    assert torch.equal(got2, sep2)
+
+
 @pytest.mark.parametrize("Nout,Kin,M,with_cs", [(128, 128, 64, True), (384, 128, 64 * 7, True), (256, 384, 64 * 13, False),
                                                  (1152, 384, 2304, True)])
 def test_gemm_tokred_slabs_match_fp64_and_are_bit_reproducible(K, Nout, Kin, M, with_cs):
