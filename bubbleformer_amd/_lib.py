@@ -77,7 +77,7 @@ SIGNATURES = {
     "bf_trunk_eval_prepare": (C.c_int, [C.POINTER(Dims), C.c_int, C.POINTER(C.c_int32), C.POINTER(vp), vp, vp]),
     "bf_trunk_eval_fwd": (C.c_int, [C.POINTER(Dims), C.c_int, C.POINTER(C.c_int32), C.POINTER(vp), vp, vp, vp, vp, vp]),
     "bf_frame_linear": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, fp, fp, fp, fp, fp, vp, i64, C.c_int, fp, fp, fp,
-                                  vp, i64, vp]),
+                                  vp, i64, fp, fp, vp, i64, vp]),
     "bf_side_join": (C.c_int, [vp]),
     "bf_prof_report": (C.c_int, [C.c_char_p, C.c_int]),
     "bf_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, P(Operand), P(Operand), P(Epilogue), C.c_int, vp]),

@@ -33,6 +33,7 @@ struct FrameArgs {
     const bf16* resid; long ldr;                          // v += resid
     int gelu;                                             // v = gelu(v)
     const float* en_w; const float* en_b; const float* en_g;     // InstanceNorm behind: out = resid + en_g * IN(bf16(acc + bias))
+    const float* xw; const float* xb; bf16* xn; long ldx;        // second output: the NEXT layer's InstanceNorm of `out` (its norm1), xn = IN(out) * xw + xb
 };
 
 __device__ __forceinline__ void wait_vm_n(int n) {      // n is wave-uniform; a smaller count than asked for is always safe (in-order retirement)
@@ -99,6 +100,114 @@ __device__ __forceinline__ void frame_stats(const float (&x)[4][5][NJ], float (&
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) rs[j] = rsqrtf(tot[j] / (float)FS + BF_IN_EPS);
+}
+
+// Column statistics of a staged [144][LDZ] fp32 tile (values already rounded to the storage type), 8 columns per wave-task in
+// frame_stats' order, -> tab[c] = scale, tab[BN + c] = shift of the InstanceNorm affine (w, b, optional layer scale g).  Whole workgroup;
+// the caller brackets it with barriers.
+template <int BN, int LDZ>
+__device__ __forceinline__ void tile_col_stats(const float* zs, float* tab, const float* __restrict__ w, const float* __restrict__ b,
+                                               const float* __restrict__ g, int n0, int wave, int lane) {
+    const int rgp = lane >> 3, c8 = lane & 7;
+    for (int task = wave; task < BN / 8; task += NW) {
+        const int c = 8 * task + c8;
+        float x[4][5][1];
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4)
+#pragma unroll
+            for (int qq = 0; qq < 5; ++qq) x[w4][qq][0] = (w4 < 2 || qq < 4) ? zs[(8 * w4 + rgp + 32 * qq) * LDZ + c] : 0.f;
+        float mu[1], rs[1];
+        frame_stats<1>(x, mu, rs);
+        if (rgp == 0) {
+            float aa = rs[0] * w[n0 + c];
+            float s0 = fmaf(-mu[0], aa, b[n0 + c]);
+            if (g) { const float gg = g[n0 + c]; aa *= gg; s0 = fmaf(s0, gg, 0.f); }
+            tab[c] = aa; tab[BN + c] = s0;
+        }
+    }
+}
+
+// Epilogue of both kernel forms, from registers: acc[i][j][r] = row wm*48 + 16 i + li, column wn*16*NTC + 16 j + 4 lg + r of the tile.
+//   en_w:  z = bf16(acc + bias); v = IN(z) * en_w * en_g + ... + resid     (statistics over the tile's whole-frame columns)
+//   else:  v = acc + bias; v = v * cs + ch; v += resid; v = gelu(v)        (each step if given)
+//   xn:    second output bf16(IN(bf16(v)) * xw + xb): the next layer's norm1 of this tensor, again whole-frame columns
+// The operand images are dead when this runs; the staging tile and the 2 x BN table overlay them (the callers' LDS is large enough).
+template <int NTC>
+__device__ __forceinline__ void frame_epilogue(const FrameArgs& a, f32x4 (&acc)[3][NTC], const bf16x4 (&rx)[3][NTC], char* smem, int f, int n0,
+                                               int wave, int lane) {
+    constexpr int BN = 32 * NTC, LDZ = BN + 1;
+    const int wm = wave % 3, wn = wave / 3, li = lane & 15, lg = lane >> 4;
+    float* zs = reinterpret_cast<float*>(smem);          // [144][LDZ]
+    float* tab = zs + FS * LDZ;                          // [2][BN]
+    auto stage = [&]() {                                 // acc -> zs (values are storage-rounded already)
+#pragma unroll
+        for (int j = 0; j < NTC; ++j)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) zs[(wm * 48 + i * 16 + li) * LDZ + wn * (16 * NTC) + j * 16 + 4 * lg + r] = acc[i][j][r];
+    };
+    if (a.en_w) {
+#pragma unroll
+        for (int j = 0; j < NTC; ++j)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)       // the tensor in_stats_kernel reads in the separate-launch path is bf16
+                    acc[i][j][r] = (float)(bf16)(acc[i][j][r] + (a.bias ? a.bias[n0 + wn * (16 * NTC) + j * 16 + 4 * lg + r] : 0.f));
+        lds_barrier();                                   // every wave is done with the operand images
+        stage();
+        lds_barrier();
+        tile_col_stats<BN, LDZ>(zs, tab, a.en_w, a.en_b, a.en_g, n0, wave, lane);
+        lds_barrier();
+    }
+#pragma unroll
+    for (int j = 0; j < NTC; ++j) {
+        const int c = wn * (16 * NTC) + j * 16 + 4 * lg, n = n0 + c;
+        float cb[4], cs[4], ch[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { cb[r] = a.bias ? a.bias[n + r] : 0.f; cs[r] = a.cs ? a.cs[n + r] : 1.f; ch[r] = a.cs ? a.ch[n + r] : 0.f; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const long row = (long)f * FS + wm * 48 + i * 16 + li;
+            float v[4];
+            if (a.en_w) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[i][j][r], tab[c + r], tab[BN + c + r]) + (float)rx[i][j][r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[i][j][r] + cb[r];
+                    if (a.cs) v[r] = fmaf(v[r], cs[r], ch[r]);
+                    if (a.resid) v[r] = v[r] + (float)rx[i][j][r];
+                    if (a.gelu) v[r] = gelu_fast(v[r]);
+                }
+            }
+            const bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            *reinterpret_cast<bf16x4*>(a.out + row * a.ldo + n) = o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = (float)o[r];
+        }
+    }
+    if (a.xn) {
+        lds_barrier();                                   // operand images (or the first statistics round's reads) are done
+        stage();
+        lds_barrier();
+        tile_col_stats<BN, LDZ>(zs, tab, a.xw, a.xb, nullptr, n0, wave, lane);
+        lds_barrier();
+#pragma unroll
+        for (int j = 0; j < NTC; ++j) {
+            const int c = wn * (16 * NTC) + j * 16 + 4 * lg;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const long row = (long)f * FS + wm * 48 + i * 16 + li;
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (bf16)(fmaf(acc[i][j][r], tab[c + r], tab[BN + c + r]) + 0.f);
+                *reinterpret_cast<bf16x4*>(a.xn + row * a.ldx + n0 + c) = o;
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
@@ -213,43 +322,17 @@ __global__ void __launch_bounds__(NTHR) frame_res_kernel(FrameArgs a) {
                 for (int j = 0; j < NTC; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
     }
-    // ---- epilogue from registers: acc[i][j][r] = row wm*48 + 16 i + li, column wn*16*NTC + 16 j + 4 lg + r
+    // ---- epilogue
     wait_vm<0>();
+    bf16x4 rx[3][NTC];
     if (a.resid) {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < NTC; ++j) asm volatile("" : "+v"(rr[i][j].x), "+v"(rr[i][j].y));
+            for (int j = 0; j < NTC; ++j) { asm volatile("" : "+v"(rr[i][j].x), "+v"(rr[i][j].y)); rx[i][j] = __builtin_bit_cast(bf16x4, rr[i][j]); }
     }
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < NTC; ++j) {
-        const int n = n0 + wn * (16 * NTC) + j * 16 + 4 * lg;
-        float cb[4], cs[4], ch[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { cb[r] = a.bias ? a.bias[n + r] : 0.f; cs[r] = a.cs ? a.cs[n + r] : 1.f; ch[r] = a.cs ? a.ch[n + r] : 0.f; }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const long row = (long)f * FS + wm * 48 + i * 16 + li;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = acc[i][j][r] + cb[r];
-                if (a.cs) v[r] = fmaf(v[r], cs[r], ch[r]);
-            }
-            if (a.resid) {
-                const bf16x4 x4 = __builtin_bit_cast(bf16x4, rr[i][j]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] + (float)x4[r];
-            }
-            if (a.gelu) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
-            }
-            const bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-            *reinterpret_cast<bf16x4*>(a.out + row * a.ldo + n) = o;
-        }
-    }
+    frame_epilogue<NTC>(a, acc, rx, smem, f, n0, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
@@ -257,8 +340,7 @@ __global__ void __launch_bounds__(NTHR) frame_res_kernel(FrameArgs a) {
 template <int NTC, int NS>
 __global__ void __launch_bounds__(NTHR) frame_ring_kernel(FrameArgs a) {
     constexpr int BN = 32 * NTC, PB = BN / 8, BBLK = BN * 64, SLOT = ABLK + BBLK;
-    constexpr int LDZ = BN + 1;
-    static_assert(FS * LDZ * 4 + 2 * BN * 4 <= NS * SLOT * 2, "epilogue staging must fit in the ring");
+    static_assert(FS * (BN + 1) * 4 + 2 * BN * 4 <= NS * SLOT * 2, "epilogue staging must fit in the ring");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* ring = reinterpret_cast<bf16*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -314,70 +396,7 @@ __global__ void __launch_bounds__(NTHR) frame_ring_kernel(FrameArgs a) {
             for (int j = 0; j < NTC; ++j)
                 rx[i][j] = *reinterpret_cast<const bf16x4*>(a.resid + ((long)f * FS + wm * 48 + i * 16 + li) * a.ldr + n0 + wn * (16 * NTC) + j * 16 + 4 * lg);
     }
-    float* zs = reinterpret_cast<float*>(smem);          // [144][LDZ] rounded z; then tab[2][BN]
-    float* tab = zs + FS * LDZ;
-    if (a.en_w) {
-        lds_barrier();                                   // every wave is done with the ring
-#pragma unroll
-        for (int j = 0; j < NTC; ++j) {
-            const int c = wn * (16 * NTC) + j * 16 + 4 * lg;
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float z = (float)(bf16)(acc[i][j][r] + (a.bias ? a.bias[n0 + c + r] : 0.f));     // the tensor in_stats_kernel reads is bf16
-                    acc[i][j][r] = z;
-                    zs[(wm * 48 + i * 16 + li) * LDZ + c + r] = z;
-                }
-        }
-        lds_barrier();
-        const int rgp = lane >> 3, c8 = lane & 7;
-        for (int task = wave; task < BN / 8; task += NW) {       // 8 columns per wave-task, in_stats_kernel's order (frame_stats)
-            const int c = 8 * task + c8;
-            float x[4][5][1];
-#pragma unroll
-            for (int w4 = 0; w4 < 4; ++w4)
-#pragma unroll
-                for (int qq = 0; qq < 5; ++qq) x[w4][qq][0] = (w4 < 2 || qq < 4) ? zs[(8 * w4 + rgp + 32 * qq) * LDZ + c] : 0.f;
-            float mu[1], rs[1];
-            frame_stats<1>(x, mu, rs);
-            if (rgp == 0) {
-                float aa = rs[0] * a.en_w[n0 + c];
-                float s0 = fmaf(-mu[0], aa, a.en_b[n0 + c]);
-                const float gg = a.en_g[n0 + c];
-                aa *= gg;
-                s0 = fmaf(s0, gg, 0.f);
-                tab[c] = aa; tab[BN + c] = s0;
-            }
-        }
-        lds_barrier();
-    }
-#pragma unroll
-    for (int j = 0; j < NTC; ++j) {
-        const int c = wn * (16 * NTC) + j * 16 + 4 * lg, n = n0 + c;
-        float cb[4], cs[4], ch[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { cb[r] = a.bias ? a.bias[n + r] : 0.f; cs[r] = a.cs ? a.cs[n + r] : 1.f; ch[r] = a.cs ? a.ch[n + r] : 0.f; }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const long row = (long)f * FS + wm * 48 + i * 16 + li;
-            float v[4];
-            if (a.en_w) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[i][j][r], tab[c + r], tab[BN + c + r]) + (float)rx[i][j][r];
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = acc[i][j][r] + cb[r];
-                    if (a.cs) v[r] = fmaf(v[r], cs[r], ch[r]);
-                    if (a.resid) v[r] = v[r] + (float)rx[i][j][r];
-                    if (a.gelu) v[r] = gelu_fast(v[r]);
-                }
-            }
-            const bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-            *reinterpret_cast<bf16x4*>(a.out + row * a.ldo + n) = o;
-        }
-    }
+    frame_epilogue<NTC>(a, acc, rx, smem, f, n0, wave, lane);
 }
 
 template <typename Kern>
@@ -398,7 +417,7 @@ int launch_frame(Kern k, bool& attr_done, size_t lds, unsigned grid, const Frame
 extern "C" int bf_frame_linear(int dtype, int frames, int S, int K, int N, const void* A, int64_t lda, const void* W, int64_t ldw,
                                const float* norm_w, const float* norm_b, const float* bias, const float* colscale, const float* colshift,
                                const void* resid, int64_t ldr, int gelu, const float* en_w, const float* en_b, const float* en_g,
-                               void* out, int64_t ldo, bf_stream_t stream) {
+                               void* out, int64_t ldo, const float* next_w, const float* next_b, void* out_n, int64_t ldn, bf_stream_t stream) {
     if (dtype != BF_DTYPE_BF16 || S != FS || frames < 1 || N % 32 || K % 64 || K < 128) return 1;
     const bool res = K == 384 && !en_w;
     if (!res && (norm_w || K / 64 < 2)) return 1;                       // the frame's operand is resident only at K = 384
@@ -411,6 +430,8 @@ extern "C" int bf_frame_linear(int dtype, int frames, int S, int K, int N, const
     a.A = (const bf16*)A; a.lda = lda; a.W = (const bf16*)W; a.ldw = ldw; a.out = (bf16*)out; a.ldo = ldo; a.N = N; a.KB = K / 64;
     a.nw = norm_w; a.nb = norm_b; a.bias = bias; a.cs = colscale; a.ch = colshift; a.resid = (const bf16*)resid; a.ldr = ldr; a.gelu = gelu;
     a.en_w = en_w; a.en_b = en_b; a.en_g = en_g;
+    BF_REQUIRE(!out_n || (next_w && next_b && ldn % 4 == 0 && ((uintptr_t)out_n & 7) == 0), "bf_frame_linear: the second output needs the next norm's weight and bias");
+    a.xw = next_w; a.xb = next_b; a.xn = (bf16*)out_n; a.ldx = ldn;
     hipStream_t st = (hipStream_t)stream;
     // widest column block that still gives every CU a workgroup (a frame's operand is shared by the N / BN workgroups of the frame)
     static const int force = []() { const char* v = getenv("BF_FRAME_NTC"); return v ? atoi(v) : 0; }();

@@ -1002,24 +1002,37 @@ extern "C" int bf_trunk_eval_fwd(const bf_dims* dims, int n, const int32_t* kind
     BF_REQUIRE(sc.tokred_floats >= (int64_t)4 * F * E, "bf_trunk_eval_fwd: scratch too small");
     const char* base = (const char*)weights;
     const void* cur = x;
+    const void* xn = nullptr;                             // norm1(cur) of the stage about to run, when the previous stage's last kernel made it
+    void* xn_buf = sc.s1;
+    auto norm1_of = [&](int i, const float** w, const float** b) {
+        if (kinds[i] == 0) { const bf_temporal_params* q = (const bf_temporal_params*)params[i]; *w = q->norm1_w; *b = q->norm1_b; }
+        else { const bf_spatial_params* q = (const bf_spatial_params*)params[i]; *w = q->norm1_w; *b = q->norm1_b; }
+    };
     for (int i = 0; i < n; ++i) {
         BF_REQUIRE(params[i] && (kinds[i] == 0 || kinds[i] == 1), "bf_trunk_eval_fwd: bad stage entry");
         EvalStage ev(d, kinds[i], (void*)base);
         base += ev.bytes;
         void* nxt = i == n - 1 ? out : ((i & 1) ? sc.e7 : sc.e6);
+        // the stage's last kernel holds whole-frame columns of its output: it also writes the NEXT stage's norm1 of it
+        const float *nw = nullptr, *nb = nullptr;
+        if (i + 1 < n) { BF_REQUIRE(params[i + 1] && (kinds[i + 1] == 0 || kinds[i + 1] == 1), "bf_trunk_eval_fwd: bad stage entry"); norm1_of(i + 1, &nw, &nb); }
+        void* xn_next = nw ? xn_buf : nullptr;
 #define FRL(...) do { const int rc_ = bf_frame_linear(__VA_ARGS__); if (rc_ != 0) return rc_ < 0 ? rc_ : bf_fail_msg("bf_trunk_eval_fwd: frame kernel refused a covered shape", __FILE__, __LINE__); } while (0)
+        const float *w1n, *b1n;
+        norm1_of(i, &w1n, &b1n);
+        const float* qkv_bias = kinds[i] == 0 ? ((const bf_temporal_params*)params[i])->input_head_b : ((const bf_spatial_params*)params[i])->input_head_b;
+        if (xn) FRL(d.dtype, F, 144, E, 3 * E, xn, E, ev.win_c, E, nullptr, nullptr, qkv_bias, nullptr, nullptr, nullptr, 0, 0,
+                    nullptr, nullptr, nullptr, qkv, 3L * E, nullptr, nullptr, nullptr, 0, s);
+        else FRL(d.dtype, F, 144, E, 3 * E, cur, E, ev.win_c, E, w1n, b1n, qkv_bias, nullptr, nullptr, nullptr, 0, 0,
+                 nullptr, nullptr, nullptr, qkv, 3L * E, nullptr, nullptr, nullptr, 0, s);
         if (kinds[i] == 0) {
             const bf_temporal_params* p = (const bf_temporal_params*)params[i];
-            FRL(d.dtype, F, 144, E, 3 * E, cur, E, ev.win_c, E, p->norm1_w, p->norm1_b, p->input_head_b, nullptr, nullptr, nullptr, 0, 0,
-                nullptr, nullptr, nullptr, qkv, 3L * E, s);
             TRY(bf_attn_fwd(d.dtype, qkv, o, (long)d.B * d.S, d.T, d.S, (long)d.T * d.S, 1, d.S, d.heads, d.d, p->qnorm_w, p->qnorm_b,
                             p->knorm_w, p->knorm_b, p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor : nullptr, 1.f, 0, st));
             FRL(d.dtype, F, 144, E, E, o, E, ev.wout_c, E, p->norm2_w, p->norm2_b, nullptr, ev.alpha, ev.beta, cur, E, 0,
-                nullptr, nullptr, nullptr, nxt, E, s);
+                nullptr, nullptr, nullptr, nxt, E, nw, nb, xn_next, E, s);
         } else {
             const bf_spatial_params* p = (const bf_spatial_params*)params[i];
-            FRL(d.dtype, F, 144, E, 3 * E, cur, E, ev.win_c, E, p->norm1_w, p->norm1_b, p->input_head_b, nullptr, nullptr, nullptr, 0, 0,
-                nullptr, nullptr, nullptr, qkv, 3L * E, s);
             const int rc = bf_attn_axial_norm_fwd(d.dtype, qkv, o, on, d.F, (int)d.h, (int)d.w, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w,
                                                   p->knorm_b, p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_x : nullptr,
                                                   d.attn_scale ? p->attn_scale_factor_y : nullptr, p->norm2_w, p->norm2_b, stat, stat + (size_t)F * E,
@@ -1029,16 +1042,17 @@ extern "C" int bf_trunk_eval_fwd(const bf_dims* dims, int n, const int32_t* kind
                 TRY(bf_attn_axial_fwd(d.dtype, qkv, o, d.F, (int)d.h, (int)d.w, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
                                       p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_x : nullptr, d.attn_scale ? p->attn_scale_factor_y : nullptr, st));
                 FRL(d.dtype, F, 144, E, E, o, E, ev.wout_c, E, p->norm2_w, p->norm2_b, nullptr, ev.alpha, ev.beta, cur, E, 0,
-                    nullptr, nullptr, nullptr, x1, E, s);
+                    nullptr, nullptr, nullptr, x1, E, nullptr, nullptr, nullptr, 0, s);
             } else {
                 FRL(d.dtype, F, 144, E, E, on, E, ev.wout_c, E, nullptr, nullptr, nullptr, ev.alpha, ev.beta, cur, E, 0,
-                    nullptr, nullptr, nullptr, x1, E, s);
+                    nullptr, nullptr, nullptr, x1, E, nullptr, nullptr, nullptr, 0, s);
             }
             FRL(d.dtype, F, 144, E, 4 * E, x1, E, ev.w1_c, E, nullptr, nullptr, p->fc1_b, nullptr, nullptr, nullptr, 0, 1,
-                nullptr, nullptr, nullptr, hid, 4L * E, s);
+                nullptr, nullptr, nullptr, hid, 4L * E, nullptr, nullptr, nullptr, 0, s);
             FRL(d.dtype, F, 144, 4 * E, E, hid, 4L * E, ev.w2_c, 4L * E, nullptr, nullptr, p->fc2_b, nullptr, nullptr, x1, E, 0,
-                p->mlp_norm_w, p->mlp_norm_b, p->gamma_mlp, nxt, E, s);
+                p->mlp_norm_w, p->mlp_norm_b, p->gamma_mlp, nxt, E, nw, nb, xn_next, E, s);
         }
+        xn = xn_next;
 #undef FRL
         cur = nxt;
     }

@@ -77,18 +77,20 @@ def attn_fwd(qkv, out, nseq, Lq, inner, outer_stride, inner_stride, tok_stride, 
                                 _p(qw), _p(qb), _p(kw), _p(kb), _p(emb), _p(hscale), out_scale, int(accumulate), _stream()), "bf_attn_fwd")
 
 
-def frame_linear(A, W, frames, S, norm=None, bias=None, colscale=None, colshift=None, resid=None, gelu=False, out_norm=None):
-    """Whole-frame inference projection (bf_frame_linear).  norm = (w, b): InstanceNorm in front; out_norm = (w, b, g): out = resid + g * IN(A W^T + bias).
-    Returns the output or None when the shape is not covered."""
+def frame_linear(A, W, frames, S, norm=None, bias=None, colscale=None, colshift=None, resid=None, gelu=False, out_norm=None, next_norm=None):
+    """Whole-frame inference projection (bf_frame_linear).  norm = (w, b): InstanceNorm in front; out_norm = (w, b, g): out = resid + g * IN(A W^T + bias);
+    next_norm = (w, b): also return IN(out) * w + b.  Returns the output (or (out, out_n)), or None when the shape is not covered."""
     M, K = A.shape
     N = W.shape[0]
     out = torch.empty(M, N, dtype=A.dtype, device=A.device)
     nw, nb = norm if norm is not None else (None, None)
     ew, eb, eg = out_norm if out_norm is not None else (None, None, None)
+    xw, xb = next_norm if next_norm is not None else (None, None)
+    out_n = torch.empty_like(out) if next_norm is not None else None
     rc = L.lib().bf_frame_linear(_dt(A.dtype), frames, S, K, N, _p(A), A.stride(0), _p(W), W.stride(0), _p(nw), _p(nb), _p(bias), _p(colscale),
                                  _p(colshift), _p(resid), resid.stride(0) if resid is not None else 0, int(gelu), _p(ew), _p(eb), _p(eg),
-                                 _p(out), out.stride(0), _stream())
+                                 _p(out), out.stride(0), _p(xw), _p(xb), _p(out_n), N if out_n is not None else 0, _stream())
     if rc == 1:
         return None
     L.check(rc, "bf_frame_linear")
-    return out
+    return out if out_n is None else (out, out_n)

@@ -123,14 +123,18 @@ int64_t bf_gemm_tokred_ws_floats(int Nout, int Kin, int64_t M);
  *     120-121 norm2 + output_head); K = 384 only (the frame's operand is LDS-resident);
  *   en_w/en_b/en_g != NULL: the InstanceNorm behind fc2 with layer scale and residual, out = resid + en_g * IN(A @ W^T + bias)
  *     (layers/attention.py:316-322);
- *   otherwise v = acc + bias; v = v * colscale + colshift (if given); v += resid (if given); v = gelu(v) (if gelu).
+ *   otherwise v = acc + bias; v = v * colscale + colshift (if given); v += resid (if given); v = gelu(v) (if gelu);
+ *   out_n != NULL: a second output, the NEXT layer's InstanceNorm of `out` (its norm1: out_n = IN(out) * next_w + next_b, statistics
+ *     over the stored bf16 values) -- the tile holds whole-frame columns of `out`, so the next projection needs no norm in front.
  * A [frames*S][lda], W [N][ldw] (K-contiguous), resid / out [frames*S][ld*], all bf16.  Statistics are summed in bf_in_stats' order and
  * the products in bf_gemm's: results equal the separate launches bit for bit.  Returns 0 when done, 1 when the shape is not covered
  * (bf16, S = 144, N % 32 = 0, K = 384 or (no norm in front) K % 64 = 0), < 0 on error. */
 int bf_frame_linear(int dtype, int frames, int S, int K, int N, const void* A, int64_t lda, const void* W, int64_t ldw,
                     const float* norm_w, const float* norm_b, const float* bias, const float* colscale, const float* colshift,
                     const void* resid, int64_t ldr, int gelu, const float* en_w, const float* en_b, const float* en_g,
-                    void* out, int64_t ldo, bf_stream_t stream);
+                    void* out, int64_t ldo,
+                    const float* next_w, const float* next_b, void* out_n, int64_t ldn, /* optional second output, see above */
+                    bf_stream_t stream);
 
 /* ---------------------------------------------------------------- kernel-level entry points (unit-testable) */
 

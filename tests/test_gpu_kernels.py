@@ -177,6 +177,13 @@ def test_frame_linear_equals_the_separate_launches(K, frames, N, variant):
     if "fold" not in variant:     # (the fold rescales and shifts the product: its element-wise check is the bit-equality below)
         assert float(((got.float() - ref).abs() / (ref.abs() + 0.05 * ref.abs().mean())).max()) < 0.3      # the bf16 rounding of the normalised operand included
     assert torch.equal(got, sep), "differs from the separate launches: %g of the elements" % float((got != sep).float().mean())
+    if variant == "norm_fold_resid":       # the temporal out-projection also emits the next block's norm1 of its output
+        xw = 1 + 0.3 * torch.randn(N, device="cuda", generator=g); xb = 0.3 * torch.randn(N, device="cuda", generator=g)
+        got_o, got_n = K.frame_linear(a, w, frames, S, norm=(nw, nb), colscale=cs, colshift=ch, resid=resid, next_norm=(xw, xb))
+        _, _, sc2, sh2 = K.in_stats(sep, frames, S, N, xw, xb)
+        sep_n = torch.empty_like(sep)
+        L.check(L.lib().bf_affine_apply(L.BF_DTYPE_BF16, sep.data_ptr(), None, sc2.data_ptr(), sh2.data_ptr(), sep_n.data_ptr(), M, S, N, torch.cuda.current_stream().cuda_stream), "affine")
+        assert torch.equal(got_o, sep) and torch.equal(got_n, sep_n), float((got_n != sep_n).float().mean())
 
 
 @pytest.mark.parametrize("frames,N", [(16, 384), (3, 384), (64, 384), (24, 512)])
@@ -206,6 +213,13 @@ def test_frame_linear_fc2_with_the_instance_norm_behind(K, frames, N):
     torch.cuda.synchronize()
     assert _rel(got.float(), ref) < 6e-3
     assert torch.equal(got, sep), "differs from the separate launches: %g of the elements" % float((got != sep).float().mean())
+    # second output: the next layer's norm1 of `out`, as bf_in_stats + bf_affine_apply make it from the stored tensor
+    xw = 1 + 0.3 * torch.randn(N, device="cuda", generator=g); xb = 0.3 * torch.randn(N, device="cuda", generator=g)
+    got_o, got_n = K.frame_linear(hid, w, frames, S, bias=bias, resid=resid, out_norm=(ew, eb, eg), next_norm=(xw, xb))
+    _, _, sc2, sh2 = K.in_stats(sep, frames, S, N, xw, xb)
+    sep_n = torch.empty_like(sep)
+    L.check(L.lib().bf_affine_apply(L.BF_DTYPE_BF16, sep.data_ptr(), None, sc2.data_ptr(), sh2.data_ptr(), sep_n.data_ptr(), M, S, N, torch.cuda.current_stream().cuda_stream), "affine")
+    assert torch.equal(got_o, sep) and torch.equal(got_n, sep_n), float((got_n != sep_n).float().mean())
     # plain streamed form (no norm): bias + residual
     got2 = K.frame_linear(hid, w, frames, S, bias=bias, resid=resid)
     sep2 = torch.empty_like(z)
