@@ -354,8 +354,8 @@ __global__ void __launch_bounds__(256) attn_fwd_mfma(const bf16* __restrict__ qk
 // all h*w tokens of its d channels, i.e. everything a per-(frame, channel) statistic needs: two-pass mean / variance over the LDS tile,
 // then `out` and the normalised `out_n` (the out-projection's operand) are written together; the separate statistics launch is gone.
 struct AxNorm { const float* w; const float* b; bf16* out_n; float* mean; float* rstd; float* sc; float* sh; };
-template <int KS, bool NORM>
-__global__ void __launch_bounds__(256) attn_fwd_axial_mfma(const bf16* __restrict__ qkv, bf16* __restrict__ out, int frames, int h, int w, int heads, Par p,
+template <int KS, bool NORM, int WPB = 4>      // WPB waves per workgroup: 4 (two workgroups per CU, large batches) or 12 (inference: one round per pass)
+__global__ void __launch_bounds__(64 * WPB) attn_fwd_axial_mfma(const bf16* __restrict__ qkv, bf16* __restrict__ out, int frames, int h, int w, int heads, Par p,
                                                            const float* __restrict__ hscale_y, AxNorm nrm) {
     constexpr int NB = 1, D = 32 * KS, LD = D + 16, NT16 = D / 16, DP = D + 8;
     extern __shared__ __attribute__((aligned(16))) bf16 smem_ax[];
@@ -954,20 +954,24 @@ int bf_attn_axial_fwd_mfma(const void* qkv, void* out, int frames, int h, int w,
     static const bool off = []() { const char* v = getenv("BF_ATTN_AXIAL_FUSED"); return v && atoi(v) == 0; }();
     if (off || h > 16 || w > 16 || h < 1 || w < 1 || d % 32 || d > 128 || heads > 16) return 1;
     Par p{qw, qb, kw, kb, emb, hscale_x};
-    const int ks = d / 32, wpb = 4;
+    const long ntile = (long)frames * heads;
+    // few (frame, head) tiles (inference at batch 1-2: 96-192 on 256 CUs): 12 waves per workgroup run the h row sequences in ONE round and
+    // the w column sequences in one more instead of three each -- the launch is a chain of dependent ~2 us rounds, not throughput
+    static const int wpb_env = []() { const char* v = getenv("BF_ATTN_AXIAL_WPB"); return v ? atoi(v) : 0; }();
+    const int ks = d / 32, wpb = (wpb_env == 4 || wpb_env == 12) ? wpb_env : (ntile <= 256 ? 12 : 4);
     const bool norm = nw != nullptr;
     const size_t tile = ((size_t)h * w * (d + 8) + 7) & ~(size_t)7;
     const size_t shm = ((size_t)wpb * 16 * (d + 16) + tile) * sizeof(bf16) + (norm ? ((size_t)(256 / (d / 8)) + 2) * d * sizeof(float) : 0);
-    const long ntile = (long)frames * heads;
     const int grid = (int)std::min<long>(ntile, 256L * 3);
     const AxNorm nrm{nw, nb, (bf16*)out_n, mean, rstd, sc, sh};
+#define GO2(KS, NRM, W) { if (int rc = set_lds(attn_fwd_axial_mfma<KS, NRM, W>, shm)) return rc; \
+        hipLaunchKernelGGL((attn_fwd_axial_mfma<KS, NRM, W>), dim3(grid), dim3(W * 64), shm, st, (const bf16*)qkv, (bf16*)out, frames, h, w, heads, p, hscale_y, nrm); }
 #define GO(KS) if (ks == KS) { \
-        if (norm) { if (int rc = set_lds(attn_fwd_axial_mfma<KS, true>, shm)) return rc; \
-            hipLaunchKernelGGL((attn_fwd_axial_mfma<KS, true>), dim3(grid), dim3(wpb * 64), shm, st, (const bf16*)qkv, (bf16*)out, frames, h, w, heads, p, hscale_y, nrm); } \
-        else { if (int rc = set_lds(attn_fwd_axial_mfma<KS, false>, shm)) return rc; \
-            hipLaunchKernelGGL((attn_fwd_axial_mfma<KS, false>), dim3(grid), dim3(wpb * 64), shm, st, (const bf16*)qkv, (bf16*)out, frames, h, w, heads, p, hscale_y, nrm); } }
+        if (norm) { if (wpb == 12) GO2(KS, true, 12) else GO2(KS, true, 4) } \
+        else { if (wpb == 12) GO2(KS, false, 12) else GO2(KS, false, 4) } }
     GO(1) GO(2) GO(3) GO(4)
 #undef GO
+#undef GO2
     BF_CHECK_LAUNCH();
     return 0;
 }
