@@ -372,7 +372,10 @@ int launch(int M, int N, int K, const bf_operand* A, const bf_operand* B, const 
     const int nt = bf_cdiv(N, BN);
     static const int small_env = []() { const char* v = getenv("BF_GEMM_SMALL"); return v ? atoi(v) : -1; }();
     // measured: with 8-wave workgroups the 128 x 128 tile beats 64 x 128 even on grids of < 2 workgroups per CU
-    const bool small = small_env >= 0 ? (small_env != 0 && M > 64) : (M <= 64);
+    // ... except where 128-row tiles leave most CUs without a workgroup (the patch stages at batch 1: 18-72 row tiles): 64-row tiles then
+    static const int few_env = []() { const char* v = getenv("BF_GEMM_FEW_TILES"); return v ? atoi(v) : 100; }();
+    const bool few = splitk <= 1 && (long)bf_cdiv(M, 128) * nt < few_env && M > 64;
+    const bool small = small_env >= 0 ? (small_env != 0 && M > 64) : (M <= 64 || few);
     const int bm = small ? 64 : 128;
     const int mt = bf_cdiv(M, bm);
     dim3 grid((unsigned)((long)mt * nt * splitk));

@@ -36,13 +36,18 @@ def alias(t):
 
 cases = []
 for name, N, Kd, kw in (("qkv+norm", 3 * E, E, dict(norm=(nw, nb))), ("qkv", 3 * E, E, {}), ("outproj+norm", E, E, dict(norm=(nw, nb))), ("outproj", E, E, {}),
-                        ("fc1", 4 * E, E, dict(gelu=True)), ("fc2+in", E, 4 * E, "in")):
+                        ("outproj+next", E, E, "next"), ("fc1", 4 * E, E, dict(gelu=True)), ("fc2+in", E, 4 * E, "in"), ("fc2+in+next", E, 4 * E, "in+next")):
     w = (torch.randn(N, Kd, device="cuda", generator=g) * 0.05).to(dt)
     a = hid if Kd == 4 * E else x
     bias = torch.randn(N, device="cuda", generator=g)
     resid = torch.randn(M, N, device="cuda", generator=g).to(dt)
+    one, zero = torch.ones(N, device="cuda"), torch.zeros(N, device="cuda")
     if kw == "in":
-        kw = dict(resid=resid, out_norm=(torch.ones(N, device="cuda"), torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")))
+        kw = dict(resid=resid, out_norm=(one, zero, one))
+    elif kw == "in+next":
+        kw = dict(resid=resid, out_norm=(one, zero, one), next_norm=(one, zero))
+    elif kw == "next":
+        kw = dict(resid=resid, colscale=one, colshift=zero, next_norm=(one, zero))
     t_real = timeit(lambda: K.frame_linear(a, w, frames, S, bias=bias, **kw))
     t_alias = timeit(lambda: K.frame_linear(alias(a), w, frames, S, bias=bias, **kw))
     t_alias2 = timeit(lambda: K.frame_linear(alias(a), alias(w), frames, S, bias=bias, **kw))
