@@ -336,34 +336,24 @@ __global__ void __launch_bounds__(NTHR) frame_res_kernel(FrameArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
-// Streamed form (fc2: K = 4E): both operands go through a ring of NS slots {[144][64] | [BN][64]}; optional InstanceNorm behind.
+// Streamed product of one frame tile: acc += A[144 rows][64 KB] @ W[BN rows][64 KB]^T, both operands through a ring of NS slots
+// {[144][64] | [BN][64]} filled by LDS-DMA, NS - 1 blocks in flight, counted vmcnt + one raw barrier per 64-deep K-block.
 template <int NTC, int NS>
-__global__ void __launch_bounds__(NTHR) frame_ring_kernel(FrameArgs a) {
+__device__ __forceinline__ void ring_product(const bf16* Af, long lda, const bf16* Wb, long ldw, int KB, char* smem, f32x4 (&acc)[3][NTC], int wave, int lane) {
     constexpr int BN = 32 * NTC, PB = BN / 8, BBLK = BN * 64, SLOT = ABLK + BBLK;
-    static_assert(FS * (BN + 1) * 4 + 2 * BN * 4 <= NS * SLOT * 2, "epilogue staging must fit in the ring");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* ring = reinterpret_cast<bf16*>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % 3, wn = wave / 3;
-    const int li = lane & 15, lg = lane >> 4;
-    const int ncb = a.N / BN, KB = a.KB;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int f = bid / ncb, n0 = (bid % ncb) * BN;
-    const bf16* Af = a.A + (long)f * FS * a.lda;
-    const bf16* Wb = a.W + (long)n0 * a.ldw;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     const int cntB = (PB - wave + NW - 1) / NW;          // weight pieces this wave issues per block (wave-uniform)
     const int grp = 3 + (cntB > 0 ? cntB : 0);
     auto issue = [&](int kb) {
         const unsigned s = lds0 + (unsigned)(kb % NS) * (unsigned)(SLOT * 2);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) dma_piece(Af + (long)kb * 64, a.lda, s, wave + NW * t, lane);
-        for (int p = wave; p < PB; p += NW) dma_piece(Wb + (long)kb * 64, a.ldw, s + (unsigned)(ABLK * 2), p, lane);
+        for (int t = 0; t < 3; ++t) dma_piece(Af + (long)kb * 64, lda, s, wave + NW * t, lane);
+        for (int p = wave; p < PB; p += NW) dma_piece(Wb + (long)kb * 64, ldw, s + (unsigned)(ABLK * 2), p, lane);
     };
     int last = -1;                                       // newest block issued
     for (int kb = 0; kb < NS && kb < KB; ++kb) { issue(kb); last = kb; }
-
-    f32x4 acc[3][NTC];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -387,6 +377,22 @@ __global__ void __launch_bounds__(NTHR) frame_ring_kernel(FrameArgs a) {
                 for (int j = 0; j < NTC; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
     }
+}
+
+// Streamed form (fc2: K = 4E); optional InstanceNorm behind.
+template <int NTC, int NS>
+__global__ void __launch_bounds__(NTHR) frame_ring_kernel(FrameArgs a) {
+    constexpr int BN = 32 * NTC, SLOT = ABLK + BN * 64;
+    static_assert(FS * (BN + 1) * 4 + 2 * BN * 4 <= NS * SLOT * 2, "epilogue staging must fit in the ring");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % 3, wn = wave / 3;
+    const int li = lane & 15, lg = lane >> 4;
+    const int ncb = a.N / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int f = bid / ncb, n0 = (bid % ncb) * BN;
+    f32x4 acc[3][NTC];
+    ring_product<NTC, NS>(a.A + (long)f * FS * a.lda, a.lda, a.W + (long)n0 * a.ldw, a.ldw, a.KB, smem, acc, wave, lane);
     // ---- epilogue
     bf16x4 rx[3][NTC];
     if (a.resid) {
@@ -454,3 +460,4 @@ extern "C" int bf_frame_linear(int dtype, int frames, int S, int K, int N, const
 #undef FR_RING
     return 0;
 }
+
