@@ -293,6 +293,28 @@ def test_config4_inference_trunk_equals_the_stage_forwards(B, monkeypatch):
         assert torch.equal(f3, s3) and not torch.equal(f3, f2)
 
 
+@pytest.mark.parametrize("name,kw", [("avit", dict(attn_scale=False, feat_scale=False)), ("avit", dict(attn_scale=True, feat_scale=False)),
+                                     ("filmavit", dict(attn_scale=False, feat_scale=True, num_fluid_params=9))])
+def test_inference_trunk_variants_equal_the_stage_forwards(name, kw, monkeypatch):
+    """The inference path with the reference's switches off (`attn_scale`, `feat_scale`: models/axial_vit.py constructor arguments) and for
+    the unconditioned AViT: 3 blocks at E = 384, 4 x 192 x 192 clips, batch 2 -- bit-identical to the stage forwards."""
+    from bubbleformer_amd.models import get_model
+    torch.manual_seed(3)
+    m = get_model(name, input_fields=4, output_fields=4, time_window=4, patch_size=16, embed_dim=384, num_heads=6, processor_blocks=3,
+                  drop_path=0.1, compute_dtype=torch.bfloat16, **kw).cuda().eval()
+    with torch.no_grad():
+        for p in m.parameters():          # layer scales start at 1e-6: give every branch weight
+            if p.ndim == 1 and float(p.abs().max()) < 1e-3:
+                p.fill_(0.3)
+    x = torch.randn(2, 4, 4, 192, 192, device="cuda")
+    args = (x, torch.randn(2, 9, device="cuda")) if name == "filmavit" else (x,)
+    with torch.no_grad():
+        fast = m(*args)
+        monkeypatch.setenv("BF_TRUNK_EVAL", "0")
+        slow = m(*args)
+    assert torch.isfinite(fast).all() and torch.equal(fast, slow)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_film_avit_big_width(dtype):
     """`film_avit_big` width (E = 768, 12 heads of 64; config/model_cfg/film_avit_big.yaml) through the same kernels: 3 blocks,
