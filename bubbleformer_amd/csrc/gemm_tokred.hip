@@ -5,8 +5,8 @@
 //
 // The reduction runs over tens of thousands of tokens and the result is a few hundred KB, so the split over workgroups is a split
 // of the TOKENS.  What that costs is the partial results: (#workgroups) x (tile bytes) of fp32 leave the chip whatever the tile
-// shape.  This kernel therefore uses FEW, LONG slices (4-8): one workgroup = one 384 x 128 (or 128 x 128) output tile x one token slice,
-// 24-144 workgroups per launch -- the launch deliberately does not fill the chip; it runs beside the data-gradient kernels of the
+// shape.  This kernel therefore uses FEW, LONG slices (8): one workgroup = one 128 x 128 (or 384 x 128) output tile x one token slice,
+// 72-288 workgroups per launch -- the launch deliberately does not fill the chip; it runs beside the data-gradient kernels of the
 // caller's stream -- and its partial tile goes to a slab with plain 16-byte stores.  A second tiny kernel adds the slabs in slice
 // order: the result is bit-reproducible run to run (no float atomics anywhere) and the slab traffic is 2 x 4 x |out| instead of
 // the split-K atomics' 9-19 x |out|.
@@ -167,15 +167,21 @@ __global__ void __launch_bounds__(512) tokred_kernel(const bf16* __restrict__ A,
     }
 }
 
-// out[i] = (accumulate ? out[i] : 0) + sum_s slab[s][i] in slice order; colsum likewise from cslab
+// out[i] = (accumulate ? out[i] : 0) + sum_s slab[s][i] in slice order; colsum likewise from cslab.  The slices' loads are issued together
+// (batches of 8 independent 16-byte loads per thread) and added in slice order: a loop of load-then-add ran at one memory round trip per
+// slice (24 us per launch at 8 slices for 18 MB).
 __global__ void __launch_bounds__(256) tokred_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ cslab, int nslice, long n,
                                                             int Nout, float* __restrict__ out, float* __restrict__ colsum, int accumulate) {
     const long n4 = n / 4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         float4 a = accumulate ? reinterpret_cast<const float4*>(out)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s = 0; s < nslice; ++s) {
-            const float4 v = reinterpret_cast<const float4*>(slab + (size_t)s * n)[i];
-            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        for (int s0 = 0; s0 < nslice; s0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = s0 + q < nslice ? reinterpret_cast<const float4*>(slab + (size_t)(s0 + q) * n)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (s0 + q < nslice) { a.x += v[q].x; a.y += v[q].y; a.z += v[q].z; a.w += v[q].w; }
         }
         reinterpret_cast<float4*>(out)[i] = a;
     }
@@ -193,7 +199,7 @@ int env_int(const char* name, int dflt) { const char* v = getenv(name); return v
 int pick_slices(long steps, int dflt) {
     static const int env = env_int("BF_TOKRED_SLICES", 0);
     int ns = env > 0 ? env : dflt;
-    ns = ns < 1 ? 1 : ns > 8 ? 8 : ns;
+    ns = ns < 1 ? 1 : ns > 16 ? 16 : ns;
     if (ns > steps) ns = (int)steps;
     return ns;
 }
@@ -202,7 +208,7 @@ int pick_slices(long steps, int dflt) {
 
 extern "C" int64_t bf_gemm_tokred_ws_floats(int Nout, int Kin, int64_t M) {
     if (Nout <= 0 || Kin <= 0 || M <= 0) return 0;
-    return (int64_t)8 * ((int64_t)Nout * Kin + Nout);           // up to 8 slices of the result and of the column sums
+    return (int64_t)16 * ((int64_t)Nout * Kin + Nout);          // up to 16 slices of the result and of the column sums
 }
 
 // Returns 0 when done, 1 when the shape is not covered (the caller then runs bf_gemm's token-reduction form), < 0 on error.
@@ -223,7 +229,9 @@ extern "C" int bf_gemm_tokred(int dtype, int Nout, int Kin, int64_t M, const voi
     const bool tall = tall_env != 0 && Nout % 384 == 0;
     const int tm = tall ? 384 : TB, bkt = tall ? 32 : BK;
     const long steps = M / bkt;
-    const int nslice = pick_slices(steps, tall ? (Nout / 384 >= 3 ? 6 : 8) : 4);
+    // 8 token slices (216-288 workgroups for the trunk's shapes; 4 until the round-2 kernels shifted the balance of the two queues: measured
+    // on the final tree 4 / 6 / 8 / 10 / 12 / 16 slices -> 649 / 662 / 670 / 634-642 / 626-630 / 619 samples/s)
+    const int nslice = pick_slices(steps, tall ? (Nout / 384 >= 3 ? 6 : 8) : 8);
     const long n = (long)Nout * Kin;
     BF_REQUIRE(ws_floats >= (int64_t)nslice * (n + Nout), "bf_gemm_tokred: workspace too small (bf_gemm_tokred_ws_floats)");
     const int steps_per = bf_cdiv(steps, nslice);
