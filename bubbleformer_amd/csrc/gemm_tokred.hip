@@ -231,6 +231,7 @@ extern "C" int bf_gemm_tokred(int dtype, int Nout, int Kin, int64_t M, const voi
     const long steps = M / bkt;
     // 8 token slices (216-288 workgroups for the trunk's shapes; 4 until the round-2 kernels shifted the balance of the two queues: measured
     // on the final tree 4 / 6 / 8 / 10 / 12 / 16 slices -> 649 / 662 / 670 / 634-642 / 626-630 / 619 samples/s)
+    // (slice counts chosen per shape for 200-256 workgroups -- 9 / 16 / 7 for the QKV / out-projection / MLP shapes: 670-673, no better)
     const int nslice = pick_slices(steps, tall ? (Nout / 384 >= 3 ? 6 : 8) : 8);
     const long n = (long)Nout * Kin;
     BF_REQUIRE(ws_floats >= (int64_t)nslice * (n + Nout), "bf_gemm_tokred: workspace too small (bf_gemm_tokred_ws_floats)");
