@@ -56,16 +56,17 @@ class _AxialBase(nn.Module):
     def _process(self, tok):
         # training mode: the per-sample stochastic-depth factors of ALL blocks come from one draw (2 launches per step
         # instead of 6 per block); each DropPath call of the reference still gets its own independent Bernoulli(keep) samples.
-        if not self.training and not torch.is_grad_enabled() and len(self.blocks) > 0:
-            # inference: all stages in one native call, InstanceNorms inside the whole-frame projection kernels (ops.trunk_eval)
+        if not self.training and not torch.is_grad_enabled() and len(self.blocks) > 0 and ops.trunk_eval_applies(tok):
+            # inference: all stages in one native call, InstanceNorms inside the whole-frame projection kernels -- through the
+            # dispatcher-visible operator torch.ops.bubbleformer_amd.trunk_eval (torch_ops.py)
+            from .. import torch_ops  # noqa: F401  (registers the operators)
             b0 = self.blocks[0]
-            stages = []
+            kinds, params = [], []
             for blk in self.blocks:
-                stages.append(("temporal", blk.temporal.stage_params()))
-                stages.append(("spatial", blk.spatial.stage_params()))
-            out = ops.trunk_eval(tok, b0.temporal.num_heads, b0.temporal.attn_scale, b0.spatial.feat_scale, stages)
-            if out is not None:
-                return out
+                kinds += [0, 1]
+                params += list(blk.temporal.stage_params()) + list(blk.spatial.stage_params())
+            return torch.ops.bubbleformer_amd.trunk_eval(tok.contiguous(), b0.temporal.num_heads, bool(b0.temporal.attn_scale),
+                                                        bool(b0.spatial.feat_scale), kinds, params)
         rates = [float(getattr(blk.temporal.drop_path, "drop_prob", 0.0)) for blk in self.blocks]
         table = None
         if self.training and any(r > 0.0 for r in rates):

@@ -244,6 +244,12 @@ def clear_eval_weights() -> None:
     _EVAL_ARENAS.clear()
 
 
+def trunk_eval_applies(tok: torch.Tensor) -> bool:
+    """Whether ops.trunk_eval covers this token tensor (bf16 on the GPU, 12 x 12-token frames, E = 384, not switched off)."""
+    return (tok.is_cuda and tok.dtype == torch.bfloat16 and tok.dim() == 5 and tok.shape[2] * tok.shape[3] == 144 and tok.shape[4] == 384
+            and tok.shape[2] <= 16 and tok.shape[3] <= 16 and tok.shape[1] <= 32 and os.environ.get("BF_TRUNK_EVAL", "1") != "0")
+
+
 def trunk_eval(tok: torch.Tensor, heads: int, attn_scale: bool, feat_scale: bool, stages) -> Optional[torch.Tensor]:
     """Eval forward of all trunk stages in ONE native call (bf_trunk_eval_fwd: whole-frame projection kernels with the InstanceNorms
     inside, nothing saved for a backward).  stages: [(kind, params)] in call order.  The bf16 weight copies and out-projection folds

@@ -293,6 +293,34 @@ def test_config4_inference_trunk_equals_the_stage_forwards(B, monkeypatch):
         assert torch.equal(f3, s3) and not torch.equal(f3, f2)
 
 
+def test_inference_operators_are_registered_with_the_dispatcher():
+    """torch.ops.bubbleformer_amd.trunk_eval / frame_linear (torch_ops.py): schema + fake-tensor implementation pass torch.library.opcheck,
+    the eval forward shows up under its operator name in the profiler, and the model's prediction goes through it."""
+    from bubbleformer_amd import torch_ops  # noqa: F401
+    from bubbleformer_amd.models import get_model
+    torch.manual_seed(5)
+    m = get_model("filmavit", input_fields=4, output_fields=4, time_window=4, patch_size=16, embed_dim=384, num_heads=6, processor_blocks=2,
+                  num_fluid_params=9, drop_path=0.0, compute_dtype=torch.bfloat16).cuda().eval()
+    x, c = torch.randn(1, 4, 4, 192, 192, device="cuda"), torch.randn(1, 9, device="cuda")
+    kinds, params = [], []
+    for blk in m.blocks:
+        kinds += [0, 1]
+        params += list(blk.temporal.stage_params()) + list(blk.spatial.stage_params())
+    with torch.no_grad():
+        tok = m.embed.tokens(x, c, m.film_embed.film_params(), compute_dtype=torch.bfloat16)
+        args = (tok, 6, True, True, kinds, [p.detach() if p is not None else None for p in params])
+        torch.library.opcheck(torch.ops.bubbleformer_amd.trunk_eval.default, args, test_utils=("test_schema", "test_faketensor"))
+        a = torch.randn(2 * 144, 384, device="cuda").bfloat16()
+        w = (torch.randn(96, 384, device="cuda") * 0.1).bfloat16()
+        torch.library.opcheck(torch.ops.bubbleformer_amd.frame_linear.default, (a, w, 2, 144),
+                              dict(norm_w=torch.ones(384, device="cuda"), norm_b=torch.zeros(384, device="cuda"), bias=torch.randn(96, device="cuda")),
+                              test_utils=("test_schema", "test_faketensor"))
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU]) as prof:
+            pred = m(x, c)
+        assert any("bubbleformer_amd::trunk_eval" in e.key for e in prof.key_averages())
+        assert torch.equal(m.debed.from_tokens(torch.ops.bubbleformer_amd.trunk_eval(*args)), pred)
+
+
 @pytest.mark.parametrize("name,kw", [("avit", dict(attn_scale=False, feat_scale=False)), ("avit", dict(attn_scale=True, feat_scale=False)),
                                      ("filmavit", dict(attn_scale=False, feat_scale=True, num_fluid_params=9))])
 def test_inference_trunk_variants_equal_the_stage_forwards(name, kw, monkeypatch):
