@@ -171,7 +171,15 @@ __global__ void __launch_bounds__(512) tokred_kernel(const bf16* __restrict__ A,
 // (batches of 8 independent 16-byte loads per thread) and added in slice order: a loop of load-then-add ran at one memory round trip per
 // slice (24 us per launch at 8 slices for 18 MB).
 __global__ void __launch_bounds__(256) tokred_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ cslab, int nslice, long n,
-                                                            int Nout, float* __restrict__ out, float* __restrict__ colsum, int accumulate) {
+                                                            int Nout, float* __restrict__ out, float* __restrict__ colsum, int accumulate, int cs_mode) {
+    if (colsum && cs_mode == 0 && blockIdx.x == 0) {      // single-block column sum (the default, see the host side)
+        for (int m = threadIdx.x; m < Nout; m += 256) {
+            float a = accumulate ? colsum[m] : 0.f;
+            for (int s = 0; s < nslice; ++s) a += cslab[(size_t)s * Nout + m];
+            colsum[m] = a;
+        }
+    }
+    if (cs_mode == 0) colsum = nullptr;
     const long n4 = n / 4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         float4 a = accumulate ? reinterpret_cast<const float4*>(out)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -185,10 +193,18 @@ __global__ void __launch_bounds__(256) tokred_reduce_kernel(const float* __restr
         }
         reinterpret_cast<float4*>(out)[i] = a;
     }
-    if (colsum && blockIdx.x == 0) {
-        for (int m = threadIdx.x; m < Nout; m += 256) {
+    if (colsum) {       // spread over the LAST blocks of the grid (one block doing all Nout columns was the launch's long pole: 6 x 8 dependent loads)
+        const long t = ((long)gridDim.x - 1 - blockIdx.x) * 256 + threadIdx.x;
+        for (long m = t; m < Nout; m += (long)gridDim.x * 256) {
             float a = accumulate ? colsum[m] : 0.f;
-            for (int s = 0; s < nslice; ++s) a += cslab[(size_t)s * Nout + m];
+            for (int s0 = 0; s0 < nslice; s0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = s0 + q < nslice ? cslab[(size_t)(s0 + q) * Nout + m] : 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (s0 + q < nslice) a += v[q];
+            }
             colsum[m] = a;
         }
     }
@@ -272,7 +288,12 @@ extern "C" int bf_gemm_tokred(int dtype, int Nout, int Kin, int64_t M, const voi
     {
         BfProfScope prof(st, "tokred_reduce_kernel", 0.0, (double)(ns + 1 + (accumulate ? 1 : 0)) * n * 4.0);
         const int blocks = (int)std::min<long>(512, (n / 4 + 255) / 256);
-        hipLaunchKernelGGL(tokred_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, cslab, ns, n, Nout, out, colsum, accumulate);
+        // BF_TOKRED_CS=1: the column sums spread over the grid with batched loads -- the reduce drops from 15.5 to 7.6 us alone and from 20 to
+        // 10.6 us in the step, and the STEP gets slower (658-660 vs 667-669 samples/s, three A/B pairs on two boxes; tokred_kernel itself
+        // 56 -> 63 us beside the main queue).  An explicit pause of 5 / 10 / 20 us after the reduce is no substitute (664 / 661 / 630): the
+        // step's two queues sit at an operating point that the side queue's exact timing decides.  Default: the single-block form.
+        static const int cs_mode = env_int("BF_TOKRED_CS", 0);
+        hipLaunchKernelGGL(tokred_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, cslab, ns, n, Nout, out, colsum, accumulate, cs_mode);
         BF_CHECK_LAUNCH();
     }
     return 0;
