@@ -65,8 +65,11 @@ class _AxialBase(nn.Module):
             for blk in self.blocks:
                 kinds += [0, 1]
                 params += list(blk.temporal.stage_params()) + list(blk.spatial.stage_params())
+            owner = self.__dict__.get("_bf_eval_owner")
+            if owner is None:
+                owner = self.__dict__["_bf_eval_owner"] = ops.new_eval_token()      # this instance's prepared-weights cache key
             return torch.ops.bubbleformer_amd.trunk_eval(tok.contiguous(), b0.temporal.num_heads, bool(b0.temporal.attn_scale),
-                                                        bool(b0.spatial.feat_scale), kinds, params)
+                                                        bool(b0.spatial.feat_scale), kinds, params, owner)
         rates = [float(getattr(blk.temporal.drop_path, "drop_prob", 0.0)) for blk in self.blocks]
         table = None
         if self.training and any(r > 0.0 for r in rates):

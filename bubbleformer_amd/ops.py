@@ -250,12 +250,24 @@ def trunk_eval_applies(tok: torch.Tensor) -> bool:
             and tok.shape[2] <= 16 and tok.shape[3] <= 16 and tok.shape[1] <= 32 and os.environ.get("BF_TRUNK_EVAL", "1") != "0")
 
 
-def trunk_eval(tok: torch.Tensor, heads: int, attn_scale: bool, feat_scale: bool, stages) -> Optional[torch.Tensor]:
+_EVAL_TOKENS = [0]
+
+
+def new_eval_token() -> int:
+    """A process-unique id for one owner of prepared inference weights (a model instance).  The prepared-weights cache is keyed by it:
+    parameter ADDRESSES alone would let a new model that the allocator placed where a freed one lived, with equal version counters,
+    find the old model's weights."""
+    _EVAL_TOKENS[0] += 1
+    return _EVAL_TOKENS[0]
+
+
+def trunk_eval(tok: torch.Tensor, heads: int, attn_scale: bool, feat_scale: bool, stages, owner: int = 0) -> Optional[torch.Tensor]:
     """Eval forward of all trunk stages in ONE native call (bf_trunk_eval_fwd: whole-frame projection kernels with the InstanceNorms
     inside, nothing saved for a backward).  stages: [(kind, params)] in call order.  The bf16 weight copies and out-projection folds
     are prepared once per set of weights (torch version counters + this package's optimizer epoch) and kept per model.
     Returns None when the path does not apply (not bf16 on the GPU, shape not covered, BF_TRUNK_EVAL=0): the caller then runs the
-    stage forwards.  Under HIP-graph capture the preparation must already have happened (utils/rollout.py warms up first)."""
+    stage forwards.  Under HIP-graph capture the preparation must already have happened (utils/rollout.py warms up first).
+    owner: ops.new_eval_token() of the caller that owns these parameters (models pass theirs); 0 = keyed by parameter addresses only."""
     if not tok.is_cuda or tok.dtype != torch.bfloat16 or not stages or os.environ.get("BF_TRUNK_EVAL", "1") == "0":
         return None
     tok = tok.contiguous()
@@ -268,7 +280,7 @@ def trunk_eval(tok: torch.Tensor, heads: int, attn_scale: bool, feat_scale: bool
     structs = [(L.TemporalParams if kind == "temporal" else L.SpatialParams)(*[_p(p) for p in ps]) for (kind, _), ps in zip(stages, plist)]
     pp = (C.c_void_p * n)(*[C.addressof(s) for s in structs])
     flat = [p for ps in plist for p in ps if p is not None]
-    key = (str(tok.device), tuple(p.data_ptr() for p in flat), h, w, E, heads, bool(attn_scale), bool(feat_scale))
+    key = (int(owner), str(tok.device), tuple(p.data_ptr() for p in flat), h, w, E, heads, bool(attn_scale), bool(feat_scale))
     stamp = (_WEIGHTS_EPOCH[0], tuple(p._version for p in flat))
     ent = _EVAL_ARENAS.get(key)
     if ent is None or ent[0] != stamp:

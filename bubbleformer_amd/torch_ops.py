@@ -24,9 +24,10 @@ _NT, _NS = len(L.TEMPORAL_FIELDS), len(L.SPATIAL_FIELDS)
 
 @custom_op("bubbleformer_amd::trunk_eval", mutates_args=(), device_types="cuda")
 def trunk_eval(tok: torch.Tensor, heads: int, attn_scale: bool, feat_scale: bool, kinds: List[int],
-               params: List[Optional[torch.Tensor]]) -> torch.Tensor:
+               params: List[Optional[torch.Tensor]], owner: int = 0) -> torch.Tensor:
     """tok (B, T, h, w, E) bf16 tokens; kinds[i] 0 = temporal, 1 = axial stage; params: the stages' parameters, flattened in
-    ``_lib.TEMPORAL_FIELDS`` / ``_lib.SPATIAL_FIELDS`` order (None where the reference has no parameter)."""
+    ``_lib.TEMPORAL_FIELDS`` / ``_lib.SPATIAL_FIELDS`` order (None where the reference has no parameter); owner: ops.new_eval_token() of
+    the model instance (the key of its prepared-weights cache)."""
     stages, at = [], 0
     for k in kinds:
         n = _NT if k == 0 else _NS
@@ -34,14 +35,14 @@ def trunk_eval(tok: torch.Tensor, heads: int, attn_scale: bool, feat_scale: bool
         at += n
     if at != len(params):
         raise L.BubbleformerHipError("trunk_eval: parameter list does not match the stage kinds")
-    out = ops.trunk_eval(tok, heads, attn_scale, feat_scale, stages)
+    out = ops.trunk_eval(tok, heads, attn_scale, feat_scale, stages, owner)
     if out is None:
         raise L.BubbleformerHipError("trunk_eval: shape not covered (bf16, 12 x 12-token frames, E = 384): check ops.trunk_eval_applies first")
     return out
 
 
 @trunk_eval.register_fake
-def _(tok, heads, attn_scale, feat_scale, kinds, params):
+def _(tok, heads, attn_scale, feat_scale, kinds, params, owner=0):
     return torch.empty_like(tok)
 
 
