@@ -245,9 +245,13 @@ def clear_eval_weights() -> None:
 
 
 def trunk_eval_applies(tok: torch.Tensor) -> bool:
-    """Whether ops.trunk_eval covers this token tensor (bf16 on the GPU, 12 x 12-token frames, E = 384, not switched off)."""
+    """Whether ops.trunk_eval is the path for this token tensor: bf16 on the GPU, 12 x 12-token frames, E = 384, not switched off, and at most
+    BF_TRUNK_EVAL_MAX_FRAMES frames (default 96).  The whole-frame kernels are built for few frames: measured eval forward, 16x192x192 clips,
+    batch 1 / 2 / 4 / 8 / 16: 2.23 / 1.83 / 2.76 / 4.67 / 8.97 ms against 3.20 / 2.37 / 3.02 / 4.09 / 7.71 ms for the stage forwards (eager) --
+    from 128 frames on the streaming GEMMs of the training-shaped forward win (one workgroup per CU pays its prologue and epilogue serially)."""
     return (tok.is_cuda and tok.dtype == torch.bfloat16 and tok.dim() == 5 and tok.shape[2] * tok.shape[3] == 144 and tok.shape[4] == 384
-            and tok.shape[2] <= 16 and tok.shape[3] <= 16 and tok.shape[1] <= 32 and os.environ.get("BF_TRUNK_EVAL", "1") != "0")
+            and tok.shape[2] <= 16 and tok.shape[3] <= 16 and tok.shape[1] <= 32 and os.environ.get("BF_TRUNK_EVAL", "1") != "0"
+            and tok.shape[0] * tok.shape[1] <= int(os.environ.get("BF_TRUNK_EVAL_MAX_FRAMES", "96")))
 
 
 _EVAL_TOKENS = [0]
