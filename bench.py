@@ -213,11 +213,12 @@ def roofline_from(prof, nprof, dtype, config):
     tflops = flops / (avg_ms * 1e-3) / 1e12
     gbs = nbytes / (avg_ms * 1e-3) / 1e9
     traffic, src = None, None
-    tpath = os.path.join(REPO, "profiles", "r02_kernels.json")          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
-    if config == "configs1" and os.path.exists(tpath):
+    tname = {"configs1": "r02_kernels.json", "configs4": "r02_rollout_kernels.json"}.get(config)     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
+    tpath = os.path.join(REPO, "profiles", tname) if tname else None
+    if tpath and os.path.exists(tpath):
         for k in json.load(open(tpath))["kernels"]:
             if k["kernel"] == name and "hbm_bytes_per_launch" in k:
-                traffic, src = k["hbm_bytes_per_launch"], "profiles/r02_kernels.json (rocprofv3 --pmc passes of this command, committed; not re-measured in this run)"
+                traffic, src = k["hbm_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc passes of this command, committed; not re-measured in this run)" % tname
     if flops > 0 and flops / max(nbytes, 1.0) >= ridge:
         r = {"kernel": name, "bound": "mfma", "achieved": tflops, "peak": peak_tf, "unit": "TFLOP/s", "frac": tflops / peak_tf}
     else:

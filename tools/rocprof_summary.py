@@ -46,6 +46,13 @@ def normalise(name: str) -> str:
     if m:
         ns, mt, bk = m.groups()
         return "tokred_kernel<%dx128,bk%s,slots%s>" % (128 * int(mt), bk, ns)
+    m = re.search(r"frame_res_kernel<(\d), (\d), (true|false)>", name) or re.search(r"frame_res_kernelILi(\d)ELi(\d)ELb([01])E", name)
+    if m:
+        ntc, _, norm = m.groups()
+        return "frame_linear<res,bn%d%s>" % (32 * int(ntc), ",norm" if norm in ("true", "1") else "")
+    m = re.search(r"frame_ring_kernel<(\d), (\d)>", name) or re.search(r"frame_ring_kernelILi(\d)ELi(\d)E", name)
+    if m:
+        return "frame_linear<ring,bn%d,in>" % (32 * int(m.group(1)))      # the model uses the streamed form for fc2 + InstanceNorm only
     if "tokred_reduce_kernel" in name:
         return "tokred_reduce_kernel"
     if "gemm_inbwd_frames_kernel" in name:
