@@ -4,6 +4,10 @@
 
 namespace bfgemm {
 
+#ifndef PP_SETPRIO
+#define PP_SETPRIO 0      // s_setprio around the MFMA clusters of the ping-pong kernels (measured, see DESIGN)
+#endif
+
 constexpr int TAB = 2048;   // floats per prologue-table array (sc, sh): 16 KiB together
 
 struct OpDev {

@@ -264,6 +264,250 @@ __global__ void __launch_bounds__(512) stream_gemm_kernel(StreamArgs a) {
     }
 }
 
+
+// ================================================================================================ ping-pong form (both operands streamed)
+// The same product, tiles, teams and epilogue, with a different main loop (cdna_hip_programming.md section 5, the 8-phase template's
+// wave stagger; MI355X_MICROARCH.md "Two waves per SIMD"):
+//  * nothing is resident: each 64-deep K-step brings a [256][64] token chunk AND the [128][64] weight chunk (from L2: the weight is a
+//    few hundred KB that every workgroup re-reads) into one of THREE 48 KB slots; two K-steps are always in flight ahead of the one being
+//    multiplied -- across tile boundaries -- so a DMA has more than a whole K-step to land and any K (a multiple of 64) is covered;
+//  * a K-step is two halves (k 0..31, 32..63); per half a wave runs a LOAD segment (8 ds_read_b128 for 4 + 4 fragments, 3 of its 6 DMA
+//    pieces of step + 2, the counted vmcnt wait) and a COMPUTE segment (16 MFMA = 256 matrix-pipe cycles), each closed by a raw
+//    s_barrier.  Waves 4-7 run one barrier behind waves 0-3: on every SIMD one wave computes while its partner loads, so the matrix pipe
+//    alternates between the two instead of idling through LDS reads, DMA issue and barrier skew (the lock-step loop above spends a step as
+//    the SUM of those parts);
+//  * at the end of a tile the two halves re-align (one barrier), run the register epilogue at the same time (its stores drain under the
+//    next tile's first steps: the DMAs those steps wait for are OLDER than the stores in the in-order vmcnt queue) and stagger again.
+constexpr int PSLOT = (ACHUNK + CHUNK) * 2;   // bytes of one ring slot: token chunk + weight chunk
+constexpr int PNSLOT = 3;
+
+__device__ __forceinline__ void wait_vm_wide(int n) {      // as wait_vm_n, up to 40 outstanding operations (epilogue stores + look-ahead DMAs)
+    if (n < 16) { wait_vm_n(n); return; }
+    if (n >= 40) { wait_vm<40>(); return; }
+    switch ((n - 16) >> 2) {          // steps of 4: a smaller count than asked for is always safe
+        case 0: wait_vm<16>(); break; case 1: wait_vm<20>(); break; case 2: wait_vm<24>(); break;
+        case 3: wait_vm<28>(); break; case 4: wait_vm<32>(); break; default: wait_vm<36>(); break;
+    }
+}
+
+template <int AUX, bool GELU2, bool CS>
+__global__ void __launch_bounds__(512) stream_pp_kernel(StreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int KS = a.KS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                     // 4 x 2 waves, 64 x 64 outputs each
+    const bool late = wave >= 4;                                 // the half that runs one barrier behind
+
+    // ---- teams (as above): nb workgroups on one XCD hold the nb column blocks and sweep the same row tiles
+    const int xl = blockIdx.x & 7, j = blockIdx.x >> 3, wpx = gridDim.x >> 3;
+    const int tpx = wpx / a.nb;
+    if (j >= tpx * a.nb) return;
+    const int team = xl * tpx + j / a.nb, nteams = 8 * tpx;
+    const int c_nb = j % a.nb;
+    const int t_beg = (int)((long)a.mt * team / nteams), t_end = (int)((long)a.mt * (team + 1) / nteams);
+    if (t_beg >= t_end) return;
+    const int total_steps = (t_end - t_beg) * KS;
+
+    // ---- DMA geometry (as above): piece = 8 rows x 128 bytes; token chunk 32 pieces (4 per wave), weight chunk 16 (2 per wave)
+    long roffA[4], roffB[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int r = 8 * (wave * 4 + t) + (lane >> 3);
+        roffA[t] = (long)r * a.lda + 8 * ((lane & 7) ^ ((r >> 1) & 7));
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int r = 8 * (wave * 2 + t) + (lane >> 3);
+        roffB[t] = (long)r * a.ldw + 8 * ((lane & 7) ^ ((r >> 1) & 7));
+    }
+    const unsigned lds0 = lds_addr(smem);
+    const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 4096u);                              // this wave's four pieces of a token chunk
+    const unsigned ldsB = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(ACHUNK * 2) + (unsigned)wave * 2048u);     // ... two pieces of a weight chunk
+    const bf16* w0 = a.W + (long)c_nb * BNB * a.ldw;
+
+    int issued = 0;                                  // vector-memory operations this wave has issued so far (DMA, loads, stores)
+    // ---- DMA issue cursor: two K-steps in front of the compute loop, across tile boundaries
+    int i_ks = 0, i_left = total_steps, i_slot = 0;
+    const bf16* i_row = a.A + (long)t_beg * BM * a.lda;
+    auto issue_lo = [&]() {                          // first half of a step's pieces: token pieces 0 .. 2
+        const unsigned dst = ldsA + (unsigned)i_slot * (unsigned)PSLOT;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) glds16(i_row + roffA[t] + i_ks * BK, dst + t * 1024u);
+        issued += 3;
+    };
+    auto issue_hi = [&]() {                          // second half: token piece 3 and the two weight pieces; the cursor moves on
+        glds16(i_row + roffA[3] + i_ks * BK, ldsA + (unsigned)i_slot * (unsigned)PSLOT + 3 * 1024u);
+        const unsigned dst = ldsB + (unsigned)i_slot * (unsigned)PSLOT;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) glds16(w0 + roffB[t] + i_ks * BK, dst + t * 1024u);
+        issued += 3;
+        i_slot = i_slot == PNSLOT - 1 ? 0 : i_slot + 1;
+        --i_left;
+        if (++i_ks == KS) { i_ks = 0; i_row += (long)BM * a.lda; }
+    };
+
+    // ---- epilogue constants (as above)
+    const int li = lane & 15, lg = lane >> 4;
+    const int c8 = wn * 64 + (lg & 1) * 16 + (lg >> 1) * 8;       // + 32 * pp
+    float e_bias[2][8], e_cs[2][CS ? 8 : 1], e_ch[2][CS ? 8 : 1];
+    {
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int n = c_nb * BNB + c8 + 32 * pp + q;
+                e_bias[pp][q] = a.bias ? a.bias[n] : 0.f;
+                if constexpr (CS) { e_cs[pp][q] = a.colscale ? a.colscale[n] : 1.f; e_ch[pp][q] = a.colscale ? a.colshift[n] : 0.f; }
+            }
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                asm volatile("" : "+v"(e_bias[pp][q]));
+                if constexpr (CS) { asm volatile("" : "+v"(e_cs[pp][q])); asm volatile("" : "+v"(e_ch[pp][q])); }
+            }
+    }
+
+    // ---- prologue: steps 0 and 1 in flight, step 0 landed for every wave
+    issue_lo(); issue_hi();
+    const int mark0 = issued;
+    if (i_left > 0) { issue_lo(); issue_hi(); }
+    int mark_next = issued;                          // `issued` right after the last piece of the step FOLLOWING the one being multiplied
+    wait_vm_wide(issued - mark0);
+    __builtin_amdgcn_s_barrier();
+
+    f32x4 acc[4][4];
+    uint4 auxr[4][2];
+    float rsr[4] = {1.f, 1.f, 1.f, 1.f};
+    const bool has_rs = CS && a.rowscale != nullptr;
+    int aux_mark = 0;
+    int slot = 0, done = 0;                          // done: K-steps multiplied so far
+    for (int t = t_beg; t < t_end; ++t) {
+        const int m0 = t * BM;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (late) __builtin_amdgcn_s_barrier();      // stagger: waves 4-7 one barrier behind
+        for (int ks = 0; ks < KS; ++ks, ++done) {
+            const bf16* cA = reinterpret_cast<const bf16*>(smem + (size_t)slot * PSLOT);
+            const bf16* cB = cA + ACHUNK;
+            bf16x8 fa[4], fb[4];
+            int mark_nn = mark_next;
+            // ======== load segment, k 0..31
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = frag_bf16<false, BK>(cA, wm * 64 + i * 16, 0, lane);
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn) fb[jn] = frag_bf16<false, BK>(cB, wn * 64 + jn * 16, 0, lane);
+            if (ks == 0) {                           // this tile's residual / gelu' operand and row factors: in flight for the whole tile
+                if constexpr (AUX != BF_AUX_NONE) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int pp = 0; pp < 2; ++pp)
+                            gload16(auxr[i][pp], a.aux + (long)(m0 + wm * 64 + i * 16 + li) * a.ld_aux + c_nb * BNB + c8 + 32 * pp);
+                    issued += 8;
+                }
+                if (has_rs) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gload4(rsr[i], a.rowscale + (m0 + wm * 64 + i * 16 + li) / a.rpg);
+                    issued += 4;
+                }
+                aux_mark = issued;
+            }
+            // step done + 2 goes into the slot that held step done - 1: every wave finished reading it before the barrier that ended
+            // ITS load segment of that step's second half
+            const bool more = i_left > 0 && !(a.dbg & 32);
+            if (more) issue_lo();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ======== compute segment
+            if (PP_SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jn = 0; jn < 4; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[jn], fa[i], acc[i][jn], 0, 0, 0);
+            if (PP_SETPRIO) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ======== load segment, k 32..63
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = frag_bf16<false, BK>(cA, wm * 64 + i * 16, 32, lane);
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn) fb[jn] = frag_bf16<false, BK>(cB, wn * 64 + jn * 16, 32, lane);
+            if (more) { issue_hi(); mark_nn = issued; }
+            if (done + 1 < total_steps && !(a.dbg & 1)) wait_vm_wide(issued - mark_next);      // this wave's pieces of the next step have landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ======== compute segment
+            if (PP_SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jn = 0; jn < 4; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[jn], fa[i], acc[i][jn], 0, 0, 0);
+            if (PP_SETPRIO) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            slot = slot == PNSLOT - 1 ? 0 : slot + 1;
+            mark_next = mark_nn;
+        }
+        if (!late) __builtin_amdgcn_s_barrier();     // re-align: pairs with the extra barrier of waves 4-7
+        // ---- epilogue of the tile, from registers, both halves at the same time
+        if (AUX != BF_AUX_NONE || has_rs) {
+            wait_vm_wide(issued - aux_mark);
+            if constexpr (AUX != BF_AUX_NONE) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp) asm volatile("" : "+v"(auxr[i][pp].x), "+v"(auxr[i][pp].y), "+v"(auxr[i][pp].z), "+v"(auxr[i][pp].w));
+            }
+            if constexpr (CS) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(rsr[i]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + li;
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                    const u32x2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][2 * pp][r]), __float_as_uint(acc[i][2 * pp + 1][r]), false, false);
+                    v[r] = __uint_as_float(sw[0]); v[4 + r] = __uint_as_float(sw[1]);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    v[q] += e_bias[pp][q];
+                    if constexpr (CS) v[q] = fmaf(v[q], e_cs[pp][q], e_ch[pp][q]) * (has_rs ? rsr[i] : 1.f);
+                }
+                if constexpr (AUX != BF_AUX_NONE) {
+                    const bf16x8 ax = __builtin_bit_cast(bf16x8, auxr[i][pp]);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = AUX == BF_AUX_ADD ? v[q] + (float)ax[q] : v[q] * dgelu_fast((float)ax[q]);
+                }
+                bf16x8 o;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o[q] = (bf16)v[q];
+                const long off = (long)m * a.ldc + c_nb * BNB + c8 + 32 * pp;
+                *reinterpret_cast<bf16x8*>(a.C + off) = o;
+                if constexpr (GELU2) {
+                    bf16x8 g8;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) g8[q] = (bf16)gelu_fast(v[q]);
+                    *reinterpret_cast<bf16x8*>(a.gelu_out + off) = g8;
+                }
+            }
+        }
+        issued += GELU2 ? 16 : 8;
+    }
+}
+
 int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 
 int num_cus() {
@@ -284,7 +528,16 @@ int bf_gemm_stream_try(int M, int N, int K, const bf_operand* A, const bf_operan
     if (A->layout != BF_LAY_KC || B->layout != BF_LAY_KC || A->pro != BF_PRO_NONE || B->pro != BF_PRO_NONE) return 1;
     if (A->gw > 0 || A->seglen > 0 || B->gw > 0 || B->seglen > 0 || E->gw > 0 || E->seglen > 0) return 1;
     if (E->out_mode != BF_OUT_STORE || E->colsum) return 1;
-    if (M % BM || N % BNB || K % BK || K < 4 * BK || K > 6 * BK) return 1;
+    // Two main loops share the tiles, teams and epilogue.  K = 256..384 (the weight block fits the LDS beside a 2-slot token ring): the
+    // weight-stationary loop -- measured 31.0 vs 34.5 us (QKV), 56.7 vs 60.9 us (fc1) against the ping-pong form, whose per-step gain is
+    // eaten by streaming the weight chunk too (6 instead of 4 DMA pieces per wave and step, ~65 cycles of wave time each).  Longer K
+    // (fc2 forward, K = 1536): only the ping-pong form applies, 36 us against 40 us for the 128 x 128 tile kernel.  BF_STREAM_PP=1 / 0
+    // forces one form where both apply.
+    static const int pp_env = env_int("BF_STREAM_PP", -1);
+    if (M % BM || N % BNB || K % BK || K < 2 * BK) return 1;
+    const bool ws_ok = K >= 4 * BK && K <= 6 * BK;
+    const bool use_pp = pp_env == 1 || !ws_ok;
+    if (pp_env == 0 && !ws_ok) return 1;
     if (A->ld % 8 || B->ld % 8 || E->ldc % 8 || (E->aux_mode != BF_AUX_NONE && E->ld_aux % 8)) return 1;
     if (((uintptr_t)A->p | (uintptr_t)B->p | (uintptr_t)E->c | (uintptr_t)E->aux | (uintptr_t)E->gelu_out) & 15) return 1;
     if (E->gelu_out && E->aux_mode != BF_AUX_NONE) return 1;
@@ -302,11 +555,20 @@ int bf_gemm_stream_try(int M, int N, int K, const bf_operand* A, const bf_operan
     if (a.nb > grid / 8) return 1;                    // a team (one workgroup per column block) must fit one XCD
     const int lds_bytes = a.KS * CHUNK * 2 + NSLOT * ACHUNK * 2;
     static thread_local char pname[64];
-    snprintf(pname, sizeof(pname), "stream_gemm<%s>", E->gelu_out ? "gelu2" : E->aux_mode == BF_AUX_ADD ? "add" : E->aux_mode == BF_AUX_DGELU ? "dgelu" : "plain");
+    snprintf(pname, sizeof(pname), use_pp ? "stream_pp<%s>" : "stream_gemm<%s>", E->gelu_out ? "gelu2" : E->aux_mode == BF_AUX_ADD ? "add" : E->aux_mode == BF_AUX_DGELU ? "dgelu" : "plain");
     BfProfScope prof(st, pname, 2.0 * M * N * K, ((double)M * K + (double)N * K + (double)M * N * (E->gelu_out ? 2 : 1) + (E->aux_mode != BF_AUX_NONE ? (double)M * N : 0.0)) * 2.0);
 #define BF_STREAM_GO(AUXM, G2, CSF)                                                                                                       \
     do {                                                                                                                                \
-        static bool attr_done = false;                                                                                                  \
+        static bool attr_done = false, attr_pp_done = false;                                                                            \
+        if (use_pp) {                                                                                                                   \
+            if (!attr_pp_done) {                                                                                                        \
+                hipError_t e_ = hipFuncSetAttribute((const void*)stream_pp_kernel<AUXM, G2, CSF>, hipFuncAttributeMaxDynamicSharedMemorySize, PNSLOT * PSLOT); \
+                if (e_ != hipSuccess) return bf_fail(e_, __FILE__, __LINE__);                                                           \
+                attr_pp_done = true;                                                                                                    \
+            }                                                                                                                           \
+            hipLaunchKernelGGL((stream_pp_kernel<AUXM, G2, CSF>), dim3(grid), dim3(512), PNSLOT * PSLOT, st, a);                        \
+            break;                                                                                                                      \
+        }                                                                                                                               \
         if (!attr_done) {                                                                                                               \
             hipError_t e_ = hipFuncSetAttribute((const void*)stream_gemm_kernel<AUXM, G2, CSF>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * CHUNK * 2 + NSLOT * ACHUNK * 2); \
             if (e_ != hipSuccess) return bf_fail(e_, __FILE__, __LINE__);                                                               \

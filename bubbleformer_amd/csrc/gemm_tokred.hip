@@ -4,19 +4,29 @@
 //                                                                         linear_layers.py:18-25; both operands token-major)
 //
 // The reduction runs over tens of thousands of tokens and the result is a few hundred KB, so the split over workgroups is a split
-// of the TOKENS.  What that costs is the partial results: (#workgroups) x (tile bytes) of fp32 leave the chip whatever the tile
-// shape.  This kernel therefore uses FEW, LONG slices (8): one workgroup = one 128 x 128 (or 384 x 128) output tile x one token slice,
-// 72-288 workgroups per launch -- the launch deliberately does not fill the chip; it runs beside the data-gradient kernels of the
-// caller's stream -- and its partial tile goes to a slab with plain 16-byte stores.  A second tiny kernel adds the slabs in slice
-// order: the result is bit-reproducible run to run (no float atomics anywhere) and the slab traffic is 2 x 4 x |out| instead of
-// the split-K atomics' 9-19 x |out|.
+// of the TOKENS, and what that costs is the partial results: (#workgroups) x (tile bytes) of fp32 leave the chip whatever the tile
+// shape.  So: FEW workgroups, each as efficient as a CU can be, beside the caller's data-gradient kernels (the launch deliberately
+// does not fill the chip).  The partial tile goes to a slab with plain 16-byte stores and a second small kernel adds the slabs in
+// slice order: bit-reproducible run to run, no float atomics.
 //
-// Pipeline (cdna_hip_programming.md section 5, "glds ... counted vmcnt ... raw s_barrier"): operand chunks of 64 tokens x 128
-// channels go global -> LDS directly (global_load_lds_dwordx4, no staging registers) into a ring of NSLOT slots; NSLOT-1 chunks are
-// in flight while one is multiplied; one raw s_barrier per K-step with a counted s_waitcnt vmcnt, never 0 inside the loop.  The LDS
-// image is the swizzled [k][128] tile of gemm_common.h (conflict-free ds_read_b64_tr_b16); the DMA writes LDS lane-linearly, so the
-// swizzle is applied to each lane's SOURCE address (a permutation of the 16-byte chunks inside a 256-byte row).
-// The bias gradient colsum(dy) comes out of the same pass: one extra MFMA per K-step against an all-ones operand.
+// Main kernel (tokred_pp_kernel): one workgroup = one 384 x 192 output tile x one token slice -- 128 FLOP per staged byte, the ratio
+// of a 256 x 256 tile, in a shape that divides every trunk width (E, 3E, 4E with E a multiple of 384) -- one workgroup per CU
+// (144 KB of LDS), 8 waves as 4 x 2 with 96 x 96 outputs each (36 accumulator tiles of 16 x 16).  Schedule (cdna_hip_programming.md
+// section 5, the 8-phase template's ping-pong, and MI355X_MICROARCH.md "Two waves per SIMD"):
+//  * the unit of work is a HALF-step of 32 tokens.  Operand rows go global -> LDS by DMA (global_load_lds_dwordx4, no staging
+//    registers) into a ring of four 36 KB half-buffers: while half H is read, halves H+1 .. H+3 are landing or in flight; each wave
+//    waits with a counted s_waitcnt vmcnt for exactly its own pieces of half H+1 and never drains the queue inside the loop;
+//  * per half a wave runs a LOAD segment (24 ds_read_b64_tr_b16 for 6 + 6 fragments, its 4-5 DMA pieces of half H+3, the counted wait)
+//    and a COMPUTE segment (36 MFMA 16x16x32 = 576 matrix-pipe cycles), each closed by a raw s_barrier.  Waves 4-7 run one barrier
+//    behind waves 0-3, so on every SIMD one wave computes while its partner loads: the matrix pipe alternates between the two and
+//    never waits for LDS reads or DMA issue (with all eight waves in the same phase, the earlier kernel's step was the SUM of its parts);
+//  * LDS image: sub-chunks [32 tokens][64 channels] with 128-byte rows whose 32-byte segments are XORed with a row key, so that the
+//    eight rows a half-wave of the transposing read touches fall on eight different bank groups (no conflicts); the DMA writes LDS
+//    lane-linearly, so the same permutation is applied to each lane's SOURCE address.  A wave's fragments all sit at one column
+//    position of their sub-chunks (output tiles are dealt to the waves interleaved), i.e. one address register per operand side and
+//    immediates for the rest; its DMA pieces are the same rows of consecutive sub-chunks: one source pointer, immediates again.
+//  * the bias gradient colsum(dy) comes out of the same pass: three extra MFMAs per half against an all-ones operand (column block 0 only).
+// Shapes outside that tiling (tiny test models) take the 128 x 128 kernel below (3-slot ring, one barrier per 64-token step).
 #include "gemm_common.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -25,72 +35,267 @@
 namespace {
 using namespace bfgemm;
 
+// ================================================================================================ ping-pong kernel: 384 x 192 or 192 x 192 tiles
+constexpr int PTN = 192;                      // output tile, Kin side (3 sub-chunks of 64 channels)
+constexpr int HR = 32;                        // tokens per half-step
+constexpr int NSB = PTN / 64;
+constexpr int SUBB = HR * 64 * 2;             // bytes of one sub-chunk [32][64] (4 KB = 4 DMA pieces of 8 rows)
+constexpr int NBUF = 4;                       // ring of half-buffers
+// NI = 16-row output tiles per wave on the Nout side = 64-channel sub-chunks of dy per half: 6 -> 384 x 192 tiles (128 FLOP per staged
+// byte, 144 KB of LDS), 3 -> 192 x 192 (96 FLOP per byte, 96 KB): the same slab traffic (that is set by the slice count alone), twice
+// as many, half as long workgroups.
+template <int NI> struct PPGeom {
+    static constexpr int TM = 64 * NI, HALFB = (NI + NSB) * SUBB, TILES = NI * 6, TILE_FLOATS = TM * PTN;
+};
+
+// LDS-DMA with an immediate byte offset (one source pointer serves the same rows of several sub-chunks).  The instruction adds its
+// immediate to BOTH addresses -- the global source and the LDS destination (M0 + offset + 16 * lane) -- so M0 is given the
+// destination minus the offset.
+template <int OFF>
+__device__ __forceinline__ void glds16_off(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst - (unsigned)OFF), "n"(OFF) : "memory");
+}
+
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+__device__ __forceinline__ bf16x8 tr_frag(unsigned addr) {       // addr: LDS byte address of the lane's "lo" block row; "hi" = 4 rows on
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(uintptr_t)addr);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(uintptr_t)(addr + 512u));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+// GRP 0: waves 0-3 (start in the load segment), GRP 1: waves 4-7 (one barrier behind).  Same program, different DMA pieces.
+template <int NI, int GRP>
+__device__ __forceinline__ void tokred_pp_body(const bf16* __restrict__ A, long lda, const bf16* __restrict__ B, long ldb,
+                                               float* __restrict__ slab_tile, float* __restrict__ cslab_row, int nh, bool do_cs,
+                                               unsigned ring_lds, int lane, int w4) {
+    using Gm = PPGeom<NI>;
+    constexpr int HALFB = Gm::HALFB;
+    // DMA pieces per wave per half: the NI + 3 sub-chunks are dealt to the two wave groups (same 8 rows of each): 5 + 4 or 3 + 3
+    constexpr int PG = NI == 6 ? (GRP == 0 ? 5 : 4) : 3;
+    constexpr int NCS = 3;                    // column-sum accumulators per wave (NI = 6: three of its six Nout tiles each; NI = 3: waves 0-3 take all three)
+    const int wm = w4, wn = GRP;              // 4 x 2 waves; output tiles dealt interleaved: Nout tiles wm + 4i, Kin tiles wn + 2j
+    // ---- DMA geometry: piece = 8 token rows x 128 bytes of one sub-chunk; lane -> row 8 w4 + (lane >> 3), LDS 16-byte chunk (lane & 7),
+    // which holds global chunk (lane & 7) ^ (key(row) << 1), key(r) = ((r >> 1) & 1) | (((r >> 3) & 1) << 1)
+    const int dr = 8 * w4 + (lane >> 3);
+    const int dkey = ((dr >> 1) & 1) | (((dr >> 3) & 1) << 1);
+    const int dch = (lane & 7) ^ (dkey << 1);
+    const bf16* pA = A + (long)dr * lda + 8 * dch;
+    const bf16* pB = B + (long)dr * ldb + 8 * dch;
+    const long stepA = (long)HR * lda, stepB = (long)HR * ldb;
+    auto issue = [&](int buf) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)buf * (unsigned)HALFB + (unsigned)w4 * 1024u);
+        if constexpr (NI == 6 && GRP == 0) {
+            glds16_off<0>(pA, base + 0 * SUBB); glds16_off<128>(pA, base + 1 * SUBB); glds16_off<256>(pA, base + 2 * SUBB);
+            glds16_off<384>(pA, base + 3 * SUBB); glds16_off<512>(pA, base + 4 * SUBB);
+            pA += stepA;
+        } else if constexpr (NI == 6) {
+            glds16_off<640>(pA, base + 5 * SUBB);
+            glds16_off<0>(pB, base + 6 * SUBB); glds16_off<128>(pB, base + 7 * SUBB); glds16_off<256>(pB, base + 8 * SUBB);
+            pA += stepA; pB += stepB;
+        } else if constexpr (GRP == 0) {
+            glds16_off<0>(pA, base + 0 * SUBB); glds16_off<128>(pA, base + 1 * SUBB); glds16_off<256>(pA, base + 2 * SUBB);
+            pA += stepA;
+        } else {
+            glds16_off<0>(pB, base + 3 * SUBB); glds16_off<128>(pB, base + 4 * SUBB); glds16_off<256>(pB, base + 5 * SUBB);
+            pB += stepB;
+        }
+    };
+    // ---- fragment addresses (byte offsets inside a half-buffer): lane 16 g + 4 q + p reads block row 8 g + q (lo) / + 4 (hi),
+    // columns pos + 4 p .. + 3 of its tile; key(row) = ((q >> 1) & 1) | ((g & 1) << 1), the same for lo and hi
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int fkey = ((q >> 1) & 1) | ((g & 1) << 1);
+    const unsigned rowb = (unsigned)(8 * g + q) * 128u + (unsigned)(p & 1) * 8u;
+    const unsigned offA = rowb + (unsigned)(((2 * wm + (p >> 1)) ^ (fkey << 1)) * 16);
+    const unsigned offB0 = rowb + (unsigned)(((2 * wn + (p >> 1)) ^ (fkey << 1)) * 16) + (unsigned)(NI * SUBB);
+    const unsigned offB1 = rowb + (unsigned)(((2 * wn + 4 + (p >> 1)) ^ (fkey << 1)) * 16) + (unsigned)(NI * SUBB);
+
+    f32x4 acc[NI][6];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 cs[NCS];
+#pragma unroll
+    for (int c = 0; c < NCS; ++c) cs[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) ones[c] = (bf16)1.0f;
+
+    // ---- prologue: three halves in flight, the first one landed for every wave
+    issue(0);
+    if (nh > 1) issue(1);
+    if (nh > 2) issue(2);
+    if (nh > 2) wait_vm<2 * PG>(); else if (nh > 1) wait_vm<PG>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if constexpr (GRP == 1) __builtin_amdgcn_s_barrier();          // one barrier behind waves 0-3 from here on
+
+    int buf = 0;
+    for (int h = 0; h < nh; ++h) {
+        // ======== load segment: fragments of half h, DMA of half h + 3 (its buffer held half h - 1: every wave finished reading it
+        // before the barrier that ended ITS load segment of h - 1), then the counted wait for this wave's pieces of half h + 1
+        const unsigned hb = ring_lds + (unsigned)buf * (unsigned)HALFB;
+        bf16x8 fa[NI], fb[6];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) fa[i] = tr_frag(hb + offA + (unsigned)(i * SUBB));
+#pragma unroll
+        for (int j = 0; j < 6; ++j) fb[j] = tr_frag(hb + ((j & 1) ? offB1 : offB0) + (unsigned)((j >> 1) * SUBB));
+        if (h + 3 < nh) issue((buf + 3) & 3);
+        const int younger = min(h + 3, nh - 1) - (h + 1);           // halves issued after h + 1 (0 .. 2; negative at the very end)
+        if (younger >= 2) wait_vm<2 * PG>(); else if (younger == 1) wait_vm<PG>(); else wait_vm<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the reads are done before the barrier: the buffer may be refilled after it
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ======== compute segment
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        if (do_cs) {                   // column sums of dy against an all-ones operand
+#pragma unroll
+            for (int c = 0; c < NCS; ++c) {
+                if constexpr (NI == 6) cs[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[NCS * GRP + c], cs[c], 0, 0, 0);
+                else if constexpr (GRP == 0) cs[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[c], cs[c], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        buf = (buf + 1) & 3;
+    }
+    if constexpr (GRP == 0) __builtin_amdgcn_s_barrier();          // pairs with the extra barrier of waves 4-7
+
+    // ---- partial tile -> slab in FRAGMENT order ([wave][i][j][lane] float4: 1 KB contiguous per wave-instruction); the reduce
+    // kernel undoes the order when it writes the result
+    const int wave = GRP * 4 + w4;
+    float* so = slab_tile + ((size_t)wave * Gm::TILES * 64 + lane) * 4;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            *reinterpret_cast<float4*>(so + (size_t)(i * 6 + j) * 256) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    if (do_cs && lane < 16) {
+        if constexpr (NI == 6) {
+#pragma unroll
+            for (int c = 0; c < NCS; ++c) cslab_row[16 * (wm + 4 * (NCS * GRP + c)) + lane] = cs[c][0];
+        } else if constexpr (GRP == 0) {
+#pragma unroll
+            for (int c = 0; c < NCS; ++c) cslab_row[16 * (wm + 4 * c) + lane] = cs[c][0];
+        }
+    }
+}
+
+template <int NI>
+__global__ void __launch_bounds__(512) tokred_pp_kernel(const bf16* __restrict__ A, long lda, const bf16* __restrict__ B, long ldb,
+                                                      float* __restrict__ slab, float* __restrict__ cslab, int Nout, int halves_total,
+                                                      int halves_per, int tiles_k, int ntiles) {
+    using Gm = PPGeom<NI>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // contiguous runs of the (slice, tile) sequence per XCD: the tiles of a slice read the same token rows through one L2
+    const int seq = xcd_remap(blockIdx.x, gridDim.x);
+    const int slice = seq / ntiles, tile = seq - slice * ntiles;
+    const int n0 = (tile / tiles_k) * Gm::TM, c0 = (tile % tiles_k) * PTN;
+    const int h_beg = slice * halves_per;
+    const int nh = min(halves_per, halves_total - h_beg);
+    const bf16* a0 = A + (long)h_beg * HR * lda + n0;
+    const bf16* b0 = B + (long)h_beg * HR * ldb + c0;
+    float* slab_tile = slab + ((size_t)slice * ntiles + tile) * Gm::TILE_FLOATS;
+    const bool do_cs = cslab != nullptr && c0 == 0;
+    float* cslab_row = do_cs ? cslab + (size_t)slice * Nout + n0 : nullptr;
+    const unsigned ring_lds = lds_addr(smem);
+    if (wave < 4) tokred_pp_body<NI, 0>(a0, lda, b0, ldb, slab_tile, cslab_row, nh, do_cs, ring_lds, lane, wave);
+    else tokred_pp_body<NI, 1>(a0, lda, b0, ldb, slab_tile, cslab_row, nh, do_cs, ring_lds, lane, wave - 4);
+}
+
+// out (+)= sum over slices of the fragment-ordered slabs, in slice order; one float4 of one tile per thread, the slices' loads issued
+// together (a load-then-add loop paid a memory round trip per slice).  Column sums likewise from cslab.
+template <int NI, int MAXS>
+__global__ void __launch_bounds__(256) tokred_pp_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ cslab, int nslice,
+                                                               int ntiles, int tiles_k, int Nout, int Kin, float* __restrict__ out,
+                                                               float* __restrict__ colsum, int accumulate) {
+    using Gm = PPGeom<NI>;
+    constexpr int T4 = Gm::TILE_FLOATS / 4;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e < (long)ntiles * T4) {
+        const int tile = (int)(e / T4), r = (int)(e - (long)tile * T4);
+        const int lane = r & 63, t = r >> 6, wave = t / Gm::TILES, ij = t - wave * Gm::TILES, i = ij / 6, j = ij - i * 6;
+        const int wm = wave & 3, wn = wave >> 2;
+        const int nout = (tile / tiles_k) * Gm::TM + 16 * (wm + 4 * i) + (lane & 15);
+        const int kin = (tile % tiles_k) * PTN + 16 * (wn + 2 * j) + 4 * (lane >> 4);
+        const size_t sstride = (size_t)ntiles * Gm::TILE_FLOATS;
+        const float* src = slab + (size_t)tile * Gm::TILE_FLOATS + (size_t)r * 4;
+        float4 v[MAXS];
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) v[s] = s < nslice ? *reinterpret_cast<const float4*>(src + s * sstride) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4* dst = reinterpret_cast<float4*>(out + (size_t)nout * Kin + kin);
+        float4 a = accumulate ? *dst : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s)
+            if (s < nslice) { a.x += v[s].x; a.y += v[s].y; a.z += v[s].z; a.w += v[s].w; }
+        *dst = a;
+    }
+    if (colsum && e < Nout) {
+        float v[MAXS];
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) v[s] = s < nslice ? cslab[(size_t)s * Nout + e] : 0.f;
+        float a = accumulate ? colsum[e] : 0.f;
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s)
+            if (s < nslice) a += v[s];
+        colsum[e] = a;
+    }
+}
+
+// ================================================================================================ 128 x 128 kernel (other shapes)
 constexpr int TB = 128;            // output tile edge
 constexpr int BK = 64;             // tokens per K-step
+constexpr int NSLOT = 3;           // ring slots: two chunks in flight while one is multiplied
 
-// MT = 128-row sub-chunks of the Nout side of a tile: 1 -> 128 x 128 tile, 2 x 4 waves of 64 x 32; 3 -> 384 x 128 tile, 4 x 2 waves of
-// 96 x 64 (one and a half times the FLOPs per DMA byte: a CU takes in ~55 GB/s from L2, which is what bounds a step -- measured: the
-// 128 x 128 form ran 0.6 us per 32 KB step whatever the ring depth).  8 waves either way.
-template <int NSLOT, int MT, int BKT>      // BKT: tokens per K-step (64, or 32 so that four 32 KB slots of the tall tile fit the LDS)
 __global__ void __launch_bounds__(512) tokred_kernel(const bf16* __restrict__ A, long lda, const bf16* __restrict__ B, long ldb,
                                                    float* __restrict__ slab, float* __restrict__ cslab, int Nout, int Kin,
-                                                   int steps_total, int steps_per, int tiles_k, int ntiles, int nslice, int mode) {
-    constexpr int TM = 128 * MT;                       // tile rows (Nout side)
-    constexpr int WM = MT == 1 ? 2 : 4, WN = 8 / WM;   // waves along Nout / Kin
-    constexpr int TMI = TM / WM / 16, TNI = TB / WN / 16;      // 16 x 16 MFMA tiles per wave: 4 x 2 or 6 x 4
-    constexpr int CHUNK = BKT * TB;                    // elements of one [BKT][128] sub-chunk
-    constexpr int PPC = BKT / 4;                       // 1-KiB DMA pieces per sub-chunk
-    constexpr int PA = PPC * MT / 8, PB = PPC / 8;     // pieces per wave per step: Nout side, Kin side
-    constexpr int G = PA + PB;                         // DMA instructions per thread per K-step
-    constexpr int SLOT = (MT + 1) * CHUNK;             // elements of one ring slot: MT sub-chunks [64][128] of dy, one of x
+                                                   int steps_total, int steps_per, int tiles_k, int ntiles) {
+    constexpr int WN = 4;                              // 2 x 4 waves of 64 x 32
+    constexpr int TMI = 4, TNI = 2;                    // 16 x 16 MFMA tiles per wave
+    constexpr int CHUNK = BK * TB;                     // elements of one [64][128] sub-chunk
+    constexpr int PB = 2;                              // 1-KiB DMA pieces per wave per operand per step
+    constexpr int G = 2 * PB;                          // DMA instructions per thread per K-step
+    constexpr int SLOT = 2 * CHUNK;                    // elements of one ring slot: a chunk of dy, a chunk of x
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* ring = reinterpret_cast<bf16*>(smem);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform
-    int tile, slice;
-    if (mode == 1) {            // slice s on the workgroups whose id is 2s mod 8 (one XCD per slice under round-robin placement; speed only)
-        const int x = blockIdx.x & 7;
-        if ((x & 1) || (x >> 1) >= nslice) return;
-        slice = x >> 1; tile = blockIdx.x >> 3;
-        if (tile >= ntiles) return;
-    } else {                    // contiguous runs of the (slice, tile) sequence per XCD: a slice's tiles share two L2s
-        const int seq = xcd_remap(blockIdx.x, gridDim.x);
-        slice = seq / ntiles; tile = seq - slice * ntiles;
-    }
-    const int n0 = (tile / tiles_k) * TM, c0 = (tile % tiles_k) * TB;
+    const int seq = xcd_remap(blockIdx.x, gridDim.x);      // contiguous runs of the (slice, tile) sequence per XCD
+    const int slice = seq / ntiles, tile = seq - slice * ntiles;
+    const int n0 = (tile / tiles_k) * TB, c0 = (tile % tiles_k) * TB;
     const int s_beg = slice * steps_per;
     const int steps = min(steps_per, steps_total - s_beg);
 
     // DMA source addresses: piece p of a [64][128] sub-chunk = its rows 4p .. 4p+3; lane -> row 4p + (lane >> 4), LDS 16-byte chunk
     // (lane & 15), which holds global chunk (lane & 15) ^ (2 * key(row)) of that row (lds_off<bf16, true, 128>)
-    const bf16* pa[PA];
+    const bf16* pa[PB];
     const bf16* pb[PB];
-    unsigned la[PA];                                   // LDS byte offset of each Nout-side piece inside the slot
-#pragma unroll
-    for (int t = 0; t < PA; ++t) {
-        const int pg = wave * PA + t, sub = pg / PPC, p = pg % PPC, r = 4 * p + (lane >> 4);
-        const int key = (r & 3) | ((r >> 1) & 4);
-        pa[t] = A + ((long)s_beg * BKT + r) * lda + n0 + sub * TB + 8 * ((lane & 15) ^ (key << 1));
-        la[t] = (unsigned)(sub * CHUNK * 2 + p * 1024);
-    }
 #pragma unroll
     for (int t = 0; t < PB; ++t) {
         const int p = wave * PB + t, r = 4 * p + (lane >> 4);
         const int key = (r & 3) | ((r >> 1) & 4);
-        pb[t] = B + ((long)s_beg * BKT + r) * ldb + c0 + 8 * ((lane & 15) ^ (key << 1));
+        pa[t] = A + ((long)s_beg * BK + r) * lda + n0 + 8 * ((lane & 15) ^ (key << 1));
+        pb[t] = B + ((long)s_beg * BK + r) * ldb + c0 + 8 * ((lane & 15) ^ (key << 1));
     }
-    const long stepa = (long)BKT * lda, stepb = (long)BKT * ldb;
+    const long stepa = (long)BK * lda, stepb = (long)BK * ldb;
     const unsigned ring_lds = lds_addr(ring);
     auto issue = [&](int slot) {
         const unsigned sa = ring_lds + (unsigned)slot * (unsigned)(SLOT * 2);
 #pragma unroll
-        for (int t = 0; t < PA; ++t) {
-            glds16(pa[t], __builtin_amdgcn_readfirstlane(sa + la[t]));
+        for (int t = 0; t < PB; ++t) {
+            glds16(pa[t], __builtin_amdgcn_readfirstlane(sa + (unsigned)(wave * PB + t) * 1024u));
             pa[t] += stepa;
         }
 #pragma unroll
         for (int t = 0; t < PB; ++t) {
-            glds16(pb[t], __builtin_amdgcn_readfirstlane(sa + (unsigned)(MT * CHUNK * 2) + (unsigned)(wave * PB + t) * 1024u));
+            glds16(pb[t], __builtin_amdgcn_readfirstlane(sa + (unsigned)(CHUNK * 2) + (unsigned)(wave * PB + t) * 1024u));
             pb[t] += stepb;
         }
     };
@@ -101,16 +306,12 @@ __global__ void __launch_bounds__(512) tokred_kernel(const bf16* __restrict__ A,
     for (int i = 0; i < TMI; ++i)
 #pragma unroll
         for (int j = 0; j < TNI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int CSN = TMI / WN;             // column-sum accumulators per wave: row tiles wn, wn + WN, ...
-    f32x4 cs[CSN];
-#pragma unroll
-    for (int q = 0; q < CSN; ++q) cs[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};     // column-sum accumulator: row tile wn of this wave
     const bool do_cs = cslab != nullptr && c0 == 0;
     bf16x8 ones;
 #pragma unroll
     for (int q = 0; q < 8; ++q) ones[q] = (bf16)1.0f;
 
-    // NSLOT-1 chunks in flight before the first one is needed
 #pragma unroll
     for (int s = 0; s < NSLOT - 1; ++s)
         if (s < steps) issue(s);
@@ -119,34 +320,28 @@ __global__ void __launch_bounds__(512) tokred_kernel(const bf16* __restrict__ A,
     for (int s = 0; s < steps; ++s) {
         // chunk s has landed once at most the younger chunks' DMAs are outstanding (vmcnt counts in issue order)
         const int younger = min(NSLOT - 2, steps - 1 - s);
-        if (NSLOT > 2 && younger == NSLOT - 2) wait_vm<(NSLOT > 2 ? NSLOT - 2 : 0) * G>();
-        else if (NSLOT > 3 && younger == 1) wait_vm<G>();
+        if (younger == NSLOT - 2) wait_vm<(NSLOT - 2) * G>();
         else wait_vm<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();            // every wave's pieces of chunk s are visible; nobody reads slot (s-1) % NSLOT any more
         if (s + NSLOT - 1 < steps) issue(nxt);
         const bf16* cA = ring + (size_t)cur * SLOT;
-        const bf16* cB = cA + MT * CHUNK;
+        const bf16* cB = cA + CHUNK;
 #pragma unroll
-        for (int kk = 0; kk < BKT; kk += 32) {
+        for (int kk = 0; kk < BK; kk += 32) {
             bf16x8 fa[TMI], fb[TNI];
 #pragma unroll
-            for (int i = 0; i < TMI; ++i) {
-                const int r = wm * (16 * TMI) + i * 16;                       // row of the tile: sub-chunk r / 128, row r % 128 inside it
-                fa[i] = frag_bf16<true, TB>(cA + (r >> 7) * CHUNK, r & 127, kk, lane);
-            }
+            for (int i = 0; i < TMI; ++i) fa[i] = frag_bf16<true, TB>(cA, wm * (16 * TMI) + i * 16, kk, lane);
 #pragma unroll
             for (int j = 0; j < TNI; ++j) fb[j] = frag_bf16<true, TB>(cB, wn * (16 * TNI) + j * 16, kk, lane);
 #pragma unroll
             for (int i = 0; i < TMI; ++i)
 #pragma unroll
                 for (int j = 0; j < TNI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-            if (do_cs) {          // column sums of dy (bias gradient): row tiles wn, wn + WN, .. of this wave against an all-ones operand
+            if (do_cs) {
 #pragma unroll
-                for (int q = 0; q < CSN; ++q)
-#pragma unroll
-                    for (int i = 0; i < TMI; ++i)
-                        if (wn + q * WN == i) cs[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[i], cs[q], 0, 0, 0);
+                for (int i = 0; i < TMI; ++i)
+                    if (wn == i) cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[i], cs, 0, 0, 0);
             }
         }
         cur = cur + 1 == NSLOT ? 0 : cur + 1;
@@ -161,25 +356,12 @@ __global__ void __launch_bounds__(512) tokred_kernel(const bf16* __restrict__ A,
 #pragma unroll
         for (int j = 0; j < TNI; ++j)
             *reinterpret_cast<float4*>(so + (size_t)(i * 16) * Kin + j * 16) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-    if (do_cs && lg == 0) {
-#pragma unroll
-        for (int q = 0; q < CSN; ++q) cslab[(size_t)slice * Nout + n0 + wm * (16 * TMI) + (wn + q * WN) * 16 + li] = cs[q][0];
-    }
+    if (do_cs && lg == 0) cslab[(size_t)slice * Nout + n0 + wm * (16 * TMI) + wn * 16 + li] = cs[0];
 }
 
-// out[i] = (accumulate ? out[i] : 0) + sum_s slab[s][i] in slice order; colsum likewise from cslab.  The slices' loads are issued together
-// (batches of 8 independent 16-byte loads per thread) and added in slice order: a loop of load-then-add ran at one memory round trip per
-// slice (24 us per launch at 8 slices for 18 MB).
+// out[i] = (accumulate ? out[i] : 0) + sum_s slab[s][i] in slice order; colsum likewise from cslab.  The slices' loads are issued together.
 __global__ void __launch_bounds__(256) tokred_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ cslab, int nslice, long n,
-                                                            int Nout, float* __restrict__ out, float* __restrict__ colsum, int accumulate, int cs_mode) {
-    if (colsum && cs_mode == 0 && blockIdx.x == 0) {      // single-block column sum (the default, see the host side)
-        for (int m = threadIdx.x; m < Nout; m += 256) {
-            float a = accumulate ? colsum[m] : 0.f;
-            for (int s = 0; s < nslice; ++s) a += cslab[(size_t)s * Nout + m];
-            colsum[m] = a;
-        }
-    }
-    if (cs_mode == 0) colsum = nullptr;
+                                                            int Nout, float* __restrict__ out, float* __restrict__ colsum, int accumulate) {
     const long n4 = n / 4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         float4 a = accumulate ? reinterpret_cast<const float4*>(out)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -193,107 +375,106 @@ __global__ void __launch_bounds__(256) tokred_reduce_kernel(const float* __restr
         }
         reinterpret_cast<float4*>(out)[i] = a;
     }
-    if (colsum) {       // spread over the LAST blocks of the grid (one block doing all Nout columns was the launch's long pole: 6 x 8 dependent loads)
-        const long t = ((long)gridDim.x - 1 - blockIdx.x) * 256 + threadIdx.x;
-        for (long m = t; m < Nout; m += (long)gridDim.x * 256) {
+    if (colsum) {
+        for (long m = (long)blockIdx.x * 256 + threadIdx.x; m < Nout; m += (long)gridDim.x * 256) {
             float a = accumulate ? colsum[m] : 0.f;
-            for (int s0 = 0; s0 < nslice; s0 += 8) {
-                float v[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = s0 + q < nslice ? cslab[(size_t)(s0 + q) * Nout + m] : 0.f;
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (s0 + q < nslice) a += v[q];
-            }
+            for (int s = 0; s < nslice; ++s) a += cslab[(size_t)s * Nout + m];
             colsum[m] = a;
         }
     }
 }
 
 int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
-
-int pick_slices(long steps, int dflt) {
-    static const int env = env_int("BF_TOKRED_SLICES", 0);
-    int ns = env > 0 ? env : dflt;
-    ns = ns < 1 ? 1 : ns > 16 ? 16 : ns;
-    if (ns > steps) ns = (int)steps;
-    return ns;
-}
+constexpr int MAX_SLICES = 16;
 
 }  // namespace
 
 extern "C" int64_t bf_gemm_tokred_ws_floats(int Nout, int Kin, int64_t M) {
     if (Nout <= 0 || Kin <= 0 || M <= 0) return 0;
-    return (int64_t)16 * ((int64_t)Nout * Kin + Nout);          // up to 16 slices of the result and of the column sums
+    return (int64_t)MAX_SLICES * ((int64_t)Nout * Kin + Nout);          // up to 16 slices of the result and of the column sums
 }
 
 // Returns 0 when done, 1 when the shape is not covered (the caller then runs bf_gemm's token-reduction form), < 0 on error.
 extern "C" int bf_gemm_tokred(int dtype, int Nout, int Kin, int64_t M, const void* dy, int64_t ldy, const void* x, int64_t ldx, float* out,
                               int accumulate, float* colsum, float* ws, int64_t ws_floats, bf_stream_t stream) {
-    static const int enabled = env_int("BF_TOKRED", 1);
-    if (!enabled || dtype != BF_DTYPE_BF16) return 1;
-    if (Nout % TB || Kin % TB || M % BK || M < BK || ldy % 8 || ldx % 8) return 1;
+    if (dtype != BF_DTYPE_BF16) return 1;
+    const bool pp = Nout % 192 == 0 && Kin % PTN == 0 && M % HR == 0 && M >= 4 * HR;
+    if (!pp && (Nout % TB || Kin % TB || M % BK || M < BK)) return 1;
+    if (ldy % 8 || ldx % 8) return 1;
     BF_REQUIRE(dy && x && out && ws, "bf_gemm_tokred: null pointer");
     BF_REQUIRE(((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)ws & 15) == 0,
                "bf_gemm_tokred: operands must be 16-byte aligned");
-    // BF_TOKRED_TALL=1: 384 x 128 tiles (1.5 x the FLOPs per DMA byte, a third as many tiles), 32-token steps so that FOUR 32 KB slots
-    // fit the LDS.  Measured and NOT the default: a workgroup reaches 49 % MFMA utilisation instead of 40 %, not 1.5 x (both forms
-    // sit at ~45 GB/s of DMA per CU behind one barrier per step), so on a third as many workgroups a launch takes 82-88 us instead of
-    // 57 alone; in the training step the side stream then outlasts the backward's critical path: 558 (6 slices) / 581 (8) samples/s
-    // against 632 with 128 x 128 tiles, although the caller's own kernels run faster beside it (data gradient 54 us instead of 66).
-    static const int tall_env = env_int("BF_TOKRED_TALL", 0);
-    const bool tall = tall_env != 0 && Nout % 384 == 0;
-    const int tm = tall ? 384 : TB, bkt = tall ? 32 : BK;
-    const long steps = M / bkt;
-    // 8 token slices (216-288 workgroups for the trunk's shapes; 4 until the round-2 kernels shifted the balance of the two queues: measured
-    // on the final tree 4 / 6 / 8 / 10 / 12 / 16 slices -> 649 / 662 / 670 / 634-642 / 626-630 / 619 samples/s)
-    // (slice counts chosen per shape for 200-256 workgroups -- 9 / 16 / 7 for the QKV / out-projection / MLP shapes: 670-673, no better)
-    const int nslice = pick_slices(steps, tall ? (Nout / 384 >= 3 ? 6 : 8) : 8);
+    BF_REQUIRE(ldy >= Nout && ldx >= Kin, "bf_gemm_tokred: leading dimensions smaller than the row length");
+    hipStream_t st = (hipStream_t)stream;
     const long n = (long)Nout * Kin;
+    // Token slices.  More slices = more, shorter workgroups and more slab traffic (2 x slices x |out|, whatever the tile shape).
+    // BF_TOKRED_SLICES / BF_TOKRED_TILE (384 or 192 rows) override the defaults.
+    static const int slices_env = env_int("BF_TOKRED_SLICES", 0);
+    static const int tile_env = env_int("BF_TOKRED_TILE", 0);
+    if (pp) {
+        const long halves = M / HR;
+        const bool big = Nout % 384 == 0 && tile_env != 192;
+        const int tm = big ? 384 : 192;
+        int nslice = slices_env > 0 ? slices_env : 12;
+        nslice = (int)std::max<long>(1, std::min<long>({(long)nslice, (long)MAX_SLICES, halves / 4}));
+        const int halves_per = bf_cdiv(halves, nslice);
+        const int ns = bf_cdiv(halves, halves_per);                // slices that actually have tokens
+        BF_REQUIRE(ws_floats >= (int64_t)ns * (n + Nout), "bf_gemm_tokred: workspace too small (bf_gemm_tokred_ws_floats)");
+        const int tiles_k = Kin / PTN, ntiles = (Nout / tm) * tiles_k;
+        float* slab = ws;
+        float* cslab = colsum ? ws + (size_t)ns * n : nullptr;
+        const unsigned rblocks = (unsigned)bf_cdiv(std::max<long>(n / 4, Nout), 256);
+#define BF_PP_GO(NIV)                                                                                                                     \
+        do {                                                                                                                              \
+            {                                                                                                                             \
+                BfProfScope prof(st, NIV == 6 ? "tokred_pp_kernel<384x192,h32,ring4>" : "tokred_pp_kernel<192x192,h32,ring4>",           \
+                                 2.0 * Nout * Kin * (double)M, (double)M * (Nout + Kin) * 2.0 + (double)n * 4.0);                         \
+                static bool attr_done = false;                                                                                            \
+                constexpr int lds_bytes = NBUF * PPGeom<NIV>::HALFB;                                                                      \
+                if (!attr_done) {                                                                                                         \
+                    hipError_t e_ = hipFuncSetAttribute((const void*)tokred_pp_kernel<NIV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+                    if (e_ != hipSuccess) return bf_fail(e_, __FILE__, __LINE__);                                                         \
+                    attr_done = true;                                                                                                     \
+                }                                                                                                                         \
+                hipLaunchKernelGGL(tokred_pp_kernel<NIV>, dim3((unsigned)(ns * ntiles)), dim3(512), lds_bytes, st, (const bf16*)dy, (long)ldy, \
+                                   (const bf16*)x, (long)ldx, slab, cslab, Nout, (int)halves, halves_per, tiles_k, ntiles);               \
+                BF_CHECK_LAUNCH();                                                                                                        \
+            }                                                                                                                             \
+            BfProfScope prof(st, "tokred_reduce_kernel", 0.0, (double)(ns + 1 + (accumulate ? 1 : 0)) * n * 4.0);                         \
+            if (ns <= 8) hipLaunchKernelGGL((tokred_pp_reduce_kernel<NIV, 8>), dim3(rblocks), dim3(256), 0, st, slab, cslab, ns, ntiles, tiles_k, Nout, Kin, out, colsum, accumulate); \
+            else hipLaunchKernelGGL((tokred_pp_reduce_kernel<NIV, MAX_SLICES>), dim3(rblocks), dim3(256), 0, st, slab, cslab, ns, ntiles, tiles_k, Nout, Kin, out, colsum, accumulate); \
+            BF_CHECK_LAUNCH();                                                                                                            \
+        } while (0)
+        if (big) BF_PP_GO(6); else BF_PP_GO(3);
+#undef BF_PP_GO
+        return 0;
+    }
+    const long steps = M / BK;
+    int nslice = slices_env > 0 ? slices_env : 8;
+    nslice = (int)std::max<long>(1, std::min<long>({(long)nslice, (long)MAX_SLICES, steps}));
     BF_REQUIRE(ws_floats >= (int64_t)nslice * (n + Nout), "bf_gemm_tokred: workspace too small (bf_gemm_tokred_ws_floats)");
     const int steps_per = bf_cdiv(steps, nslice);
     const int ns = bf_cdiv(steps, steps_per);                  // slices that actually have tokens
-    const int tiles_k = Kin / TB, ntiles = (Nout / tm) * tiles_k;
+    const int tiles_k = Kin / TB, ntiles = (Nout / TB) * tiles_k;
     float* slab = ws;
     float* cslab = colsum ? ws + (size_t)ns * n : nullptr;
-    hipStream_t st = (hipStream_t)stream;
-    static const int mode_env = env_int("BF_TOKRED_MODE", 0);
-    const int mode = (mode_env == 1 && ntiles <= 32 && ns <= 4) ? 1 : 0;
-    const unsigned grid = mode == 1 ? 8u * (unsigned)ntiles : (unsigned)(ns * ntiles);
-    static const int nslot_env = env_int("BF_TOKRED_SLOTS", 0);
-    const int nslot = tall ? 4 : (nslot_env >= 2 && nslot_env <= 4 ? nslot_env : 3);
     {
-        static thread_local char pname[64];
-        snprintf(pname, sizeof(pname), "tokred_kernel<%dx128,bk%d,slots%d>", tm, bkt, nslot);
-        BfProfScope prof(st, pname, 2.0 * Nout * Kin * (double)M, (double)M * (Nout + Kin) * 2.0 + (double)n * 4.0);
-#define BF_TOKRED_GO(NSLOT, MTV, BKV)                                                                                                     \
-        do {                                                                                                                              \
-            static bool attr_done = false;                                                                                                \
-            constexpr int lds_bytes = NSLOT * (MTV + 1) * BKV * TB * 2;                                                                   \
-            if (!attr_done) {                                                                                                             \
-                hipError_t e_ = hipFuncSetAttribute((const void*)tokred_kernel<NSLOT, MTV, BKV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
-                if (e_ != hipSuccess) return bf_fail(e_, __FILE__, __LINE__);                                                             \
-                attr_done = true;                                                                                                         \
-            }                                                                                                                             \
-            hipLaunchKernelGGL((tokred_kernel<NSLOT, MTV, BKV>), dim3(grid), dim3(512), lds_bytes, st, (const bf16*)dy, (long)ldy, (const bf16*)x,  \
-                               (long)ldx, slab, cslab, Nout, Kin, (int)steps, steps_per, tiles_k, ntiles, ns, mode);                      \
-        } while (0)
-        if (tall) BF_TOKRED_GO(4, 3, 32);
-        else if (nslot == 2) BF_TOKRED_GO(2, 1, 64);
-        else if (nslot == 4) BF_TOKRED_GO(4, 1, 64);
-        else BF_TOKRED_GO(3, 1, 64);
-#undef BF_TOKRED_GO
+        BfProfScope prof(st, "tokred_kernel<128x128,bk64,slots3>", 2.0 * Nout * Kin * (double)M, (double)M * (Nout + Kin) * 2.0 + (double)n * 4.0);
+        static bool attr_done = false;
+        constexpr int lds_bytes = NSLOT * 2 * BK * TB * 2;
+        if (!attr_done) {
+            hipError_t e_ = hipFuncSetAttribute((const void*)tokred_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            if (e_ != hipSuccess) return bf_fail(e_, __FILE__, __LINE__);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(tokred_kernel, dim3((unsigned)(ns * ntiles)), dim3(512), lds_bytes, st, (const bf16*)dy, (long)ldy, (const bf16*)x,
+                           (long)ldx, slab, cslab, Nout, Kin, (int)steps, steps_per, tiles_k, ntiles);
         BF_CHECK_LAUNCH();
     }
     {
         BfProfScope prof(st, "tokred_reduce_kernel", 0.0, (double)(ns + 1 + (accumulate ? 1 : 0)) * n * 4.0);
         const int blocks = (int)std::min<long>(512, (n / 4 + 255) / 256);
-        // BF_TOKRED_CS=1: the column sums spread over the grid with batched loads -- the reduce drops from 15.5 to 7.6 us alone and from 20 to
-        // 10.6 us in the step, and the STEP gets slower (658-660 vs 667-669 samples/s, three A/B pairs on two boxes; tokred_kernel itself
-        // 56 -> 63 us beside the main queue).  An explicit pause of 5 / 10 / 20 us after the reduce is no substitute (664 / 661 / 630): the
-        // step's two queues sit at an operating point that the side queue's exact timing decides.  Default: the single-block form.
-        static const int cs_mode = env_int("BF_TOKRED_CS", 0);
-        hipLaunchKernelGGL(tokred_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, cslab, ns, n, Nout, out, colsum, accumulate, cs_mode);
+        hipLaunchKernelGGL(tokred_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, cslab, ns, n, Nout, out, colsum, accumulate);
         BF_CHECK_LAUNCH();
     }
     return 0;
