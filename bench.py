@@ -9,8 +9,10 @@
 
   --config configs1  (default) the headline: training step at 16x192x192, batch 8 per GPU
            configs3  BASELINE configs[3]: the long-aspect 32x384x192 training step (batch 4 per GPU: 36,864 tokens)
-           configs4  BASELINE configs[4]: 200-step autoregressive rollout at batch 1, forward captured in a HIP graph; writes the
-                     per-step record (relative L2, Eikonal residual, heater heat flux) to profiles/r02_rollout_record.json
+           configs4  BASELINE configs[4]: 200-step autoregressive rollout at batch 1, forward captured in a HIP graph; --record PATH
+                     writes the per-step record (relative L2, Eikonal residual, heater heat flux) there
+  --data device-store  every timed step draws its batch from HBM-resident trajectories (DeviceClipStore.gather = bf_clip_gather) instead of
+                     re-using one resident batch; the default run reports that rate too, beside the headline, as `clip_supply`
 
 One process per GPU; training step = forward + fused relative-L2 loss + backward + (N>1: RCCL bucketed gradient all-reduce
 overlapped with backward) + fused AdamW.  Rank 0 prints ONE JSON line.  After the timed region the same step is run twice more with
@@ -69,19 +71,61 @@ def self_launch(args) -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    procs, logs = [], []
+    logdir = os.environ.get("BENCH_RANK_LOG_DIR", os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpurun_out"))
+    try:
+        os.makedirs(logdir, exist_ok=True)
+    except OSError:
+        logdir = None
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        # rank 0's stderr is the caller's; the other ranks' goes to a file each, so that a first multi-GPU run that fails can be read afterwards
+        err = None
+        if r > 0 and logdir is not None:
+            err = open(os.path.join(logdir, "bench_rank%d.err" % r), "w")
+            logs.append(err)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = max(rc, p.wait())
-    sys.stdout.write(out.decode())
-    sys.stdout.flush()
-    return rc
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=err))
+    # Poll every child: the first one that fails (any non-zero return code -- a rank killed by a signal has a NEGATIVE one) takes the
+    # others down (they would otherwise block forever in their next collective, holding their GPUs); an overall limit does the same.
+    import threading
+    out_box = []
+    reader = threading.Thread(target=lambda: out_box.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("BENCH_LAUNCH_TIMEOUT_S", "1500"))
+    failed = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            failed = abs(bad[0]) or 1
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            log("self-launch: ranks still running after the limit; terminating them")
+            failed = 124
+            break
+        time.sleep(0.2)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+        log("self-launch: a rank failed (return codes %s); rank stderr files: %s" % ([p.returncode for p in procs], logdir))
+    reader.join(timeout=5)
+    for f in logs:
+        f.close()
+    if not failed and out_box:
+        sys.stdout.write(out_box[0].decode())
+        sys.stdout.flush()
+    return failed
 
 
 def synthetic_batch(w, seed, device):
@@ -246,6 +290,42 @@ def prof_steps(fn, nprof=2):
     return json.loads(buf.value.decode()) if n > 0 else {}
 
 
+def clip_store_batches(w, dev, rank, world):
+    """step index -> (input, fluid parameters, target) drawn from a DeviceClipStore over the reference's two sample trajectories tiled
+    to the bench resolution (bubbleformer/data/dataset.py:120-184 semantics: sliding windows, std normalisation, 9 fluid parameters;
+    the sample files ship without their .json sidecars, so the parameter records are synthetic).  The index order is a seeded
+    shuffle, rank-strided like DistributedSampler's."""
+    import numpy as np
+    from bubbleformer_amd.data import hdf5_lite
+    from bubbleformer_amd.data.dataset import BubbleForecast
+    names = ("dfun", "temperature", "velx", "vely")
+    trajs = []
+    for k in (1, 2):
+        f = hdf5_lite.File(os.path.join(REPO, "tests", "golden", "samples", "sample_%d.hdf5" % k))
+        t = {}
+        for n in names:
+            a = np.asarray(f[n].array(), dtype=np.float32)
+            ry, rx = -(-w["H"] // a.shape[-2]), -(-w["W"] // a.shape[-1])
+            t[n] = np.tile(a, (1, ry, rx))[:, :w["H"], :w["W"]].copy()
+        f.close()
+        trajs.append(t)
+    fluid = [{"inv_reynolds": 0.0042 * (1 + 0.1 * i), "cpgas": 0.83, "mugas": 0.023, "rhogas": 0.0083, "thcogas": 0.25, "stefan": 0.5298,
+              "prandtl": 8.4, "heater": {"nucWaitTime": 0.4, "wallTemp": 1.0 + 0.05 * i}} for i in range(len(trajs))]
+    ds = BubbleForecast.from_arrays(trajs, fluid, norm="std", time_window=w["T"], start_time=0)
+    ds.normalize()
+    store = ds.device_store(dev)
+    import torch
+    g = torch.Generator(device=dev).manual_seed(7)
+    order = torch.cat([torch.randperm(len(ds), device=dev, generator=g) for _ in range(64)])     # device-resident shuffles: no host work per step
+    B = w["batch"]
+
+    def batch(s_):
+        at = ((s_ * world + rank) * B) % (order.numel() - B)
+        inp, tgt, fp = store.gather(order[at:at + B])
+        return inp, fp, tgt
+    return batch
+
+
 def sample_trajectory(w, dev):
     """(frames, 4, H, W) trajectory derived from the reference's own sample file (tests/golden/samples/sample_1.hdf5: 50 frames of
     64 x 64, fields dfun / temperature / velx / vely): tiled to the clip size -- the rollout's target and first input."""
@@ -318,6 +398,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--config", default="configs1", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--data", default="synthetic", choices=["synthetic", "device-store"],
+                    help="device-store: every timed step draws its batch from a DeviceClipStore (HBM-resident trajectories, bf_clip_gather)")
+    ap.add_argument("--record", default=None, help="configs4: write the per-step rollout record (relative L2, Eikonal, heat flux) to this file")
     ap.add_argument("--eager-gpu-baseline", action="store_true", help="also time the oracle eagerly on the GPU (fp32 and bf16 autocast)")
     args = ap.parse_args()
     w = WORKLOADS[args.config]
@@ -368,6 +451,7 @@ def main():
         torch.cuda.synchronize()
 
     rollout_record = None
+    clip_supply = None
     if w["kind"] == "rollout":                                   # replicas only: every rank runs its own rollout
         sync()
         dt, prof, rollout_record = run_rollout(args, w, dev, cdt)
@@ -386,11 +470,39 @@ def main():
                 log("first step done, loss", float(loss))
         sync()
         log("warm-up done")
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = step(x, cond, y)
-        sync()
-        dt = time.perf_counter() - t0
+
+        def timed(batch_fn, nsteps):
+            sync()
+            t0 = time.perf_counter()
+            for s_ in range(nsteps):
+                xb, cb, yb = batch_fn(s_)
+                ls = step(xb, cb, yb)
+            sync()
+            return time.perf_counter() - t0, ls
+
+        store_fn = None
+        if args.config == "configs1" and (args.data == "device-store" or world == 1):
+            store_fn = clip_store_batches(w, dev, rank, world)
+        if args.data == "device-store":
+            if store_fn is None:
+                raise SystemExit("--data device-store is built for configs1 (the 16x192x192 training step)")
+            timed(store_fn, min(3, args.steps))                 # first gathers (index tables, allocator)
+            dt, loss = timed(store_fn, args.steps)
+            dt_syn, _ = timed(lambda s_: (x, cond, y), min(args.steps, 50))
+            clip_supply = {"samples_per_s_device_store": w["batch"] * world * args.steps / dt,
+                           "samples_per_s_synthetic_same_run": w["batch"] * world * min(args.steps, 50) / dt_syn}
+        else:
+            dt, loss = timed(lambda s_: (x, cond, y), args.steps)
+            if store_fn is not None:                             # the clip supply in a timed loop beside the resident-batch figure (bounded: 50 steps)
+                n2 = min(args.steps, 50)
+                timed(store_fn, 3)
+                dt2, _ = timed(store_fn, n2)
+                clip_supply = {"samples_per_s_device_store": w["batch"] * world * n2 / dt2, "steps": n2,
+                               "samples_per_s_synthetic_same_run": w["batch"] * world * args.steps / dt}
+        if clip_supply is not None:
+            clip_supply["ratio"] = clip_supply["samples_per_s_device_store"] / clip_supply["samples_per_s_synthetic_same_run"]
+            clip_supply["what"] = ("each step: DeviceClipStore.gather(8 shuffled sample indices) -> (input, target, fluid parameters) -> TrainStep; "
+                                   "trajectories: tests/golden/samples/sample_{1,2}.hdf5 tiled 3 x 3 to 192 x 192, 38 sliding windows")
         final_loss = float(loss)
         # ---- roofline leg: per-launch HIP-event timing (on the launch stream) over two more steps
         prof = prof_steps(lambda: step(x, cond, y))
@@ -426,14 +538,18 @@ def main():
                           "algorithmic_GB_per_sample": w["bytes"] / 1e9, "algorithmic_GFLOP_per_sample": w["flops"] / 1e9},
     }
     if rollout_record is not None:
-        path = os.path.join(REPO, "profiles", "r02_rollout_record.json")
-        try:
-            os.makedirs(os.path.dirname(path), exist_ok=True)
-            json.dump({"config": out["config"], "dtype": args.dtype, "ms_per_step": ms, "record": rollout_record}, open(path, "w"), indent=0)
-            out["rollout_record"] = {"file": "profiles/r02_rollout_record.json", "steps": len(rollout_record),
-                                     "first": rollout_record[0], "last": rollout_record[-1]}
-        except OSError as e:
-            out["rollout_record"] = {"error": str(e), "first": rollout_record[0], "last": rollout_record[-1]}
+        out["rollout_record"] = {"steps": len(rollout_record), "first": rollout_record[0], "last": rollout_record[-1]}
+        if args.record:           # opt-in: profiling passes of this command must not rewrite a committed record
+            try:
+                os.makedirs(os.path.dirname(os.path.abspath(args.record)), exist_ok=True)
+                json.dump({"config": out["config"], "dtype": args.dtype, "ms_per_step": ms, "record": rollout_record}, open(args.record, "w"), indent=0)
+                out["rollout_record"]["file"] = args.record
+            except OSError as e:
+                out["rollout_record"]["error"] = str(e)
+    if clip_supply is not None:
+        out["clip_supply"] = clip_supply
+        if args.data == "device-store":
+            out["data"] = "device-store: batches gathered per step from HBM-resident trajectories (the reference's sample files tiled to 192 x 192, std-normalised; DeviceClipStore.gather = bf_clip_gather)"
     if world == 1 and not args.no_cpu_baseline:
         log("timing the CPU baseline (oracle) on", host_threads(), "threads")
         out["cpu_baseline"] = cpu_baseline(w, host_threads())

@@ -51,6 +51,21 @@ class BubbleForecast(Dataset):
                 with open(fname.replace(".hdf5", ".json"), "r", encoding="utf-8") as f:
                     self.fluid_params.append(json.load(f))
 
+    @classmethod
+    def from_arrays(cls, trajectories: Sequence[Dict[str, np.ndarray]], fluid_params: Optional[Sequence[dict]] = None, **kw) -> "BubbleForecast":
+        """The same dataset over trajectories that are already in memory: one dict {field: array [frames][H][W]} per simulation in
+        place of one HDF5 file each (synthetic or pre-loaded studies; bench.py's clip-supply leg).  Keyword arguments as the constructor's."""
+        self = cls([], **{k: v for k, v in kw.items() if k != "return_fluid_params"})
+        self.data = [dict(t) for t in trajectories]
+        self.num_trajs = [1 for _ in self.data]
+        self.traj_lens = [t[self.input_fields[0]].shape[0] for t in self.data]
+        self.return_fluid_params = fluid_params is not None
+        if fluid_params is not None:
+            if len(fluid_params) != len(self.data):
+                raise ValueError("one fluid-parameter record per trajectory")
+            self.fluid_params = list(fluid_params)
+        return self
+
     # ---------------------------------------------------------------- reference contract
     def _per_traj(self) -> List[int]:
         return [n * (t - self.start_time - 2 * self.time_window + 1) for n, t in zip(self.num_trajs, self.traj_lens)]
@@ -152,16 +167,37 @@ class DeviceClipStore:
             return ids, diff, div
         self.in_tab, self.out_tab = tab(ds.input_fields), tab(ds.output_fields)
 
-    def gather(self, indices: Sequence[int]):
+    def _index_tables(self):
+        """Per sample index: absolute first input frame and file index, resident on the device (a few KB): gather() then needs no host
+        work per step beyond the launch."""
+        ds = self.ds
+        key = (len(ds), ds.time_window, ds.start_time)
+        if getattr(self, "_tab_key", None) != key:
+            loc = [ds.locate(i) for i in range(len(ds))]
+            self._first_all = torch.tensor([int(self.frame0[fi]) + st for fi, st in loc], dtype=torch.int64, device=self.device)
+            self._file_all = torch.tensor([fi for fi, _ in loc], dtype=torch.int64, device=self.device)
+            self._tab_key = key
+        return self._first_all, self._file_all
+
+    def gather(self, indices):
+        """indices: sample indices as a sequence of ints or an integer tensor -- a DEVICE tensor (e.g. a slice of
+        ``torch.randperm(len(ds), device=...)``) keeps the whole step free of host-device synchronisation; host indices are staged
+        through pinned memory."""
         from .. import ops
         ds = self.ds
-        loc = [ds.locate(int(i)) for i in indices]
-        first = torch.tensor([self.frame0[fi] + st for fi, st in loc], dtype=torch.int64).to(self.device, non_blocking=True)
+        first_all, file_all = self._index_tables()
+        if isinstance(indices, torch.Tensor) and indices.device == self.device:
+            idx = indices.to(torch.int64)
+        else:
+            host = torch.as_tensor(np.asarray(indices, dtype=np.int64) if not isinstance(indices, torch.Tensor) else indices.to(torch.int64).cpu())
+            if host.numel() and (int(host.min()) < 0 or int(host.max()) >= len(ds)):
+                raise IndexError("sample index out of range")
+            idx = host.pin_memory().to(self.device, non_blocking=True) if self.device.type == "cuda" else host.to(self.device)
+        first = first_all[idx]
         tw, f = ds.time_window, ds.downsample_factor
         ho, wo = (self.H // f, self.W // f) if f > 1 else (self.H, self.W)
         inp = ops.clip_gather(self.frames, first, 0, tw, self.in_tab, ho, wo)
         out = ops.clip_gather(self.frames, first, tw, tw, self.out_tab, ho, wo)
         if self.fluid is not None:
-            fidx = torch.tensor([fi for fi, _ in loc], dtype=torch.int64, device=self.device)
-            return inp, out, self.fluid[fidx]
+            return inp, out, self.fluid[file_all[idx]]
         return inp, out

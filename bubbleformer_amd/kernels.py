@@ -77,15 +77,50 @@ def attn_fwd(qkv, out, nseq, Lq, inner, outer_stride, inner_stride, tok_stride, 
                                 _p(qw), _p(qb), _p(kw), _p(kb), _p(emb), _p(hscale), out_scale, int(accumulate), _stream()), "bf_attn_fwd")
 
 
+def check_frame_linear(A, W, frames, S, nw=None, nb=None, bias=None, colscale=None, colshift=None, resid=None, ew=None, eb=None, eg=None,
+                       xw=None, xb=None) -> None:
+    """Everything bf_frame_linear assumes about its operands, checked on the host: the kernel addresses frames * S rows of A / out / resid
+    and N or K entries of every table through raw pointers, so a mismatched call would read or write out of bounds on the GPU."""
+    E = L.BubbleformerHipError
+    if A.dim() != 2 or W.dim() != 2:
+        raise E("frame_linear: A must be [tokens][K], W [N][K]")
+    M, K = A.shape
+    N = W.shape[0]
+    if frames < 1 or S < 1 or frames * S != M:
+        raise E(f"frame_linear: frames * tokens_per_frame = {frames} * {S} != {M} rows of A")
+    if W.shape[1] != K:
+        raise E(f"frame_linear: W has K = {W.shape[1]}, A has K = {K}")
+    if A.dtype != torch.bfloat16 or W.dtype != torch.bfloat16:
+        raise E(f"frame_linear: A and W must be bfloat16 (got {A.dtype}, {W.dtype})")
+    if not A.is_cuda or W.device != A.device:
+        raise E("frame_linear: A and W must be on the same ROCm device")
+    if A.stride(1) != 1 or W.stride(1) != 1:
+        raise E("frame_linear: A and W need unit inner strides")
+    if resid is not None and (resid.shape != (M, N) or resid.dtype != torch.bfloat16 or resid.stride(1) != 1 or resid.device != A.device):
+        raise E(f"frame_linear: resid must be a bfloat16 [{M}][{N}] tensor with a unit inner stride on {A.device}")
+    for name, t, n in (("norm weight", nw, K), ("norm bias", nb, K), ("bias", bias, N), ("colscale", colscale, N), ("colshift", colshift, N),
+                       ("out_norm weight", ew, N), ("out_norm bias", eb, N), ("out_norm scale", eg, N), ("next_norm weight", xw, N),
+                       ("next_norm bias", xb, N)):
+        if t is None:
+            continue
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() < n or t.device != A.device:
+            raise E(f"frame_linear: {name} must be a contiguous fp32 tensor of at least {n} elements on {A.device}")
+    if (nw is None) != (nb is None) or (colscale is None) != (colshift is None) or (xw is None) != (xb is None):
+        raise E("frame_linear: norm / colscale+colshift / next_norm tables come in pairs")
+    if ew is not None and (eb is None or eg is None):
+        raise E("frame_linear: out_norm needs (weight, bias, scale)")
+
+
 def frame_linear(A, W, frames, S, norm=None, bias=None, colscale=None, colshift=None, resid=None, gelu=False, out_norm=None, next_norm=None):
     """Whole-frame inference projection (bf_frame_linear).  norm = (w, b): InstanceNorm in front; out_norm = (w, b, g): out = resid + g * IN(A W^T + bias);
     next_norm = (w, b): also return IN(out) * w + b.  Returns the output (or (out, out_n)), or None when the shape is not covered."""
-    M, K = A.shape
-    N = W.shape[0]
-    out = torch.empty(M, N, dtype=A.dtype, device=A.device)
     nw, nb = norm if norm is not None else (None, None)
     ew, eb, eg = out_norm if out_norm is not None else (None, None, None)
     xw, xb = next_norm if next_norm is not None else (None, None)
+    check_frame_linear(A, W, frames, S, nw, nb, bias, colscale, colshift, resid, ew, eb, eg, xw, xb)
+    M, K = A.shape
+    N = W.shape[0]
+    out = torch.empty(M, N, dtype=A.dtype, device=A.device)
     out_n = torch.empty_like(out) if next_norm is not None else None
     rc = L.lib().bf_frame_linear(_dt(A.dtype), frames, S, K, N, _p(A), A.stride(0), _p(W), W.stride(0), _p(nw), _p(nb), _p(bias), _p(colscale),
                                  _p(colshift), _p(resid), resid.stride(0) if resid is not None else 0, int(gelu), _p(ew), _p(eb), _p(eg),

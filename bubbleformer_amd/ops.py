@@ -52,12 +52,16 @@ def _dims_key(d: L.Dims):
 _SCRATCH_BYTES = {}
 
 
+_SCRATCH_PINNED: list = []      # arenas a HIP-graph capture has seen: a captured graph holds their raw addresses, so they are never freed
+
+
 def scratch_for(d: L.Dims, device) -> torch.Tensor:
-    """ONE transient arena per device, grown to the largest problem seen (a ragged last batch, a validation batch or another stream
-    do not pin further arenas): stage calls are stream-ordered and a stage never keeps scratch contents across calls, so every shape
-    can share it.  Two host threads driving two streams of one device concurrently must serialise their stage calls themselves, or set
-    BF_SCRATCH_PER_STREAM=1 (one arena per stream).  A HIP-graph capture finds the arena of its warm-up runs -- nothing is allocated
-    from the graph's private pool.  clear_scratch() releases everything."""
+    """The transient arena of the current stream on `device`, grown to the largest problem seen on that stream (a ragged last batch or
+    a validation batch do not pin further arenas): stage calls are stream-ordered and a stage never keeps scratch contents across
+    calls, so every shape can share it.  One arena per (device, stream): two streams of one device never share scratch, whatever
+    their host threads do (BF_SCRATCH_SHARED=1 opts into ONE arena per device for callers that order their streams themselves).
+    An arena that was handed out while its stream was being captured into a HIP graph is pinned: the graph's kernels hold its raw
+    address, so a later, larger problem gets a NEW arena and the captured one stays alive until clear_scratch()."""
     key = _dims_key(d)
     n = _SCRATCH_BYTES.get(key)
     if n is None:
@@ -65,21 +69,25 @@ def scratch_for(d: L.Dims, device) -> torch.Tensor:
         if n < 0:
             L.check(-1, "bf_scratch_bytes")
         _SCRATCH_BYTES[key] = n
-    slot = (str(device), _stream()) if os.environ.get("BF_SCRATCH_PER_STREAM") == "1" else str(device)
+    slot = str(device) if os.environ.get("BF_SCRATCH_SHARED") == "1" else (str(device), _stream())
+    capturing = torch.cuda.is_current_stream_capturing()
     buf = _SCRATCH.get(slot)
     if buf is None or buf.numel() < n:
-        if buf is not None:       # the library's side stream may still read the old arena: order it before the arena can be recycled
+        if buf is not None and not capturing:       # the library's side stream may still read the old arena: order it before the arena can be recycled
             L.check(L.lib().bf_side_join(_stream()), "bf_side_join")
         buf = torch.empty(n, dtype=torch.uint8, device=device)
         _SCRATCH[slot] = buf
+    if capturing and not any(b is buf for b in _SCRATCH_PINNED):
+        _SCRATCH_PINNED.append(buf)
     return buf
 
 
 def clear_scratch() -> None:
-    """Release the scratch arenas (after the work that used them has been synchronised)."""
+    """Release the scratch arenas, the pinned ones included (after the work -- and every captured graph -- that used them is gone)."""
     if _SCRATCH:
         L.check(L.lib().bf_side_join(_stream()), "bf_side_join")
     _SCRATCH.clear()
+    _SCRATCH_PINNED.clear()
 
 
 def _saved(nbytes: int, device, what: str) -> torch.Tensor:
@@ -238,6 +246,31 @@ def _weights_changed() -> None:
     _WEIGHTS_EPOCH[0] += 1
 
 
+def _evict_eval_arenas(limit: int = 8) -> None:
+    """Least recently used first; entries a captured graph reads are kept."""
+    for k in list(_EVAL_ARENAS):
+        if len(_EVAL_ARENAS) < limit:
+            break
+        if not _EVAL_ARENAS[k][2]:
+            del _EVAL_ARENAS[k]
+
+
+def refresh_eval_weights(owner: int) -> None:
+    """Re-prepare, in place and on the current stream, the inference weights of every cache entry of `owner` whose parameters changed
+    since they were prepared (torch version counters / this package's optimizer epoch).  utils.rollout.GraphedForward calls it before
+    each replay: a captured graph contains only bf_trunk_eval_fwd reading the arena, so without it a graph kept across optimizer
+    steps would replay with the weights of capture time."""
+    for key, ent in _EVAL_ARENAS.items():
+        if key[0] != int(owner) or ent[3] is None:
+            continue
+        d, n, kinds, pp, _structs, plist = ent[3]
+        flat = [p for ps in plist for p in ps if p is not None]
+        stamp = (_WEIGHTS_EPOCH[0], tuple(p._version for p in flat))
+        if stamp != ent[0]:
+            L.check(L.lib().bf_trunk_eval_prepare(C.byref(d), n, kinds, pp, _p(ent[1]), _stream()), "bf_trunk_eval_prepare")
+            ent[0] = stamp
+
+
 def clear_eval_weights() -> None:
     """Drop the prepared inference weights (they are re-made on the next eval forward).  Needed only after parameters were rewritten
     through raw pointers by code outside this package; torch in-place ops and ops.adamw_ / ops.lion_ are noticed by themselves."""
@@ -252,6 +285,31 @@ def trunk_eval_applies(tok: torch.Tensor) -> bool:
     return (tok.is_cuda and tok.dtype == torch.bfloat16 and tok.dim() == 5 and tok.shape[2] * tok.shape[3] == 144 and tok.shape[4] == 384
             and tok.shape[2] <= 16 and tok.shape[3] <= 16 and tok.shape[1] <= 32 and os.environ.get("BF_TRUNK_EVAL", "1") != "0"
             and tok.shape[0] * tok.shape[1] <= int(os.environ.get("BF_TRUNK_EVAL_MAX_FRAMES", "96")))
+
+
+def _stage_param_shapes(kind: str, E: int, heads: int) -> dict:
+    """Element counts the native stage reads from each parameter (layers/attention.py:35-63, 149-197): a shorter tensor would be read
+    out of bounds on the GPU."""
+    d = E // heads
+    base = {"gamma": E, "gamma_att": E, "gamma_mlp": E, "attn_scale_factor": heads, "attn_scale_factor_x": heads, "attn_scale_factor_y": heads,
+            "low_freq_scalar": E, "high_freq_scalar": E, "norm1_w": E, "norm1_b": E, "norm2_w": E, "norm2_b": E, "mlp_norm_w": E, "mlp_norm_b": E,
+            "input_head_w": 3 * E * E, "input_head_b": 3 * E, "output_head_w": E * E, "output_head_b": E, "qnorm_w": d, "qnorm_b": d,
+            "knorm_w": d, "knorm_b": d, "rel_pos_emb": 32 * heads, "fc1_w": 4 * E * E, "fc1_b": 4 * E, "fc2_w": 4 * E * E, "fc2_b": E}
+    return base
+
+
+def _check_stage_params(kind: str, params, E: int, heads: int, device) -> None:
+    fields = L.TEMPORAL_FIELDS if kind == "temporal" else L.SPATIAL_FIELDS
+    if len(params) != len(fields):
+        raise L.BubbleformerHipError(f"{kind} stage: expected {len(fields)} parameters, got {len(params)}")
+    want = _stage_param_shapes(kind, E, heads)
+    for name, p in zip(fields, params):
+        if p is None:
+            continue
+        if p.device != device:
+            raise L.BubbleformerHipError(f"{kind} stage: parameter {name} is on {p.device}, the tokens on {device}")
+        if name in want and p.numel() != want[name]:
+            raise L.BubbleformerHipError(f"{kind} stage: parameter {name} has {p.numel()} elements, the kernels read {want[name]}")
 
 
 _EVAL_TOKENS = [0]
@@ -275,30 +333,44 @@ def trunk_eval(tok: torch.Tensor, heads: int, attn_scale: bool, feat_scale: bool
     if not tok.is_cuda or tok.dtype != torch.bfloat16 or not stages or os.environ.get("BF_TRUNK_EVAL", "1") == "0":
         return None
     tok = tok.contiguous()
+    if tok.dim() != 5:
+        raise L.BubbleformerHipError("trunk_eval: tokens must be (B, T, h, w, E)")
     B, T, h, w, E = tok.shape
+    if heads < 1 or E % heads:
+        raise L.BubbleformerHipError(f"trunk_eval: embed dim {E} is not a multiple of {heads} heads")
     d = make_dims(tok.dtype, B, T, h, w, E, heads, attn_scale, feat_scale)
     lib = L.lib()
     n = len(stages)
     kinds = (C.c_int32 * n)(*[0 if kind == "temporal" else 1 for kind, _ in stages])
     plist = [[_f32c(p) for p in params] for _, params in stages]
+    for (kind, _), ps in zip(stages, plist):
+        _check_stage_params(kind, ps, E, heads, tok.device)
     structs = [(L.TemporalParams if kind == "temporal" else L.SpatialParams)(*[_p(p) for p in ps]) for (kind, _), ps in zip(stages, plist)]
     pp = (C.c_void_p * n)(*[C.addressof(s) for s in structs])
     flat = [p for ps in plist for p in ps if p is not None]
     key = (int(owner), str(tok.device), tuple(p.data_ptr() for p in flat), h, w, E, heads, bool(attn_scale), bool(feat_scale))
     stamp = (_WEIGHTS_EPOCH[0], tuple(p._version for p in flat))
     ent = _EVAL_ARENAS.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
     if ent is None or ent[0] != stamp:
-        if torch.cuda.is_current_stream_capturing() and ent is None:
+        if capturing and ent is None:
             raise L.BubbleformerHipError("trunk_eval: run one eval forward before capturing it in a HIP graph (the weights are prepared on the first call)")
         nbytes = lib.bf_trunk_eval_weights_bytes(C.byref(d), n, kinds)
         arena = ent[1] if ent is not None else _saved(nbytes, tok.device, "bf_trunk_eval_weights_bytes")
+        # re-preparing inside a capture puts the launch INTO the graph (same arena): every replay then re-reads the live parameters
         rc = lib.bf_trunk_eval_prepare(C.byref(d), n, kinds, pp, _p(arena), _stream())
         if rc == 1:
             return None
         L.check(rc, "bf_trunk_eval_prepare")
-        if len(_EVAL_ARENAS) > 8:
-            _EVAL_ARENAS.clear()
-        ent = _EVAL_ARENAS[key] = [stamp, arena]
+        if ent is None:
+            _evict_eval_arenas()
+            ent = _EVAL_ARENAS[key] = [stamp, arena, False, None]
+        else:
+            ent[0] = stamp
+    if capturing:
+        ent[2] = True         # a captured graph reads this arena by address: never evicted, refreshed in place (refresh_eval_weights)
+    ent[3] = (d, n, kinds, pp, structs, plist)      # what a refresh needs (keeps the parameter tensors and ctypes records alive)
+    _EVAL_ARENAS[key] = _EVAL_ARENAS.pop(key)       # most recently used last
     out = torch.empty_like(tok)
     rc = lib.bf_trunk_eval_fwd(C.byref(d), n, kinds, pp, _p(ent[1]), _p(tok), _p(out), _p(scratch_for(d, tok.device)), _stream())
     if rc == 1:

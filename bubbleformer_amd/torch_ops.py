@@ -43,6 +43,10 @@ def trunk_eval(tok: torch.Tensor, heads: int, attn_scale: bool, feat_scale: bool
 
 @trunk_eval.register_fake
 def _(tok, heads, attn_scale, feat_scale, kinds, params, owner=0):
+    if tok.dim() != 5 or heads < 1 or tok.shape[-1] % heads:
+        raise L.BubbleformerHipError("trunk_eval: tokens must be (B, T, h, w, E) with E a multiple of the head count")
+    if sum(_NT if k == 0 else _NS for k in kinds) != len(params):
+        raise L.BubbleformerHipError("trunk_eval: parameter list does not match the stage kinds")
     return torch.empty_like(tok)
 
 
@@ -65,4 +69,10 @@ def frame_linear(a: torch.Tensor, w: torch.Tensor, frames: int, tokens_per_frame
 @frame_linear.register_fake
 def _(a, w, frames, tokens_per_frame, norm_w=None, norm_b=None, bias=None, colscale=None, colshift=None, resid=None, gelu=False,
       out_norm_w=None, out_norm_b=None, out_norm_g=None):
+    if a.dim() != 2 or w.dim() != 2 or frames * tokens_per_frame != a.shape[0] or w.shape[1] != a.shape[1]:
+        raise L.BubbleformerHipError("frame_linear: A must be [frames * tokens_per_frame][K] and W [N][K]")
+    if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
+        raise L.BubbleformerHipError("frame_linear: A and W must be bfloat16")
+    if resid is not None and tuple(resid.shape) != (a.shape[0], w.shape[0]):
+        raise L.BubbleformerHipError("frame_linear: resid must be [tokens][N]")
     return a.new_empty((a.shape[0], w.shape[0]))

@@ -72,6 +72,8 @@ def load_checkpoint(path: str, model: torch.nn.Module, train_step=None, map_loca
             train_step.v.copy_(st["v"])
         if train_step.scheduler is not None and ckpt.get("lr_schedulers"):
             train_step.scheduler.load_state_dict(ckpt["lr_schedulers"][0])
+    from .. import ops
+    ops._weights_changed()                    # prepared inference weights (ops.trunk_eval) are re-made from the loaded parameters
     if train_step is not None and hasattr(train_step, "sync_from_rank0"):
         train_step.sync_from_rank0()          # data parallel: every replica continues from rank 0's weights, moments and step count
     return ckpt

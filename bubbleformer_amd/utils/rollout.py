@@ -16,7 +16,13 @@ def relative_l2_per_step(pred: torch.Tensor, tgt: torch.Tensor) -> torch.Tensor:
 
 
 class GraphedForward:
-    """model(x, *extra) in eval / no-grad mode, captured in a HIP graph for one input shape."""
+    """model(x, *extra) in eval / no-grad mode, captured in a HIP graph for one input shape.
+
+    Weights: the captured graph reads the model's PREPARED inference weights (bf16 copies and out-projection folds in a per-model arena,
+    ops.trunk_eval) by address.  Before every replay the arena is re-prepared in place if the parameters changed since (torch in-place
+    updates, ops.adamw_ / ops.lion_, load_state_dict), so a GraphedForward kept across optimizer steps tracks the live parameters; the
+    arena and the scratch buffers the capture saw are pinned for the lifetime of the process (ops.clear_scratch / clear_eval_weights
+    release them -- only once the graph is gone)."""
 
     def __init__(self, model, x: torch.Tensor, *extra: torch.Tensor, warmup: int = 2):
         self.model = model.eval()
@@ -35,6 +41,10 @@ class GraphedForward:
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         self.static_x.copy_(x)
+        owner = self.model.__dict__.get("_bf_eval_owner")
+        if owner is not None:
+            from .. import ops
+            ops.refresh_eval_weights(owner)
         self.graph.replay()
         return self.static_out
 

@@ -147,6 +147,33 @@ def test_device_gather_is_bit_identical_to_host_collate(tmp_path, norm, ds):
     assert torch.equal(inp.cpu(), torch.stack([h[0] for h in host]))
     assert torch.equal(out.cpu(), torch.stack([h[1] for h in host]))
     assert torch.equal(fp.cpu(), torch.stack([h[2] for h in host]))
+    # indices that already live on the device (a slice of a device-side shuffle): same batch, no host staging
+    inp2, out2, fp2 = store.gather(torch.tensor(idx, device="cuda"))
+    assert torch.equal(inp2, inp) and torch.equal(out2, out) and torch.equal(fp2, fp)
+    with pytest.raises(IndexError):
+        store.gather([n])
+
+
+def test_dataset_over_in_memory_trajectories_equals_the_file_backed_one(tmp_path):
+    """BubbleForecast.from_arrays (bench.py's clip-supply leg tiles the sample trajectories in memory): same length, same samples as
+    the dataset over the files the arrays were read from."""
+    import numpy as np
+    from bubbleformer_amd.data import BubbleForecast, hdf5_lite
+    files = _with_sidecars(tmp_path)
+    kw = dict(norm="std", time_window=5, start_time=3)
+    a = BubbleForecast(files, return_fluid_params=True, **kw)
+    a.normalize()
+    trajs, fluid = [], []
+    for f in files:
+        h = hdf5_lite.File(f)
+        trajs.append({k: np.asarray(h[k].array(), dtype=np.float32) for k in ALL})
+        h.close()
+    b = BubbleForecast.from_arrays(trajs, a.fluid_params, **kw)
+    b.normalize()
+    assert len(a) == len(b) and a.diff_terms == b.diff_terms and a.div_terms == b.div_terms
+    for i in (0, len(a) // 2, len(a) - 1):
+        for u, v in zip(a[i], b[i]):
+            assert torch.equal(u, v)
 
 
 @pytest.mark.gpu

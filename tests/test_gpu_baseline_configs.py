@@ -448,3 +448,100 @@ def test_shape_sweep(B, T, H, W, patch, E, heads, film, dtype):
             noisy = k.startswith("film_embed.film_net.0.")      # LayerNorm(P) of the fluid parameters: sums of 2E near-cancelling terms
             assert err < (2e-4 if f32 else 0.7) * float(ref.norm()) or (not f32 and err < (5e-2 if noisy else 5e-3) * gscale), k
     assert (num / den) ** 0.5 < gt
+
+
+def test_graph_survives_a_larger_problem_and_follows_weight_updates():
+    """A HIP graph holds the raw addresses of the scratch arena and of the prepared-weights arena it was captured with.  Both are pinned:
+    capture at batch 1, run a batch-8 forward + a training-shaped forward/backward (a larger arena request), replay -- the replay equals
+    the eager forward bit for bit.  And a GraphedForward kept across a parameter update replays with the NEW weights (the arena is
+    re-prepared in place before the replay)."""
+    from bubbleformer_amd import ops
+    from bubbleformer_amd.utils.rollout import GraphedForward
+    T, H, W, seed = 16, 192, 192, 21
+    m = _model(seed, torch.bfloat16, T).eval()
+    x1, _, c1 = (t.cuda() for t in _inputs(1, T, H, W, seed))
+    x8, y8, c8 = (t.cuda() for t in _inputs(8, T, H, W, seed + 1))
+    with torch.no_grad():
+        eager1 = m(x1, c1)
+        fwd = GraphedForward(m, x1, c1)
+        assert torch.equal(fwd(x1), eager1)
+        big = m(x8, c8)                                   # more frames than the whole-frame path takes: stage forwards, larger scratch
+        assert torch.isfinite(big).all()
+    m.train()
+    loss, _ = m.forward_loss(x8, c8, y8)                  # and a backward (the largest arena of all)
+    loss.backward()
+    m.eval()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        assert torch.equal(fwd(x1), eager1), "replay after a larger problem differs from the eager forward"
+        # weights change under the captured graph
+        m.blocks[2].spatial.mlp.fc2.weight.mul_(1.25)
+        q = m.blocks[7].temporal.input_head.weight
+        ops.adamw_(q.view(-1), torch.ones_like(q).view(-1), torch.zeros_like(q).view(-1), torch.zeros_like(q).view(-1), 1, 0.02)
+        replayed = fwd(x1).clone()
+        eager2 = m(x1, c1)
+        assert torch.equal(replayed, eager2) and not torch.equal(replayed, eager1)
+    assert len(ops._SCRATCH_PINNED) >= 1
+
+
+def test_frame_linear_and_trunk_eval_reject_malformed_operands():
+    """The dispatcher-visible operators validate what the kernels would otherwise read or write out of bounds through raw pointers."""
+    from bubbleformer_amd import _lib as L, torch_ops  # noqa: F401
+    E = L.BubbleformerHipError
+    dt = torch.bfloat16
+    a = torch.randn(2 * 144, 384, device="cuda").to(dt)
+    w = torch.randn(768, 384, device="cuda").to(dt)
+    op = torch.ops.bubbleformer_amd.frame_linear
+    assert op(a, w, 2, 144).shape == (288, 768)
+    with pytest.raises(E):
+        op(a, w, 3, 144)                                               # frames * tokens != rows
+    with pytest.raises(E):
+        op(a, w[:, :256].contiguous(), 2, 144)                         # K mismatch
+    with pytest.raises(E):
+        op(a.float(), w, 2, 144)                                       # dtype
+    with pytest.raises(E):
+        op(a, w, 2, 144, bias=torch.zeros(100, device="cuda"))         # table shorter than N
+    with pytest.raises(E):
+        op(a, w, 2, 144, bias=torch.zeros(768, device="cuda", dtype=dt))     # table dtype
+    with pytest.raises(E):
+        op(a, w, 2, 144, resid=torch.zeros(288, 384, device="cuda", dtype=dt))       # residual shape
+    with pytest.raises(E):
+        op(a, w, 2, 144, norm_w=torch.ones(384, device="cuda"))        # half a pair
+    with pytest.raises(E):
+        op(a[:, ::2], w[:, ::2], 2, 144)                               # inner stride
+    m = _model(3, dt, 16).eval()
+    blk = m.blocks[0]
+    params = list(blk.temporal.stage_params()) + list(blk.spatial.stage_params())
+    tok = torch.randn(1, 16, 12, 12, 384, device="cuda").to(dt)
+    te = torch.ops.bubbleformer_amd.trunk_eval
+    assert te(tok, 6, True, True, [0, 1], params).shape == tok.shape
+    bad = list(params)
+    bad[6] = bad[6][:100]                                              # a truncated input_head.weight
+    with pytest.raises(E):
+        te(tok, 6, True, True, [0, 1], bad)
+    with pytest.raises(E):
+        te(tok, 5, True, True, [0, 1], params)                         # 384 is not a multiple of 5 heads
+    with pytest.raises(E):
+        te(tok, 6, True, True, [0, 1], params[:-1])                    # list does not match the kinds
+
+
+def test_config1_batch8_backward_matches_the_single_sample_fixture():
+    """The bench's own launch geometry (batch 8: M = 18,432 tokens, twelve token slices x 6-8 tiles in the weight-gradient kernel, 72 row
+    tiles in the streaming GEMMs) against the REFERENCE's fp64 statistics of one 16x192x192 sample (fullsize_config1): the loss means
+    over the batch (utils/losses.py:60-65), so a batch of eight copies of that sample has the sample's loss and parameter gradients, and
+    d(clip) of every copy is 1/8 of the sample's.  fp32 mode at the 1e-4 bound, bf16 at the full-depth bf16 bounds."""
+    T, H, W, seed = 16, 192, 192, 12
+    for dtype in (torch.float32, torch.bfloat16):
+        m = _model(seed, dtype, T)
+        x, y, c = (t.cuda() for t in _inputs(1, T, H, W, seed))
+        x8 = x.repeat(8, 1, 1, 1, 1).requires_grad_(True)
+        loss, pred = m.forward_loss(x8, c.repeat(8, 1), y.repeat(8, 1, 1, 1, 1))
+        loss.backward()
+        dx = x8.grad.detach()
+        for i in (1, 7):                                   # every copy sees the same numbers (rows of different tiles / slices)
+            assert rel_l2(pred[i], pred[0]) < (1e-6 if dtype == torch.float32 else 2e-2)
+            assert rel_l2(dx[i], dx[0]) < (1e-5 if dtype == torch.float32 else 5e-2)
+        prod = (pred[3:4].detach().cpu(), float(loss.detach()), (8.0 * dx[3:4]).cpu(), {k: p.grad.detach().cpu() for k, p in m.named_parameters()})
+        _against_reference("config1_16x192x192", prod, dtype)
+        del m, x8, loss, pred, dx
+        torch.cuda.empty_cache()

@@ -157,3 +157,103 @@ def test_reference_style_ddp_wrapper_in_autograd_mode(tmp_path):
             assert float(got[k].norm()) <= 1e-5 * gscale, k
         else:
             assert float((got[k].double() - ref.double()).norm()) <= 1e-4 * float(ref.double().norm()), k
+
+
+# ---------------------------------------------------------------------------------------------- RCCL stream ordering on ONE GPU
+SMALL = dict(input_fields=4, output_fields=4, patch_size=16, embed_dim=384, num_heads=6, processor_blocks=12, num_fluid_params=9)
+EXACT = ("input_head.weight", "input_head.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
+
+
+def _bench_model():
+    from bubbleformer_amd.models import get_model
+    from oracle import weights as Wt
+    m = get_model("filmavit", time_window=16, drop_path=0.0, compute_dtype=torch.bfloat16, **SMALL)
+    m.load_state_dict(Wt.generate(Wt.param_shapes(**SMALL), seed=31))
+    return m.cuda().train()
+
+
+def _rccl_one_rank_worker(rank, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    warm = torch.ones(1024, device="cuda")
+    dist.all_reduce(warm)                          # communicator set-up (tens of ms) happens here, not inside a timed step
+    torch.cuda.synchronize()
+    from bubbleformer_amd.trainer import TrainStep
+    from oracle import weights as Wt
+    Bb = 4
+    x = Wt.synthetic_clip(Bb, 16, 4, 192, 192, 131).cuda()
+    y = Wt.synthetic_clip(Bb, 16, 4, 192, 192, 231).cuda()
+    c = Wt.synthetic_fluid_params(Bb, 9, 331).cuda()
+    res = {}
+    for mode in ("warm", "off", "fp32", "bf16", "fp32_again"):      # "warm": RCCL's first collectives on large buffers set channels up (tens of ms); not compared
+        model = _bench_model()
+        step = TrainStep(model, lr=1e-3, weight_decay=1e-2)
+        if mode not in ("off",):
+            step.reducer.enabled = True            # a 1-rank group: the all-reduce is the identity, so ANY difference is an ordering bug
+            if mode == "bf16":
+                step.reducer.bucket_dtype = torch.bfloat16
+        marks = []
+        if mode not in ("off",):                   # an event on the caller's stream at every bucket launch, one after the side-stream join
+            orig = step.reducer._launch
+            def launch(b, orig=orig, marks=marks):
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                marks.append((b, e))
+                orig(b)
+            step.reducer._launch = launch
+        t0 = torch.cuda.Event(enable_timing=True); t0.record()
+        loss = step(x, c, y)
+        t1 = torch.cuda.Event(enable_timing=True); t1.record()
+        torch.cuda.synchronize()
+        names = [k for k, _ in model.named_parameters()]
+        res[mode] = {"loss": float(loss), "grad": step.flat.grad.detach().cpu().clone(), "flat": step.flat.flat.detach().cpu().clone(),
+                     "offsets": list(step.flat.offsets), "names": names, "numel": [p.numel() for p in step.flat.params],
+                     "log": list(step.reducer.launch_log), "launch_ms": [(b, t0.elapsed_time(e)) for b, e in marks], "step_ms": t0.elapsed_time(t1)}
+    torch.save(res, out)
+    dist.destroy_process_group()
+
+
+def test_rccl_one_rank_exchange_is_ordered_after_the_side_stream(tmp_path):
+    """One GPU, backend "nccl" (= RCCL), world size 1, the gradient exchange switched ON at the bench model's width and depth (batch 4):
+    * fp32 buckets: every all-reduce is the identity, so the step's gradients and post-step weights must be BIT-identical to a step with
+      the exchange off on the families the kernels produce deterministically (the trunk's conv / Linear weights and biases; the others
+      to rounding) -- an all-reduce that ran before the library's side stream had written a bucket would copy stale sums back;
+    * bf16 buckets: a bucket is cast on the caller's stream at launch and copied back at the end: the result must equal bf16(reference
+      gradient) bit for bit on the same families -- this catches a bucket handed to the exchange before its last weight-gradient GEMM
+      (deferred joins: a bucket is launched one bucket late) even where the in-place identity would hide it;
+    * one collective per bucket, gradient-ready order; the launches (events on the caller's stream) are spread over the backward: the
+      first before 70 % of the step has elapsed, all but the last two before 95 % -- they travel under the remaining stages' kernels."""
+    out = str(tmp_path / "one_rank.pt")
+    mp.spawn(_rccl_one_rank_worker, args=(_free_port(), out), nprocs=1, join=True)
+    r = torch.load(out)
+    ref = r["off"]
+    def fam(res, k):
+        i = res["names"].index(k)
+        o, n = res["offsets"][i], res["numel"][i]
+        return res["grad"][o:o + n], res["flat"][o:o + n]
+    n_exact = 0
+    for mode in ("fp32", "fp32_again", "bf16"):
+        got = r[mode]
+        assert got["loss"] == ref["loss"]
+        for k in ref["names"]:
+            g_ref, w_ref = fam(ref, k)
+            g, w = fam(got, k)
+            exact = k.startswith("blocks.") and k.endswith(EXACT)
+            if mode == "bf16":
+                want = g_ref.to(torch.bfloat16).float()
+                if exact:
+                    assert torch.equal(g, want), (mode, k)
+                else:
+                    assert float((g - want).norm()) <= 2e-2 * float(want.norm()) + 1e-12, (mode, k)
+            elif exact:
+                assert torch.equal(g, g_ref) and torch.equal(w, w_ref), (mode, k)
+                n_exact += 1
+            else:
+                assert float((g - g_ref).norm()) <= 1e-4 * float(g_ref.norm()) + 1e-12, (mode, k)
+                assert float((w - w_ref).norm()) <= 1e-5 * float(w_ref.norm()) + 1e-12, (mode, k)
+        nb = len(set(got["log"]))
+        assert sorted(got["log"]) == list(range(nb)) and len(got["log"]) == nb, got["log"]
+        when = [ms for _, ms in got["launch_ms"]]
+        assert when == sorted(when) and when[0] < 0.7 * got["step_ms"] and when[-3] < 0.95 * got["step_ms"], (got["launch_ms"], got["step_ms"])
+    assert n_exact == 2 * 12 * (2 * 2 + 4)

@@ -403,3 +403,74 @@ def test_batched_stage_preparation_is_bit_identical(monkeypatch):
     for a, b in zip(got["1"], got["0"]):
         assert a[0] == b[0] and torch.equal(a[1], b[1])
     assert got["1"][0][0] != got["1"][1][0]          # the training-mode run really dropped something
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bias_type_none_equals_a_zero_table(dtype):
+    """bias_type="none" (layers/attention.py:58-59,174-175 of the reference: no bias term): the blocks built that way give what the
+    default blocks give with an all-zero embedding table -- which adds exactly 0 to every score -- forward and every gradient; the
+    fp32 oracle (zero table) bounds both."""
+    from bubbleformer_amd.layers import AttentionBlock, AxialAttentionBlock
+    from bubbleformer_amd import ops
+    torch.manual_seed(5)
+    E, heads = 128, 2
+    for cls, shape in ((AttentionBlock, (2, 6, 4, 6, E)), (AxialAttentionBlock, (2, 3, 12, 8, E))):
+        rel = cls(E, heads, layer_scale_init_value=0.5).cuda()
+        with torch.no_grad():
+            for p in rel.parameters():
+                p.add_(0.05 * torch.randn_like(p))
+            rel.rel_pos_bias.relative_attention_bias.weight.zero_()
+        none = cls(E, heads, layer_scale_init_value=0.5, bias_type="none").cuda()
+        none.load_state_dict({k: v for k, v in rel.state_dict().items() if "rel_pos_bias" not in k})
+        outs = []
+        for blk in (rel, none):
+            tok = torch.randn(*shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(9)).to(dtype).requires_grad_(True)
+            out = blk.forward_tokens(tok)
+            out.float().square().mean().backward()
+            outs.append((out.detach(), tok.grad.detach(), {k: p.grad.detach().clone() for k, p in blk.named_parameters() if "rel_pos_bias" not in k}))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        for k, g in outs[0][2].items():
+            assert rel_l2(outs[1][2][k], g) < 1e-5 or float(g.abs().max()) < 1e-9, k
+
+
+def _stock_init_run(dtype, steps, lr, seed=0):
+    """FiLMAViT with the reference's OWN initialisation (torch defaults per layer type; every layer scale at 1e-6,
+    layers/attention.py:30,142) trained for `steps` AdamW steps on fresh synthetic clips; returns the loss sequence and the layer
+    scales after every step."""
+    from bubbleformer_amd.models import get_model
+    from bubbleformer_amd.trainer import TrainStep
+    from bubbleformer_amd.utils import CosineWarmupLR
+    from oracle import weights as W
+    torch.manual_seed(seed)
+    cfg = dict(input_fields=4, output_fields=4, patch_size=16, embed_dim=384, num_heads=6, processor_blocks=4, num_fluid_params=9)
+    model = get_model("filmavit", time_window=8, drop_path=0.0, compute_dtype=dtype, **cfg).cuda().train()
+    step = TrainStep(model, lr=lr, weight_decay=1e-2, scheduler=CosineWarmupLR(lr, 5, 200, 1e-6))
+    gam = [p for k, p in model.named_parameters() if "gamma" in k]
+    losses, traj = [], []
+    for i in range(steps):
+        x = W.synthetic_clip(2, 8, 4, 96, 96, 5000 + i).cuda()
+        y = W.synthetic_clip(2, 8, 4, 96, 96, 6000 + i).cuda()
+        c = W.synthetic_fluid_params(2, 9, 7000 + i).cuda()
+        losses.append(float(step(x, c, y)))
+        traj.append(torch.stack([g.detach().float().mean() for g in gam]).cpu())
+    return losses, torch.stack(traj), {k: p.detach().float().cpu().clone() for k, p in model.named_parameters()}
+
+
+def test_bf16_training_from_stock_init_tracks_the_fp32_mode():
+    """The throughput mode from the reference's stock initialisation, where every branch enters the residual stream through a layer scale
+    of 1e-6: 40 AdamW steps (warm-up 5, lr 1e-3 so that the scales grow by three decades inside the test) in bf16 against the same
+    kernels in the fp32 parity mode, same seeds.  Bounds: every loss within 1 % of the fp32 run's, the mean layer scale of each of the
+    12 branches within 3 % at every step from step 10 on (|gamma| has left the 1e-6 start by then), final large weight tensors within
+    2 %.  The residual stream is carried as a bf16 value plus a bf16 remainder (hi / lo pair, csrc/model.hip), so a branch of relative
+    size 1e-6 .. 1e-3 is not rounded away by the residual add."""
+    l32, g32, w32 = _stock_init_run(torch.float32, 40, 1e-3)
+    l16, g16, w16 = _stock_init_run(torch.bfloat16, 40, 1e-3)
+    print("losses fp32", [round(v, 4) for v in l32[::5]], "bf16", [round(v, 4) for v in l16[::5]])
+    print("gamma fp32", g32[-1].tolist(), "bf16", g16[-1].tolist())
+    assert max(abs(a - b) / abs(a) for a, b in zip(l32, l16)) < 1e-2, (l32, l16)
+    assert float(g32[-1].abs().min()) > 2e-5                      # every scale has left the 1e-6 start by a factor of 20 at least
+    dev = ((g16[10:] - g32[10:]).abs() / g32[10:].abs()).max()
+    assert float(dev) < 3e-2, float(dev)
+    for k, p in w32.items():
+        if p.numel() >= 4096:
+            assert rel_l2(w16[k], p) < 2e-2, k

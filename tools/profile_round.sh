@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round profile: rocprofv3 kernel trace + stats of the bench command, the FETCH_SIZE / WRITE_SIZE passes (separate, as
 # MI355X_MICROARCH.md section HBM prescribes) and the two-queue timeline -> gpurun_out/prof/rNN_* (copy the summaries to profiles/).
-# usage: bash tools/profile_round.sh r02
-R=${1:-r02}
+# usage: bash tools/profile_round.sh r03
+R=${1:-r03}
 ROOT=$PWD; OUT=$ROOT/gpurun_out/prof; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
@@ -10,7 +10,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/pmc_fetch.log || { tail -5 $OUT/pmc_fetch.log; exit 1; }
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/pmc_write.log || { tail -5 $OUT/pmc_write.log; exit 1; }
 cd $ROOT
-python3 tools/rocprof_summary.py $OUT/trace $OUT/pmc_fetch $OUT/pmc_write --steps 37 --out $OUT/${R} > /dev/null
+python3 tools/rocprof_summary.py $OUT/trace $OUT/pmc_fetch $OUT/pmc_write --out $OUT/${R} > /dev/null
 python3 tools/timeline.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) --out $OUT/${R}_timeline.md > /dev/null
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/${R}_rocprofv3_kernel_stats.csv
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write

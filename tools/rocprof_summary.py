@@ -42,10 +42,18 @@ def normalise(name: str) -> str:
     if m:
         aux, g2, _ = m.groups()
         return "stream_gemm<%s>" % ("gelu2" if g2 in ("true", "1") else {"0": "plain", "1": "add", "2": "dgelu"}[aux])
-    m = re.search(r"tokred_kernel<(\d), (\d), (\d+)>", name) or re.search(r"tokred_kernelILi(\d)ELi(\d)ELi(\d+)E", name)
+    m = re.search(r"stream_pp_kernel<(\d), (true|false), (true|false)>", name) or re.search(r"stream_pp_kernelILi(\d)ELb([01])ELb([01])E", name)
     if m:
-        ns, mt, bk = m.groups()
-        return "tokred_kernel<%dx128,bk%s,slots%s>" % (128 * int(mt), bk, ns)
+        aux, g2, _ = m.groups()
+        return "stream_pp<%s>" % ("gelu2" if g2 in ("true", "1") else {"0": "plain", "1": "add", "2": "dgelu"}[aux])
+    m = re.search(r"tokred_pp_reduce_kernel", name)
+    if m:
+        return "tokred_reduce_kernel"
+    m = re.search(r"tokred_pp_kernel<(\d)>", name) or re.search(r"tokred_pp_kernelILi(\d)E", name)
+    if m:
+        return "tokred_pp_kernel<%dx192,h32,ring4>" % (64 * int(m.group(1)))
+    if "tokred_kernel" in name:
+        return "tokred_kernel<128x128,bk64,slots3>"
     m = re.search(r"frame_res_kernel<(\d), (\d), (true|false)>", name) or re.search(r"frame_res_kernelILi(\d)ELi(\d)ELb([01])E", name)
     if m:
         ntc, _, norm = m.groups()
@@ -75,7 +83,7 @@ def main():
     ap.add_argument("trace")
     ap.add_argument("pmc_fetch", nargs="?")
     ap.add_argument("pmc_write", nargs="?")
-    ap.add_argument("--steps", type=int, required=True, help="total steps the profiled command ran (warm-up + timed + profiler leg)")
+    ap.add_argument("--steps", type=int, default=0, help="total steps the profiled command ran (warm-up + timed + profiler leg); 0 = the number of optimizer launches in the trace")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     stats = glob.glob(os.path.join(a.trace, "**", "*kernel_stats.csv"), recursive=True)[0]
@@ -88,6 +96,8 @@ def main():
         e["total_ns"] += float(r["TotalDurationNs"])
         e["rocprof_names"].append(r["Name"][:120])
         total += float(r["TotalDurationNs"])
+    if a.steps <= 0:
+        a.steps = max(1, sum(e["calls"] for k, e in agg.items() if k in ("adamw_kernel", "lion_kernel")))
     traffic = {}
     if a.pmc_fetch and a.pmc_write:
         for d, ctr in ((a.pmc_fetch, "FETCH_SIZE"), (a.pmc_write, "WRITE_SIZE")):

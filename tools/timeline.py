@@ -23,7 +23,12 @@ def short(n):
     m = re.search(r"stream_gemm_kernel<(\d), (true|false)", n) or re.search(r"stream_gemm_kernelILi(\d)ELb([01])", n)
     if m:
         return "stream_gemm<%s>" % ("gelu2" if m.group(2) in ("true", "1") else {"0": "plain", "1": "add", "2": "dgelu"}[m.group(1)])
-    for key in ("tokred_reduce", "tokred_kernel", "gemm_inbwd_frames", "attn_fwd_axial_mfma", "attn_bwd_mfma", "attn_fwd_mfma", "in_bwd_slice", "in_stats_slice", "in_stats_merge", "in_slice_sum", "in_bwd_kernel",
+    m = re.search(r"stream_pp_kernel<(\d), (true|false)", n) or re.search(r"stream_pp_kernelILi(\d)ELb([01])", n)
+    if m:
+        return "stream_pp<%s>" % ("gelu2" if m.group(2) in ("true", "1") else {"0": "plain", "1": "add", "2": "dgelu"}[m.group(1)])
+    if "tokred_pp_reduce" in n:
+        return "tokred_reduce"
+    for key in ("tokred_pp_kernel", "tokred_reduce", "tokred_kernel", "gemm_inbwd_frames", "attn_fwd_axial_mfma", "attn_bwd_mfma", "attn_fwd_mfma", "in_bwd_slice", "in_stats_slice", "in_stats_merge", "in_slice_sum", "in_bwd_kernel",
                 "in_stats_kernel", "in_param_reduce", "stage_param_reduce", "stage_prep_multi", "stage_prep", "frame_scale", "frame_table", "adamw", "outproj_finalize",
                 "wgrad_unprep", "wprep", "debed_last_bwd", "debed_last", "pm2nchw", "nchw2pm", "im2col", "film_net_bwd", "film_net_fwd", "fillBufferAligned", "copyBuffer", "lploss"):
         if key in n:
