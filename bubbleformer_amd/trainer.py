@@ -191,7 +191,8 @@ class TrainStep:
         n = torch.tensor([self.step_no], dtype=torch.int64, device=self.flat.flat.device)
         dist.broadcast(n, src=0)
         self.step_no = int(n)
-        self.ops._weights_changed()      # the broadcast wrote the flat buffer behind the parameters' version counters: prepared inference weights are stale
+        from . import ops
+        ops._weights_changed()           # the broadcast wrote the flat buffer behind the parameters' version counters: prepared inference weights are stale
 
     def __call__(self, x, fluid, target) -> torch.Tensor:
         self.flat.zero_grad()
