@@ -422,6 +422,7 @@ int launch(int M, int N, int K, const bf_operand* A, const bf_operand* B, const 
 
 // gemm_stream.hip: weight-stationary persistent kernel for the short-K projections (0 = handled, 1 = not covered, < 0 = error)
 int bf_gemm_stream_try(int M, int N, int K, const bf_operand* A, const bf_operand* B, const bf_epilogue* E, hipStream_t st);
+int bf_gemm_pair_try(int M, int N, int K, const bf_operand* A, const bf_operand* B, const bf_epilogue* E, hipStream_t st);
 
 extern "C" int bf_gemm(int dtype, int M, int N, int K, const bf_operand* A, const bf_operand* B, const bf_epilogue* E,
                        int splitk, bf_stream_t stream) {
@@ -451,6 +452,8 @@ extern "C" int bf_gemm(int dtype, int M, int N, int K, const bf_operand* A, cons
     if (dtype == BF_DTYPE_BF16) {
         const int rc = bf_gemm_stream_try(M, N, K, A, B, E, st);
         if (rc <= 0) return rc;          // handled (0) or failed (< 0); 1 = not covered by the streaming kernel
+        const int rp = bf_gemm_pair_try(M, N, K, A, B, E, st);      // long-K data gradients on 288-row tiles (gemm_frame.hip)
+        if (rp <= 0) return rp;
     }
     if (dtype == BF_DTYPE_BF16) return launch<bf16>(M, N, K, A, B, E, splitk, st);
     if (dtype == BF_DTYPE_F32) return launch<float>(M, N, K, A, B, E, splitk, st);

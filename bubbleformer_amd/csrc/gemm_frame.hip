@@ -235,6 +235,270 @@ __global__ void __launch_bounds__(FNT, 3) gemm_inbwd_frames_kernel(FrameArgs a) 
     }
 }
 
+
+// ================================================================================================ frame-pair kernel (LDS-DMA, ping-pong)
+// The same product for an even number of 144-token frames, restructured around what bounds it on the MI355X: a CU takes in
+// ~50-70 GB/s from L2 however the loads are issued, so the tile is chosen for FLOP per staged byte and the schedule so that the
+// matrix pipe never waits for the staging:
+//  * one workgroup = TWO frames x 128 output columns (288 x 128, 90 FLOP per staged byte against 69 for 144 x 128), one per CU,
+//    (M / 288) x (N / 128) of them: 192 at the bench shape -- the launch leaves a quarter of the chip to the weight-gradient kernels
+//    of the side stream, whose workgroups need a whole CU's LDS as well;
+//  * 8 waves as 2 x 4: wave (g, c) owns frame g x 32 columns = 9 x 2 MFMA tiles with WHOLE frame columns, so the InstanceNorm column
+//    sums never leave the wave (9 register adds + a 16-lane DPP reduction) and the epilogue needs no LDS;
+//  * both operands go global -> LDS by DMA (no staging registers) into a ring of three 52 KB K-step slots: A chunk [288][64] in the
+//    K-contiguous swizzled image, weight chunk [64][128] in the transposing-read image (gemm_common.h: lds_off); step s + 2 is issued
+//    while step s is read, each wave waits with a counted vmcnt for its own pieces of step s + 1 only;
+//  * per K-step a wave runs a LOAD segment (18 + 4 fragment reads, its 6-7 DMA pieces, the counted wait) and a COMPUTE segment
+//    (36 MFMA 16x16x32 = 576 matrix-pipe cycles), each closed by a raw s_barrier; waves 4-7 (frame 1) run one barrier behind waves
+//    0-3 (frame 0): on every SIMD one wave multiplies while its partner loads (cdna_hip_programming.md section 5, the 8-phase
+//    template's stagger; MI355X_MICROARCH.md "Two waves per SIMD");
+//  * epilogue from registers: two neighbouring accumulator tiles are exchanged between lane rows (v_permlane16_swap), after which a
+//    lane owns 8 consecutive columns of 9 rows: 16-byte loads of x / the residual gradient and 16-byte stores (64-byte row segments).
+// MODE 0: InstanceNorm backward behind the product (bf_gemm_inbwd_frames); MODE 1: out = product (+ add) (bf_gemm_pair_try: fc1's
+// data gradient, any 288-row tiling).
+constexpr int PM = 288, PN = 128, PK = 64;
+constexpr int PA_BYTES = PM * PK * 2, PB_BYTES = PK * PN * 2, PSLOT_BYTES = PA_BYTES + PB_BYTES, PNSLOT = 3;      // 36,864 + 16,384 = 53,248; x 3 = 159,744
+constexpr int PA_PIECES = PA_BYTES / 1024, PB_PIECES = PB_BYTES / 1024;                                           // 36, 16
+
+struct PairArgs {
+    const bf16* A; long lda; const bf16* B; long ldb; int N, nk, nt;
+    const bf16* x; const bf16* add; bf16* out; long ldx;
+    const float* mean; const float* rstd; const float* w; float* ws;
+    const float* fscale; int fdiv;
+};
+
+// LDS-DMA with a wave-uniform 64-bit base in SGPRs and a per-lane 32-bit byte offset: one offset register serves every piece of a wave
+__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+template <int MODE, int GRP>
+__device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem, int lane, int w4, int m0, int n0, int fidx0) {
+    constexpr int PG = GRP == 0 ? 7 : 6;            // DMA pieces per wave per K-step: A pieces {w, w+8, w+16, w+24} (+ 32 + w for waves 0-3), B pieces {w, w+8}
+    const int wave = GRP * 4 + w4;
+    const unsigned ring = lds_addr(smem);
+    // ---- DMA geometry.  A piece p = rows 8p .. 8p+7 of the [288][64] chunk; lane -> row 8p + (lane >> 3), LDS 16-byte chunk (lane & 7)
+    // holds global chunk (lane & 7) ^ ((row >> 1) & 7); p = wave + 8t, so (row >> 1) & 7 = (4 (wave & 1) + (lane >> 4)) & 7 for every t.
+    const unsigned voffA = (unsigned)(((long)(lane >> 3) * a.lda + 8 * ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7))) * 2);
+    // B piece p = rows 4p .. 4p+3 of the [64][128] chunk; lane -> row 4p + (lane >> 4), LDS chunk (lane & 15) holds global chunk
+    // (lane & 15) ^ (2 key(row)), key(r) = (r & 3) | ((r >> 1) & 4); p = wave + 8t: key = (lane >> 4) | ((2 wave + (lane >> 5)) & 4)
+    const int bkey = (lane >> 4) | ((2 * wave + (lane >> 5)) & 4);
+    const unsigned voffB = (unsigned)(((long)(lane >> 4) * a.ldb + 8 * ((lane & 15) ^ (bkey << 1))) * 2);
+    const bf16* sA = a.A + (long)(m0 + 8 * wave) * a.lda;                  // piece t: + 64 t rows; K-step: + 64 elements
+    const bf16* sB = a.B + (long)(4 * wave) * a.ldb + n0;                  // piece t: + 32 t rows; K-step: + 64 rows
+    const long pieceA = 64 * a.lda, pieceB = 32 * a.ldb, stepB = 64 * a.ldb;
+    auto issue = [&](int slot) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ring + (unsigned)slot * (unsigned)PSLOT_BYTES + (unsigned)wave * 1024u);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) glds16_s(sA + t * pieceA, voffA, dst + (unsigned)t * 8192u);
+        if constexpr (GRP == 0) glds16_s(sA + 4 * pieceA, voffA, dst + 32768u);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) glds16_s(sB + t * pieceB, voffB, dst + (unsigned)PA_BYTES + (unsigned)t * 8192u);
+        sA += PK; sB += stepB;
+    };
+
+    f32x4 acc[9][2];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- epilogue operands: lane (li, lg) ends up with rows 16 i + li of its frame, columns c8 .. c8 + 7 of the wave's 32-column strip
+    const int li = lane & 15, lg = lane >> 4;
+    const int c8 = (lg & 1) * 16 + (lg >> 1) * 8;
+    const int col0 = n0 + 32 * w4 + c8;
+    const long row0 = (long)m0 + 144 * GRP + li;
+    // MODE 0: the frame's x rows [144][128] go by DMA into a ring slot that is free during the last K-step (frame 0: the slot of step
+    // nk - 2, frame 1: the slot of step nk - 3 -- both were read by every wave before this wave's last load segment starts); no register
+    // is written asynchronously.  Piece p = w4 + 4t (t < 9) = rows 4p .. 4p+3 of the frame, 256 bytes each.
+    const unsigned voffX = (unsigned)(((long)(lane >> 4) * a.ldx + 8 * (lane & 15)) * 2);
+    const bf16* sX = MODE == 0 ? a.x + ((long)m0 + 144 * GRP + 4 * w4) * a.ldx + n0 : nullptr;
+    const long pieceX = 16 * a.ldx;
+    int xslot = 0;
+
+    const int nk = a.nk;
+    // ---- prologue: steps 0 and 1 in flight, step 0 landed for every wave
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 1) wait_vm<PG>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if constexpr (GRP == 1) __builtin_amdgcn_s_barrier();          // one barrier behind waves 0-3 from here on
+
+    int slot = 0;
+    for (int s = 0; s < nk; ++s) {
+        // ======== load segment: fragments of step s; DMA of step s + 2 into the slot that held step s - 1 (every wave finished reading
+        // it before the barrier that ended ITS load segment of s - 1); the counted wait for this wave's pieces of step s + 1
+        const bf16* cA = reinterpret_cast<const bf16*>(smem + (size_t)slot * PSLOT_BYTES);
+        const bf16* cB = reinterpret_cast<const bf16*>(smem + (size_t)slot * PSLOT_BYTES + PA_BYTES);
+        bf16x8 fa[2][9], fb[2][2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) fa[kk][i] = frag_bf16<false, PK>(cA, 144 * GRP + 16 * i, 32 * kk, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[kk][j] = frag_bf16<true, PN>(cB, 32 * w4 + 16 * j, 32 * kk, lane);
+        }
+        const int sl2 = slot == 0 ? 2 : slot - 1;
+        if (s + 2 < nk) { issue(sl2); wait_vm<PG>(); }
+        else if (MODE == 0 && s == nk - 1) {        // last step: the x rows land under its MFMAs (waited for before the barrier that ends them)
+            xslot = GRP == 0 ? sl2 : (slot == PNSLOT - 1 ? 0 : slot + 1);
+            const unsigned dst = __builtin_amdgcn_readfirstlane(ring + (unsigned)xslot * (unsigned)PSLOT_BYTES + (unsigned)w4 * 1024u);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) glds16_s(sX + t * pieceX, voffX, dst + (unsigned)t * 4096u);
+        }
+        else wait_vm<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the reads are done before the barrier: the slot may be refilled after it
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ======== compute segment
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 9; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (MODE == 0 && GRP == 1 && s == nk - 1) wait_vm<0>();    // this wave's x pieces: visible to the workgroup after the barrier below
+        __builtin_amdgcn_s_barrier();
+        slot = slot == PNSLOT - 1 ? 0 : slot + 1;
+    }
+    if constexpr (GRP == 0) {
+        if constexpr (MODE == 0) wait_vm<0>();                      // ... and likewise for waves 0-3
+        __builtin_amdgcn_s_barrier();                               // pairs with the extra barrier of waves 4-7: everybody's x pieces have landed
+    }
+
+    // ---- epilogue.  acc[i][j]: row 16 i + li, columns 16 j + 4 lg .. + 3.  After exchanging the odd lane rows of tile 0 with the even
+    // lane rows of tile 1 a lane holds 8 consecutive columns at c8.
+    float v[9][8];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+            const u32x2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][0][r]), __float_as_uint(acc[i][1][r]), false, false);
+            v[i][r] = __uint_as_float(sw[0]); v[i][4 + r] = __uint_as_float(sw[1]);
+        }
+    if constexpr (MODE == 1) {
+        uint4 ad[9];
+        if (a.add) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) ad[i] = *reinterpret_cast<const uint4*>(a.add + (row0 + 16 * i) * a.ldx + col0);
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            bf16x8 o;
+            if (a.add) {
+                const bf16x8 d8 = __builtin_bit_cast(bf16x8, ad[i]);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o[q] = (bf16)(v[i][q] + (float)d8[q]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o[q] = (bf16)v[i][q];
+            }
+            *reinterpret_cast<bf16x8*>(a.out + (row0 + 16 * i) * a.ldx + col0) = o;
+        }
+    } else {
+        const int fidx = fidx0 + GRP;
+        if (a.fscale) {                              // dy of this frame carries its stochastic-depth factor
+            const float m = a.fscale[fidx / a.fdiv];
+#pragma unroll
+            for (int i = 0; i < 9; ++i)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[i][q] *= m;
+        }
+        const long pbase = (long)fidx * a.N + col0;
+        float mu[8], rs[8], ww[8];
+        {
+            const float4 m0 = *reinterpret_cast<const float4*>(a.mean + pbase), m1 = *reinterpret_cast<const float4*>(a.mean + pbase + 4);
+            const float4 r0 = *reinterpret_cast<const float4*>(a.rstd + pbase), r1 = *reinterpret_cast<const float4*>(a.rstd + pbase + 4);
+            const float4 w0 = *reinterpret_cast<const float4*>(a.w + col0), w1 = *reinterpret_cast<const float4*>(a.w + col0 + 4);
+            mu[0] = m0.x; mu[1] = m0.y; mu[2] = m0.z; mu[3] = m0.w; mu[4] = m1.x; mu[5] = m1.y; mu[6] = m1.z; mu[7] = m1.w;
+            rs[0] = r0.x; rs[1] = r0.y; rs[2] = r0.z; rs[3] = r0.w; rs[4] = r1.x; rs[5] = r1.y; rs[6] = r1.z; rs[7] = r1.w;
+            ww[0] = w0.x; ww[1] = w0.y; ww[2] = w0.z; ww[3] = w0.w; ww[4] = w1.x; ww[5] = w1.y; ww[6] = w1.z; ww[7] = w1.w;
+        }
+        uint4 ad[9];
+        if (a.add) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) ad[i] = *reinterpret_cast<const uint4*>(a.add + (row0 + 16 * i) * a.ldx + col0);
+        }
+        bf16x8 xr[9];                                // this lane's rows 16 i + li, columns 32 w4 + c8 .. + 7 of the staged frame
+        {
+            const unsigned char* xt = smem + (size_t)xslot * PSLOT_BYTES + (size_t)li * 256 + (size_t)(32 * w4 + c8) * 2;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) xr[i] = *reinterpret_cast<const bf16x8*>(xt + (size_t)i * 4096);
+        }
+        float s1[8], s2[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const bf16x8 x8 = xr[i];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float xh = ((float)x8[q] - mu[q]) * rs[q];
+                s1[q] += v[i][q];
+                s2[q] += v[i][q] * xh;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { s1[q] = row16_sum(s1[q]); s2[q] = row16_sum(s2[q]); }
+        if (li == 0 && a.ws) {                       // per-frame partials for the affine-parameter gradients (param_reduce.h)
+            float* wp = a.ws + pbase * 2;
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) *reinterpret_cast<float4*>(wp + 2 * q) = make_float4(s1[q], s2[q], s1[q + 1], s2[q + 1]);
+        }
+        constexpr float invS = 1.f / 144.f;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const bf16x8 x8 = xr[i];
+            const bf16x8 d8 = __builtin_bit_cast(bf16x8, ad[i]);
+            bf16x8 o;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float xh = ((float)x8[q] - mu[q]) * rs[q];
+                float t = rs[q] * ww[q] * (v[i][q] - (s1[q] + xh * s2[q]) * invS);
+                if (a.add) t += (float)d8[q];
+                o[q] = (bf16)t;
+            }
+            *reinterpret_cast<bf16x8*>(a.out + (row0 + 16 * i) * a.ldx + col0) = o;
+        }
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(512) gemm_pair_kernel(PairArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int seq = xcd_remap(blockIdx.x, gridDim.x);       // the column blocks of a frame pair run back to back on one XCD: its rows come through one L2
+    const int fp = seq / a.nt;
+    const int m0 = fp * PM, n0 = (seq - fp * a.nt) * PN;
+    if (wave < 4) pair_body<MODE, 0>(a, smem, lane, wave, m0, n0, 2 * fp);
+    else pair_body<MODE, 1>(a, smem, lane, wave - 4, m0, n0, 2 * fp);
+}
+
+template <int MODE>
+int launch_pair(const PairArgs& a, int M, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pair_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, PNSLOT * PSLOT_BYTES);
+        if (e_ != hipSuccess) return bf_fail(e_, __FILE__, __LINE__);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(gemm_pair_kernel<MODE>, dim3((unsigned)((M / PM) * a.nt)), dim3(512), PNSLOT * PSLOT_BYTES, st, a);
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+bool pair_shape_ok(int M, int N, int K, int64_t lda, int64_t ldb) {
+#ifdef BF_EXPERIMENTS
+    static const bool off = []() { const char* v = getenv("BF_PAIR"); return v && atoi(v) == 0; }();      // A/B against the kernels it replaces
+    if (off) return false;
+#endif
+    return M > 0 && M % PM == 0 && N > 0 && N % PN == 0 && K >= PK && K % PK == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
+           (long)PM * lda * 2 < (1L << 31) && (long)PK * ldb * 2 < (1L << 31);
+}
+
 }  // namespace
 
 extern "C" int bf_gemm_inbwd_frames(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, const void* x,
@@ -243,6 +507,14 @@ extern "C" int bf_gemm_inbwd_frames(int dtype, int M, int N, int K, const void* 
     BF_REQUIRE(A && B && x && out && mean && rstd && w, "bf_gemm_inbwd_frames: null pointer");
     static const bool off = []() { const char* v = getenv("BF_FUSE_INBWD"); return v && atoi(v) == 0; }();
     if (off || dtype != BF_DTYPE_BF16 || S != FM || M <= 0 || M % FM || N <= 0 || N % FN || K < FK || K % FK || lda % 8 || ldb % 8) return 1;
+    if (pair_shape_ok(M, N, K, lda, ldb) && (((uintptr_t)A | (uintptr_t)B | (uintptr_t)x | (uintptr_t)add | (uintptr_t)out) & 15) == 0) {
+        PairArgs a;      // an even number of frames: two frames per workgroup, LDS-DMA ping-pong
+        a.A = (const bf16*)A; a.lda = lda; a.B = (const bf16*)B; a.ldb = ldb; a.N = N; a.nk = K / PK; a.nt = N / PN;
+        a.x = (const bf16*)x; a.add = (const bf16*)add; a.out = (bf16*)out; a.ldx = N;
+        a.mean = mean; a.rstd = rstd; a.w = w; a.ws = ws; a.fscale = fscale; a.fdiv = fdiv > 0 ? fdiv : 1;
+        BfProfScope prof((hipStream_t)stream, "gemm_pair<inbwd>", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * N * (add ? 3 : 2)));
+        return launch_pair<0>(a, M, (hipStream_t)stream);
+    }
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_inbwd_frames_kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr != hipSuccess) return bf_fail(attr, __FILE__, __LINE__);
@@ -256,4 +528,21 @@ extern "C" int bf_gemm_inbwd_frames(int dtype, int M, int N, int K, const void* 
     hipLaunchKernelGGL(gemm_inbwd_frames_kernel, dim3((unsigned)((M / FM) * a.nt)), dim3(FNT), LDS_BYTES, st, a);
     BF_CHECK_LAUNCH();
     return 0;
+}
+
+// out[M][N] = A[M][K] @ B[K][N] (+ add) on the frame-pair kernel: A K-contiguous, B outer-contiguous (a weight [out][in] used as the
+// data gradient's operand), 288-row tiles.  0 = handled, 1 = not covered, < 0 = error.
+int bf_gemm_pair_try(int M, int N, int K, const bf_operand* A, const bf_operand* B, const bf_epilogue* E, hipStream_t st) {
+    if (A->layout != BF_LAY_KC || B->layout != BF_LAY_XC || A->pro != BF_PRO_NONE || B->pro != BF_PRO_NONE) return 1;
+    if (A->gw > 0 || A->seglen > 0 || B->gw > 0 || B->seglen > 0 || E->gw > 0 || E->seglen > 0) return 1;
+    if (E->out_mode != BF_OUT_STORE || E->colsum || E->bias || E->colscale || E->rowscale || E->gelu_out) return 1;
+    if (E->aux_mode != BF_AUX_NONE && E->aux_mode != BF_AUX_ADD) return 1;
+    if (!pair_shape_ok(M, N, K, A->ld, B->ld) || K < 2 * PK || E->ldc != N || (E->aux_mode == BF_AUX_ADD && E->ld_aux != N)) return 1;
+    if (((uintptr_t)A->p | (uintptr_t)B->p | (uintptr_t)E->c | (uintptr_t)E->aux) & 15) return 1;
+    PairArgs a;
+    a.A = (const bf16*)A->p; a.lda = A->ld; a.B = (const bf16*)B->p; a.ldb = B->ld; a.N = N; a.nk = K / PK; a.nt = N / PN;
+    a.x = nullptr; a.add = E->aux_mode == BF_AUX_ADD ? (const bf16*)E->aux : nullptr; a.out = (bf16*)E->c; a.ldx = N;
+    a.mean = nullptr; a.rstd = nullptr; a.w = nullptr; a.ws = nullptr; a.fscale = nullptr; a.fdiv = 1;
+    BfProfScope prof(st, a.add ? "gemm_pair<add>" : "gemm_pair<plain>", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * N * (a.add ? 2 : 1)));
+    return launch_pair<1>(a, M, st);
 }

@@ -398,6 +398,10 @@ extern "C" int64_t bf_gemm_tokred_ws_floats(int Nout, int Kin, int64_t M) {
 extern "C" int bf_gemm_tokred(int dtype, int Nout, int Kin, int64_t M, const void* dy, int64_t ldy, const void* x, int64_t ldx, float* out,
                               int accumulate, float* colsum, float* ws, int64_t ws_floats, bf_stream_t stream) {
     if (dtype != BF_DTYPE_BF16) return 1;
+#ifdef BF_EXPERIMENTS
+    static const int skip_env = env_int("BF_TOKRED_SKIP", 0);      // timing experiment (results wrong): the step without its weight-gradient GEMMs
+    if (skip_env) return 0;
+#endif
     const bool pp = Nout % 192 == 0 && Kin % PTN == 0 && M % HR == 0 && M >= 4 * HR;
     if (!pp && (Nout % TB || Kin % TB || M % BK || M < BK)) return 1;
     if (ldy % 8 || ldx % 8) return 1;

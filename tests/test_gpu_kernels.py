@@ -373,6 +373,36 @@ def test_gemm_inbwd_frames_matches_gemm_then_in_bwd(K, Kd, N, with_add):
     _check_gemm_inbwd_frames(K, 5, Kd, N, with_add)
 
 
+@pytest.mark.parametrize("Kd,N,with_add", [(1152, 384, True), (384, 384, False), (64, 128, True), (128, 256, True), (1536, 256, False)])
+def test_gemm_inbwd_frame_pairs(K, Kd, N, with_add):
+    """The same product on the frame-pair kernel (an even number of frames: two frames per workgroup, both operands by LDS-DMA into a
+    3-slot ring, waves 4-7 one barrier behind waves 0-3, register epilogue): K of one, two, six, 18 and 24 ring steps."""
+    _check_gemm_inbwd_frames(K, 6, Kd, N, with_add)
+
+
+@pytest.mark.parametrize("M,N,Kd,with_add", [(576, 384, 1536, True), (288, 128, 128, False), (18432, 384, 1536, True), (2304, 256, 1152, False)])
+def test_gemm_pair_plain_data_gradient(K, M, N, Kd, with_add):
+    """bf_gemm with a K-contiguous A, an outer-contiguous weight and 288-row tiles (fc1's data gradient `dpre @ W1 + dout`,
+    layers/linear_layers.py:18-25) runs on the frame-pair kernel: against fp64 on the same bf16-valued operands."""
+    g = torch.Generator(device="cuda").manual_seed(33)
+    A = (torch.randn(M, Kd, device="cuda", generator=g) * 0.5).bfloat16()
+    W = (torch.randn(Kd, N, device="cuda", generator=g) / Kd ** 0.5).bfloat16()
+    add = torch.randn(M, N, device="cuda", generator=g).bfloat16() if with_add else None
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    h = K.L.lib()
+    h.bf_prof_enable(1)
+    K.gemm(torch.bfloat16, M, N, Kd, K.operand(A, Kd, K.L.BF_LAY_KC), K.operand(W, N, K.L.BF_LAY_XC),
+           K.epilogue(out, N, **(dict(aux_mode=K.L.BF_AUX_ADD, aux=add, ld_aux=N) if with_add else {})))
+    torch.cuda.synchronize()
+    import ctypes, json
+    buf = ctypes.create_string_buffer(1 << 14)
+    h.bf_prof_report(buf, len(buf))
+    h.bf_prof_enable(0)
+    assert any(k.startswith("gemm_pair") for k in json.loads(buf.value.decode())), "the frame-pair kernel did not take this shape"
+    ref = A.double() @ W.double() + (add.double() if with_add else 0.0)
+    assert _rel(out.double(), ref) < 4e-3                      # one bf16 rounding of the result
+
+
 def test_gemm_inbwd_frames_at_the_bench_size(K):
     """BASELINE configs[1]: 128 frames (batch 8 x 16), E = 384, the QKV projection's data gradient (K = 1152) with the residual."""
     _check_gemm_inbwd_frames(K, 128, 1152, 384, True)
