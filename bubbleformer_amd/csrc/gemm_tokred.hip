@@ -413,13 +413,23 @@ extern "C" int bf_gemm_tokred(int dtype, int Nout, int Kin, int64_t M, const voi
     const long n = (long)Nout * Kin;
     // Token slices.  More slices = more, shorter workgroups and more slab traffic (2 x slices x |out|, whatever the tile shape).
     // BF_TOKRED_SLICES / BF_TOKRED_TILE (384 or 192 rows) override the defaults.
-    static const int slices_env = env_int("BF_TOKRED_SLICES", 0);
+    // Workgroups per launch: the kernel runs on the side stream beside the caller's data-gradient kernels (192 one-per-CU workgroups,
+    // gemm_frame.hip); both queues end up equally long, so what counts is the sum of their CU-time.  Measured in the step (targets of
+    // 48 / 64 / 80 / 96 / 128 workgroups: 681 / 693 / 701 / 707 / 699 samples/s): ~96, from which the slice count follows per shape
+    // (QKV 6 tiles x 16, fc1 / fc2 8 x 12, out-projection 4 tiles of 192 x 192 x 16).
+#ifdef BF_EXPERIMENTS
+    static const int slices_env = env_int("BF_TOKRED_SLICES", 0);      // sweeps: a fixed slice count / tile height / workgroup target
     static const int tile_env = env_int("BF_TOKRED_TILE", 0);
+    static const int wgs_env = env_int("BF_TOKRED_WGS", 96);
+#else
+    constexpr int slices_env = 0, tile_env = 0, wgs_env = 96;
+#endif
     if (pp) {
         const long halves = M / HR;
-        const bool big = Nout % 384 == 0 && tile_env != 192;
+        const int tiles_k0 = Kin / PTN;
+        const bool big = Nout % 384 == 0 && tile_env != 192 && (tile_env == 384 || (Nout / 384) * tiles_k0 * MAX_SLICES >= wgs_env);
         const int tm = big ? 384 : 192;
-        int nslice = slices_env > 0 ? slices_env : 12;
+        int nslice = slices_env > 0 ? slices_env : std::max(1, wgs_env / ((Nout / tm) * tiles_k0));
         nslice = (int)std::max<long>(1, std::min<long>({(long)nslice, (long)MAX_SLICES, halves / 4}));
         const int halves_per = bf_cdiv(halves, nslice);
         const int ns = bf_cdiv(halves, halves_per);                // slices that actually have tokens
