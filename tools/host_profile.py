@@ -10,9 +10,10 @@ from bubbleformer_amd.trainer import TrainStep
 
 dev = torch.device("cuda", 0)
 torch.manual_seed(42)
-model = get_model("filmavit", time_window=B.T, drop_path=B.DROP_PATH, compute_dtype=torch.bfloat16, **B.CFG).to(dev).train()
+W = B.WORKLOADS["configs1"]
+model = get_model("filmavit", time_window=W["T"], drop_path=B.DROP_PATH, compute_dtype=torch.bfloat16, **B.CFG).to(dev).train()
 step = TrainStep(model, lr=2.5e-4, weight_decay=1e-2)
-x, cond, y = B.synthetic_batch(42, dev)
+x, cond, y = B.synthetic_batch(W, 42, dev)
 for _ in range(5):
     step(x, cond, y)
 torch.cuda.synchronize()
