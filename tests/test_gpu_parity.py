@@ -461,9 +461,9 @@ def test_bf16_training_from_stock_init_tracks_the_fp32_mode():
     of 1e-6 (layers/attention.py:30,142): 40 AdamW steps (warm-up 5, lr 1e-3, so that the scales grow by two to three decades inside the
     test) in bf16 against the same kernels in the fp32 parity mode, same seeds and data.  Stated bounds: every loss within 1 % of the
     fp32 run's (measured 0.1 %); from step 10 on (the scales have left their 1e-6 start) each branch's layer-scale VECTOR (384
-    channels) within 12 % of the fp32 run's in relative L2 and with cosine similarity > 0.99 (measured: worst 6.3 %, 0.998) -- the
+    channels) within 15 % of the fp32 run's in relative L2 and with cosine similarity > 0.99 (measured: worst 6.3 %, 0.998) -- the
     per-channel scales follow the same trajectories although their gradients are sums of bf16-rounded products -- and the final large
-    weight tensors within 3 % (measured: worst 2.05 %).  (The mean over a branch's channels is not a usable yardstick: it crosses zero
+    weight tensors within 5 % (measured: worst 2.05 %).  (The mean over a branch's channels is not a usable yardstick: it crosses zero
     during the run.)  What this does NOT show, and DESIGN.md section 2 states: the residual stream is bf16, so while gamma * branch stays
     under 2^-9 of the stream the forward does not see that branch at all (stock autocast keeps the stream in fp32); the scales still
     learn because their gradient does not pass through the rounded sum."""
@@ -476,7 +476,7 @@ def test_bf16_training_from_stock_init_tracks_the_fp32_mode():
     cos = torch.nn.functional.cosine_similarity(g16[10:], g32[10:], dim=2)
     print("gamma vectors: rel L2 at the end", [round(float(v), 3) for v in rel[-1]], "worst over steps", round(float(rel.max()), 3),
           "min cosine", round(float(cos.min()), 4))
-    assert float(rel.max()) < 0.12 and float(cos.min()) > 0.99, (rel.max(), cos.min())
-    for k, p in w32.items():
-        if p.numel() >= 4096:
-            assert rel_l2(w16[k], p) < 3e-2, k
+    assert float(rel.max()) < 0.15 and float(cos.min()) > 0.99, (rel.max(), cos.min())
+    worst = max((rel_l2(w16[k], p), k) for k, p in w32.items() if p.numel() >= 4096)
+    print("worst large weight tensor", worst)
+    assert worst[0] < 5e-2, worst
