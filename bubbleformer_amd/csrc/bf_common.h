@@ -52,13 +52,6 @@ int bf_in_stats_apply(int dtype, const void* x, int frames, int S, int C, const 
 int bf_wprep_multi(int dtype, int n, const int* mode, const float* const* src, void* const* dst, const int* R, const int* K, const int* Kp, hipStream_t st);
 int bf_frame_scale(int dtype, const void* z, const float* m, int fdiv, void* out, long nrows, int S, int C, hipStream_t st);
 
-// weight-gradient GEMM, main kernel only (gemm_tokred.hip; internal): the slabs it leaves are summed later by ONE bf_tokred_reduce_multi
-// launch for all of a stage's GEMMs
-struct TokredPending { const float* slab; const float* cslab; int nslice, ntiles, tiles_k, Nout, Kin, ni; float* out; float* colsum; int accumulate; };
-int bf_gemm_tokred_partial(int dtype, int Nout, int Kin, int64_t M, const void* dy, int64_t ldy, const void* x, int64_t ldx, float* out,
-                           int accumulate, float* colsum, float* ws, int64_t ws_floats, TokredPending* pend, hipStream_t st);
-int bf_tokred_reduce_multi(const TokredPending* pend, int n, hipStream_t st);
-
 int bf_fail(hipError_t e, const char* file, int line);
 int bf_fail_msg(const char* msg, const char* file, int line);
 

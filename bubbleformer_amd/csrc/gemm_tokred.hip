@@ -210,41 +210,43 @@ __global__ void __launch_bounds__(512) tokred_pp_kernel(const bf16* __restrict__
     else tokred_pp_body<NI, 1>(a0, lda, b0, ldb, slab_tile, cslab_row, nh, do_cs, ring_lds, lane, wave - 4);
 }
 
-// One launch for the slabs of up to four GEMMs (a stage's weight gradients: blockIdx.y = job): the same sums in the same order as
-// tokred_pp_reduce_kernel, without a ~13 us launch + its boundary per GEMM on a queue that is as critical as the caller's.
-template <int NI>
-__device__ __forceinline__ void pp_reduce_elem(const TokredPending& p, long e) {
+// out (+)= sum over slices of the fragment-ordered slabs, in slice order; one float4 of one tile per thread, the slices' loads issued
+// together (a load-then-add loop paid a memory round trip per slice).  Column sums likewise from cslab.
+template <int NI, int MAXS>
+__global__ void __launch_bounds__(256) tokred_pp_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ cslab, int nslice,
+                                                               int ntiles, int tiles_k, int Nout, int Kin, float* __restrict__ out,
+                                                               float* __restrict__ colsum, int accumulate) {
     using Gm = PPGeom<NI>;
-    constexpr int T4 = Gm::TILE_FLOATS / 4, MAXS = 16;
-    if (e < (long)p.ntiles * T4) {
+    constexpr int T4 = Gm::TILE_FLOATS / 4;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e < (long)ntiles * T4) {
         const int tile = (int)(e / T4), r = (int)(e - (long)tile * T4);
         const int lane = r & 63, t = r >> 6, wave = t / Gm::TILES, ij = t - wave * Gm::TILES, i = ij / 6, j = ij - i * 6;
         const int wm = wave & 3, wn = wave >> 2;
-        const int nout = (tile / p.tiles_k) * Gm::TM + 16 * (wm + 4 * i) + (lane & 15);
-        const int kin = (tile % p.tiles_k) * PTN + 16 * (wn + 2 * j) + 4 * (lane >> 4);
-        const size_t sstride = (size_t)p.ntiles * Gm::TILE_FLOATS;
-        const float* src = p.slab + (size_t)tile * Gm::TILE_FLOATS + (size_t)r * 4;
+        const int nout = (tile / tiles_k) * Gm::TM + 16 * (wm + 4 * i) + (lane & 15);
+        const int kin = (tile % tiles_k) * PTN + 16 * (wn + 2 * j) + 4 * (lane >> 4);
+        const size_t sstride = (size_t)ntiles * Gm::TILE_FLOATS;
+        const float* src = slab + (size_t)tile * Gm::TILE_FLOATS + (size_t)r * 4;
         float4 v[MAXS];
 #pragma unroll
-        for (int s = 0; s < MAXS; ++s) v[s] = s < p.nslice ? *reinterpret_cast<const float4*>(src + s * sstride) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float4* dst = reinterpret_cast<float4*>(p.out + (size_t)nout * p.Kin + kin);
-        float4 a = p.accumulate ? *dst : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < MAXS; ++s) v[s] = s < nslice ? *reinterpret_cast<const float4*>(src + s * sstride) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4* dst = reinterpret_cast<float4*>(out + (size_t)nout * Kin + kin);
+        float4 a = accumulate ? *dst : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int s = 0; s < MAXS; ++s)
-            if (s < p.nslice) { a.x += v[s].x; a.y += v[s].y; a.z += v[s].z; a.w += v[s].w; }
+            if (s < nslice) { a.x += v[s].x; a.y += v[s].y; a.z += v[s].z; a.w += v[s].w; }
         *dst = a;
     }
-    if (p.colsum && e < p.Nout) {
-        float a = p.accumulate ? p.colsum[e] : 0.f;
-        for (int s = 0; s < p.nslice; ++s) a += p.cslab[(size_t)s * p.Nout + e];
-        p.colsum[e] = a;
+    if (colsum && e < Nout) {
+        float v[MAXS];
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) v[s] = s < nslice ? cslab[(size_t)s * Nout + e] : 0.f;
+        float a = accumulate ? colsum[e] : 0.f;
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s)
+            if (s < nslice) a += v[s];
+        colsum[e] = a;
     }
-}
-struct ReduceBatch { TokredPending j[4]; };
-__global__ void __launch_bounds__(256) tokred_pp_reduce_multi_kernel(ReduceBatch b) {
-    const TokredPending& p = b.j[blockIdx.y];
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (p.ni == 6) pp_reduce_elem<6>(p, e); else pp_reduce_elem<3>(p, e);
 }
 
 // ================================================================================================ 128 x 128 kernel (other shapes)
@@ -392,31 +394,25 @@ extern "C" int64_t bf_gemm_tokred_ws_floats(int Nout, int Kin, int64_t M) {
     return (int64_t)MAX_SLICES * ((int64_t)Nout * Kin + Nout);          // up to 16 slices of the result and of the column sums
 }
 
-// Sums the slabs of up to four pending ping-pong GEMMs (bf_gemm_tokred_partial) in ONE launch; entries with nslice == 0 are skipped.
-int bf_tokred_reduce_multi(const TokredPending* pend, int n, hipStream_t st) {
-    ReduceBatch b;
-    int k = 0;
-    long gx = 0;
-    double bytes = 0.0;
-    for (int i = 0; i < n && k < 4; ++i) {
-        if (pend[i].nslice <= 0) continue;
-        b.j[k++] = pend[i];
-        const long nn = (long)pend[i].Nout * pend[i].Kin;
-        gx = std::max<long>(gx, bf_cdiv(std::max<long>(nn / 4, pend[i].Nout), 256));
-        bytes += (double)(pend[i].nslice + 1 + (pend[i].accumulate ? 1 : 0)) * nn * 4.0;
-    }
-    if (k == 0) return 0;
-    BfProfScope prof(st, "tokred_reduce_kernel", 0.0, bytes);
-    hipLaunchKernelGGL(tokred_pp_reduce_multi_kernel, dim3((unsigned)gx, (unsigned)k), dim3(256), 0, st, b);
-    BF_CHECK_LAUNCH();
-    return 0;
-}
-
-namespace {
-// the ping-pong main kernel only; `pend` describes the slabs it leaves in `ws`
-int tokred_pp_launch(int Nout, int Kin, int64_t M, const void* dy, int64_t ldy, const void* x, int64_t ldx, float* out, int accumulate, float* colsum,
-                     float* ws, int64_t ws_floats, TokredPending* pend, hipStream_t st) {
+// Returns 0 when done, 1 when the shape is not covered (the caller then runs bf_gemm's token-reduction form), < 0 on error.
+extern "C" int bf_gemm_tokred(int dtype, int Nout, int Kin, int64_t M, const void* dy, int64_t ldy, const void* x, int64_t ldx, float* out,
+                              int accumulate, float* colsum, float* ws, int64_t ws_floats, bf_stream_t stream) {
+    if (dtype != BF_DTYPE_BF16) return 1;
+#ifdef BF_EXPERIMENTS
+    static const int skip_env = env_int("BF_TOKRED_SKIP", 0);      // timing experiment (results wrong): the step without its weight-gradient GEMMs
+    if (skip_env) return 0;
+#endif
+    const bool pp = Nout % 192 == 0 && Kin % PTN == 0 && M % HR == 0 && M >= 4 * HR;
+    if (!pp && (Nout % TB || Kin % TB || M % BK || M < BK)) return 1;
+    if (ldy % 8 || ldx % 8) return 1;
+    BF_REQUIRE(dy && x && out && ws, "bf_gemm_tokred: null pointer");
+    BF_REQUIRE(((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)ws & 15) == 0,
+               "bf_gemm_tokred: operands must be 16-byte aligned");
+    BF_REQUIRE(ldy >= Nout && ldx >= Kin, "bf_gemm_tokred: leading dimensions smaller than the row length");
+    hipStream_t st = (hipStream_t)stream;
     const long n = (long)Nout * Kin;
+    // Token slices.  More slices = more, shorter workgroups and more slab traffic (2 x slices x |out|, whatever the tile shape).
+    // BF_TOKRED_SLICES / BF_TOKRED_TILE (384 or 192 rows) override the defaults.
     // Workgroups per launch: the kernel runs on the side stream beside the caller's data-gradient kernels (192 one-per-CU workgroups,
     // gemm_frame.hip); both queues end up equally long, so what counts is the sum of their CU-time.  Measured in the step (targets of
     // 48 / 64 / 80 / 96 / 128 workgroups: 681 / 693 / 701 / 707 / 699 samples/s): ~96, from which the slice count follows per shape
@@ -428,91 +424,45 @@ int tokred_pp_launch(int Nout, int Kin, int64_t M, const void* dy, int64_t ldy, 
 #else
     constexpr int slices_env = 0, tile_env = 0, wgs_env = 96;
 #endif
-    const long halves = M / HR;
-    const int tiles_k0 = Kin / PTN;
-    const bool big = Nout % 384 == 0 && tile_env != 192 && (tile_env == 384 || (Nout / 384) * tiles_k0 * MAX_SLICES >= wgs_env);
-    const int tm = big ? 384 : 192;
-    int nslice = slices_env > 0 ? slices_env : std::max(1, wgs_env / ((Nout / tm) * tiles_k0));
-    nslice = (int)std::max<long>(1, std::min<long>({(long)nslice, (long)MAX_SLICES, halves / 4}));
-    const int halves_per = bf_cdiv(halves, nslice);
-    const int ns = bf_cdiv(halves, halves_per);                // slices that actually have tokens
-    BF_REQUIRE(ws_floats >= (int64_t)ns * (n + Nout), "bf_gemm_tokred: workspace too small (bf_gemm_tokred_ws_floats)");
-    const int tiles_k = Kin / PTN, ntiles = (Nout / tm) * tiles_k;
-    float* slab = ws;
-    float* cslab = colsum ? ws + (size_t)ns * n : nullptr;
-#define BF_PP_GO(NIV)                                                                                                                     \
-    do {                                                                                                                                  \
-        BfProfScope prof(st, NIV == 6 ? "tokred_pp_kernel<384x192,h32,ring4>" : "tokred_pp_kernel<192x192,h32,ring4>",                   \
-                         2.0 * Nout * Kin * (double)M, (double)M * (Nout + Kin) * 2.0 + (double)n * 4.0);                                 \
-        static bool attr_done = false;                                                                                                    \
-        constexpr int lds_bytes = NBUF * PPGeom<NIV>::HALFB;                                                                              \
-        if (!attr_done) {                                                                                                                 \
-            hipError_t e_ = hipFuncSetAttribute((const void*)tokred_pp_kernel<NIV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
-            if (e_ != hipSuccess) return bf_fail(e_, __FILE__, __LINE__);                                                                 \
-            attr_done = true;                                                                                                             \
-        }                                                                                                                                 \
-        hipLaunchKernelGGL(tokred_pp_kernel<NIV>, dim3((unsigned)(ns * ntiles)), dim3(512), lds_bytes, st, (const bf16*)dy, (long)ldy,    \
-                           (const bf16*)x, (long)ldx, slab, cslab, Nout, (int)halves, halves_per, tiles_k, ntiles);                       \
-        BF_CHECK_LAUNCH();                                                                                                                \
-    } while (0)
-    if (big) BF_PP_GO(6); else BF_PP_GO(3);
-#undef BF_PP_GO
-    pend->slab = slab; pend->cslab = cslab; pend->nslice = ns; pend->ntiles = ntiles; pend->tiles_k = tiles_k; pend->Nout = Nout; pend->Kin = Kin;
-    pend->ni = big ? 6 : 3; pend->out = out; pend->colsum = colsum; pend->accumulate = accumulate;
-    return 0;
-}
-bool tokred_pp_shape(int Nout, int Kin, int64_t M) { return Nout % 192 == 0 && Kin % PTN == 0 && M % HR == 0 && M >= 4 * HR; }
-int tokred_check(int dtype, int Nout, int Kin, int64_t M, const void* dy, int64_t ldy, const void* x, int64_t ldx, float* out, float* ws, bool* pp) {
-    if (dtype != BF_DTYPE_BF16) return 1;
-    *pp = tokred_pp_shape(Nout, Kin, M);
-    if (!*pp && (Nout % TB || Kin % TB || M % BK || M < BK)) return 1;
-    if (ldy % 8 || ldx % 8) return 1;
-    BF_REQUIRE(dy && x && out && ws, "bf_gemm_tokred: null pointer");
-    BF_REQUIRE(((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)ws & 15) == 0,
-               "bf_gemm_tokred: operands must be 16-byte aligned");
-    BF_REQUIRE(ldy >= Nout && ldx >= Kin, "bf_gemm_tokred: leading dimensions smaller than the row length");
-    return 0;
-}
-}  // namespace
-
-// Library-internal: the main kernel only, the reduction left to bf_tokred_reduce_multi (one launch for a stage's GEMMs).  pend->nslice == 0
-// on return 0 means nothing is pending (the shape took the 128 x 128 kernel, reduced at once).
-int bf_gemm_tokred_partial(int dtype, int Nout, int Kin, int64_t M, const void* dy, int64_t ldy, const void* x, int64_t ldx, float* out,
-                           int accumulate, float* colsum, float* ws, int64_t ws_floats, TokredPending* pend, hipStream_t st) {
-    pend->nslice = 0;
-#ifdef BF_EXPERIMENTS
-    static const int skip_env = env_int("BF_TOKRED_SKIP", 0);      // timing experiment (results wrong): the step without its weight-gradient GEMMs
-    if (skip_env && dtype == BF_DTYPE_BF16) return 0;
-#endif
-    bool pp = false;
-    const int rc = tokred_check(dtype, Nout, Kin, M, dy, ldy, x, ldx, out, ws, &pp);
-    if (rc) return rc;
-    if (pp) return tokred_pp_launch(Nout, Kin, M, dy, ldy, x, ldx, out, accumulate, colsum, ws, ws_floats, pend, st);
-    return bf_gemm_tokred(dtype, Nout, Kin, M, dy, ldy, x, ldx, out, accumulate, colsum, ws, ws_floats, (bf_stream_t)st);
-}
-
-// Returns 0 when done, 1 when the shape is not covered (the caller then runs bf_gemm's token-reduction form), < 0 on error.
-extern "C" int bf_gemm_tokred(int dtype, int Nout, int Kin, int64_t M, const void* dy, int64_t ldy, const void* x, int64_t ldx, float* out,
-                              int accumulate, float* colsum, float* ws, int64_t ws_floats, bf_stream_t stream) {
-#ifdef BF_EXPERIMENTS
-    static const int skip_env = env_int("BF_TOKRED_SKIP", 0);
-    if (skip_env && dtype == BF_DTYPE_BF16) return 0;
-#endif
-    bool pp = false;
-    const int rc = tokred_check(dtype, Nout, Kin, M, dy, ldy, x, ldx, out, ws, &pp);
-    if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    const long n = (long)Nout * Kin;
     if (pp) {
-        TokredPending pend;
-        const int rl = tokred_pp_launch(Nout, Kin, M, dy, ldy, x, ldx, out, accumulate, colsum, ws, ws_floats, &pend, st);
-        return rl ? rl : bf_tokred_reduce_multi(&pend, 1, st);
+        const long halves = M / HR;
+        const int tiles_k0 = Kin / PTN;
+        const bool big = Nout % 384 == 0 && tile_env != 192 && (tile_env == 384 || (Nout / 384) * tiles_k0 * MAX_SLICES >= wgs_env);
+        const int tm = big ? 384 : 192;
+        int nslice = slices_env > 0 ? slices_env : std::max(1, wgs_env / ((Nout / tm) * tiles_k0));
+        nslice = (int)std::max<long>(1, std::min<long>({(long)nslice, (long)MAX_SLICES, halves / 4}));
+        const int halves_per = bf_cdiv(halves, nslice);
+        const int ns = bf_cdiv(halves, halves_per);                // slices that actually have tokens
+        BF_REQUIRE(ws_floats >= (int64_t)ns * (n + Nout), "bf_gemm_tokred: workspace too small (bf_gemm_tokred_ws_floats)");
+        const int tiles_k = Kin / PTN, ntiles = (Nout / tm) * tiles_k;
+        float* slab = ws;
+        float* cslab = colsum ? ws + (size_t)ns * n : nullptr;
+        const unsigned rblocks = (unsigned)bf_cdiv(std::max<long>(n / 4, Nout), 256);
+#define BF_PP_GO(NIV)                                                                                                                     \
+        do {                                                                                                                              \
+            {                                                                                                                             \
+                BfProfScope prof(st, NIV == 6 ? "tokred_pp_kernel<384x192,h32,ring4>" : "tokred_pp_kernel<192x192,h32,ring4>",           \
+                                 2.0 * Nout * Kin * (double)M, (double)M * (Nout + Kin) * 2.0 + (double)n * 4.0);                         \
+                static bool attr_done = false;                                                                                            \
+                constexpr int lds_bytes = NBUF * PPGeom<NIV>::HALFB;                                                                      \
+                if (!attr_done) {                                                                                                         \
+                    hipError_t e_ = hipFuncSetAttribute((const void*)tokred_pp_kernel<NIV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+                    if (e_ != hipSuccess) return bf_fail(e_, __FILE__, __LINE__);                                                         \
+                    attr_done = true;                                                                                                     \
+                }                                                                                                                         \
+                hipLaunchKernelGGL(tokred_pp_kernel<NIV>, dim3((unsigned)(ns * ntiles)), dim3(512), lds_bytes, st, (const bf16*)dy, (long)ldy, \
+                                   (const bf16*)x, (long)ldx, slab, cslab, Nout, (int)halves, halves_per, tiles_k, ntiles);               \
+                BF_CHECK_LAUNCH();                                                                                                        \
+            }                                                                                                                             \
+            BfProfScope prof(st, "tokred_reduce_kernel", 0.0, (double)(ns + 1 + (accumulate ? 1 : 0)) * n * 4.0);                         \
+            if (ns <= 8) hipLaunchKernelGGL((tokred_pp_reduce_kernel<NIV, 8>), dim3(rblocks), dim3(256), 0, st, slab, cslab, ns, ntiles, tiles_k, Nout, Kin, out, colsum, accumulate); \
+            else hipLaunchKernelGGL((tokred_pp_reduce_kernel<NIV, MAX_SLICES>), dim3(rblocks), dim3(256), 0, st, slab, cslab, ns, ntiles, tiles_k, Nout, Kin, out, colsum, accumulate); \
+            BF_CHECK_LAUNCH();                                                                                                            \
+        } while (0)
+        if (big) BF_PP_GO(6); else BF_PP_GO(3);
+#undef BF_PP_GO
+        return 0;
     }
-#ifdef BF_EXPERIMENTS
-    static const int slices_env = env_int("BF_TOKRED_SLICES", 0);
-#else
-    constexpr int slices_env = 0;
-#endif
     const long steps = M / BK;
     int nslice = slices_env > 0 ? slices_env : 8;
     nslice = (int)std::max<long>(1, std::min<long>({(long)nslice, (long)MAX_SLICES, steps}));

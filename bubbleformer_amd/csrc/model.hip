@@ -12,6 +12,8 @@
 //    per-channel mean exactly norm2.bias, so mean_hw(y)[n] = W[n, :] . norm2.bias + bias[n]  =: mc[n].
 //  * parameter gradients of those folds come from G = dout^T @ on (one split-K GEMM) instead of a saved y:
 //       dW = alpha * G (+ dmc x norm2.bias), dalpha[n] = <W[n, :], G[n, :]>, dbeta = colsum(dout).
+#include <functional>
+#include <vector>
 #include "bf_common.h"
 #include "param_reduce.h"
 #include <stdlib.h>
@@ -139,6 +141,7 @@ int side_join_pending(hipStream_t main, int set = -1) {      // set: 0 / 1 = the
 }
 struct Fork {
     hipStream_t main; SideStream* s; bool used = false; bool deferred; int set;
+    std::vector<std::function<int(hipStream_t)>> jobs;          // deferred mode: the stage's side work, launched by flush()
     explicit Fork(hipStream_t m, bool may_defer = false, int scratch_set = 0) : main(m), s(side_stream()), set(scratch_set) {
         deferred = may_defer && g_side_defer && s != nullptr;
     }
@@ -152,18 +155,27 @@ struct Fork {
         *out = s->st;
         return 0;
     }
-    // side work: job(stream) enqueues it behind a fork point of its own (measured: collecting a stage's jobs behind fewer forks
-    // starts the side work later and loses more than the event records cost, EXPERIMENTS.md)
+    // side work: job(stream) enqueues it.  Eager mode forks here; deferred mode keeps it for flush().
     template <class F> int run(F&& job) {
         hipStream_t ss;
         const int rc = begin(&ss);
         return rc ? rc : job(ss);
     }
-    // the stream the stage's side work went to (the caller's own when there is no side stream): for work that depends only on it
-    hipStream_t tail_stream() const { return s ? s->st : main; }
+    // deferred mode: one fork for everything collected so far
+    int flush() {
+        if (!deferred || jobs.empty()) return 0;
+        int rc;
+        hipStream_t ss;
+        if ((rc = begin(&ss))) return rc;
+        for (auto& j : jobs) if ((rc = j(ss))) return rc;
+        jobs.clear();
+        return 0;
+    }
     // everything forked so far is ordered before what `main` is given next (deferred mode: before the next stage's fork point)
     int join() {
         if (deferred) {
+            const int rc = flush();
+            if (rc) return rc;
             if (used) { HIP_TRY(hipEventRecord(s->tail[set], s->st)); s->pending[set] = true; used = false; }
             return 0;
         }
@@ -428,9 +440,7 @@ struct Scratch {
         zeros = a.f32((size_t)4 * d.E);
         ones = a.f32((size_t)4 * d.E);
         wg = a.f32(wgn);
-        // slabs of a stage's four weight-gradient GEMMs (out-projection, fc2, fc1, QKV): all pending until the stage's one reduce launch
-        tokred_floats = bf_gemm_tokred_ws_floats(d.E, d.E, d.N) + bf_gemm_tokred_ws_floats(d.E, 4 * d.E, d.N) +
-                        bf_gemm_tokred_ws_floats(4 * d.E, d.E, d.N) + bf_gemm_tokred_ws_floats(3 * d.E, d.E, d.N);
+        tokred_floats = bf_gemm_tokred_ws_floats(4 * d.E, d.E, d.N);
         tokred_ws = a.f32((size_t)tokred_floats);
         attn_ws = a.f32(ATTN_WS_FLOATS);
         attn_ws2 = a.f32(ATTN_WS_FLOATS);       // second axial pass: both passes' rows are reduced together at the end of the stage
@@ -532,46 +542,12 @@ int dgrad_inbwd(const D& d, const void* dy, int Kdim, const void* w_xc, int Nout
     TRY(bf_gemm(d.dtype, (int)d.N, Nout, Kdim, &A, &Bo, &e, 1, st));
     return bf_in_bwd_partials(d.dtype, tmp, f.x, f.add, f.dx, (int)d.F, (int)d.S, Nout, f.mean, f.rstd, f.w, f.b, nullptr, 1, 0, f.ws, st);
 }
-// What a stage's weight-gradient GEMMs leave for the END of its side work: their slabs (one reduce launch for all of them instead
-// of one per GEMM) and the out-projection fold's finalize, which reads the reduced G.
-struct SideTail {
-    TokredPending pend[4]; int n = 0;
-    float* ws; int64_t ws_left;
-    bool fin = false;
-    const float *G, *csum, *W, *bias, *nb, *gamma, *lo, *hi, *mc; float *dW, *dbias, *dnb, *dgamma, *dlo, *dhi; int E;
-    SideTail(float* w, int64_t f) : ws(w), ws_left(f) {}
-    // a GEMM's slab region: carved from the stage's workspace, so that nothing pending is overwritten
-    int gemm(int dtype, int Nout, int Kin, int64_t M, const void* dy, int64_t ldy, const void* x, int64_t ldx, float* out, int accumulate,
-             float* colsum, hipStream_t ss) {
-        const int64_t need = bf_gemm_tokred_ws_floats(Nout, Kin, M);
-        if (n >= 4 || need > ws_left) return bf_gemm_tokred(dtype, Nout, Kin, M, dy, ldy, x, ldx, out, accumulate, colsum, ws, ws_left, ss);
-        const int rc = bf_gemm_tokred_partial(dtype, Nout, Kin, M, dy, ldy, x, ldx, out, accumulate, colsum, ws, ws_left, &pend[n], ss);
-        if (rc == 0 && pend[n].nslice > 0) { ++n; ws += need; ws_left -= need; }
-        return rc;
-    }
-};
-__global__ void outproj_finalize_kernel(const float* __restrict__ G, const float* __restrict__ csum, const float* __restrict__ W,
-                                        const float* __restrict__ bias, const float* __restrict__ nb, const float* __restrict__ gamma,
-                                        const float* __restrict__ lo, const float* __restrict__ hi, const float* __restrict__ mc,
-                                        float* __restrict__ dW, float* __restrict__ dbias, float* __restrict__ dnb, float* __restrict__ dgamma,
-                                        float* __restrict__ dlo, float* __restrict__ dhi, int E);
-int side_tail_finish(SideTail& t, hipStream_t ss) {
-    TRY(bf_tokred_reduce_multi(t.pend, t.n, ss));
-    t.n = 0;
-    if (t.fin) {
-        hipLaunchKernelGGL(outproj_finalize_kernel, dim3(t.E), dim3(256), 0, ss, t.G, t.csum, t.W, t.bias, t.nb, t.gamma, t.lo, t.hi, t.mc, t.dW, t.dbias,
-                           t.dnb, t.dgamma, t.dlo, t.dhi, t.E);
-        BF_CHECK_LAUNCH();
-        t.fin = false;
-    }
-    return 0;
-}
 bool side_frame_scale() { static const bool on = []() { const char* v = getenv("BF_SIDE_FRAME_SCALE"); return v && atoi(v) != 0; }(); return on; }
 // backward of the folded out-projection: param grads + don = (dout * alpha) @ W
 int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on, const void* w_s,
                 const float* W, const float* bias, const float* nb, const float* gamma, const float* lo, const float* hi,
                 const float* alpha, const float* mc, float* dW, float* dbias, float* dnb, float* dgamma, float* dlo, float* dhi,
-                void* don, hipStream_t st, Fork& fk, SideTail* tail, const InFuse* fu = nullptr, const float* drop = nullptr, int fdiv = 1, void* dbr = nullptr) {
+                void* don, hipStream_t st, Fork& fk, const InFuse* fu = nullptr, const float* drop = nullptr, int fdiv = 1, void* dbr = nullptr) {
     // drop (stochastic depth): the branch gradient is drop[f / fdiv] * dout.  The data-gradient path applies the factor inside its own
     // kernel (fu->fscale / the GEMM epilogue's row factor); the parameter-gradient side needs the scaled tensor itself and makes it, on
     // the SIDE stream, into `dbr` -- the caller's stream no longer pays a 2U pass and a fork bubble per stage for it.
@@ -579,7 +555,7 @@ int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on,
         const void* dsrc = dout;
         if (drop) { TRY(bf_frame_scale(d.dtype, dout, drop, fdiv, dbr, d.N, (int)d.S, d.E, ss)); dsrc = dbr; }
         // G[n][k] = sum_m dout[m][n] * on[m][k]; `on` is the normalised operand the forward saved; dbeta = colsum(dout) from the same pass
-        const int trc = tail->gemm(d.dtype, d.E, d.E, d.N, dsrc, d.E, on, d.E, sc.G, 0, sc.csum, ss);
+        const int trc = bf_gemm_tokred(d.dtype, d.E, d.E, d.N, dsrc, d.E, on, d.E, sc.G, 0, sc.csum, sc.tokred_ws, sc.tokred_floats, ss);
         if (trc < 0) return trc;
         if (trc == 1) {
             ZERO_ON(ss, sc.G, (size_t)((char*)sc.csum - (char*)sc.G) + (size_t)d.E * 4);     // G and csum are adjacent in the arena: one memset
@@ -589,9 +565,9 @@ int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on,
             e.colsum = sc.csum;                  // dbeta = colsum(dout), fused into the same pass over dout
             TRY(bf_gemm(d.dtype, d.E, d.E, (int)d.N, &A, &Bo, &e, splitk_for(d.E, d.E, d.N), ss));
         }
-        // finalize reads the reduced G: after the stage's reduce launch (side_tail_finish)
-        tail->fin = true; tail->G = sc.G; tail->csum = sc.csum; tail->W = W; tail->bias = bias; tail->nb = nb; tail->gamma = gamma; tail->lo = lo; tail->hi = hi;
-        tail->mc = mc; tail->dW = dW; tail->dbias = dbias; tail->dnb = dnb; tail->dgamma = dgamma; tail->dlo = dlo; tail->dhi = dhi; tail->E = d.E;
+        hipLaunchKernelGGL(outproj_finalize_kernel, dim3(d.E), dim3(256), 0, ss, sc.G, sc.csum, W, bias, nb, gamma, lo, hi, mc, dW, dbias, dnb,
+                           dgamma, dlo, dhi, d.E);
+        BF_CHECK_LAUNCH();
         return 0;
     }));
     if (fu) { InFuse f2 = *fu; f2.fscale = drop; f2.fdiv = fdiv; return dgrad_inbwd(d, dout, d.E, w_s, d.E, don, f2, st); }      // ... followed by norm2's backward
@@ -606,8 +582,8 @@ int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on,
 }
 // backward of y = affine(x) @ W^T + b:  dW += dy^T affine(x), db += colsum(dy), dxn = dy @ W
 int linear_bwd(const D& d, const Scratch& sc, const void* dy, int Nout, const void* x, int Kin, int xpro, const float* xsc, const float* xsh,
-               const void* w_c, float* dW, float* db, void* dxn, const bf_epilogue* dx_epi, hipStream_t st, Fork& fk, SideTail* tail,
-               const InFuse* fu = nullptr, const void* w_t = nullptr) {      // w_t: the weight transposed ([Kin][Nout], K-contiguous for the data gradient)
+               const void* w_c, float* dW, float* db, void* dxn, const bf_epilogue* dx_epi, hipStream_t st, Fork& fk, const InFuse* fu = nullptr,
+               bool last = false, const void* w_t = nullptr) {      // w_t: the weight transposed ([Kin][Nout], K-contiguous for the data gradient)
     TRY(fk.run([=](hipStream_t ss) -> int {      // weight gradient: side stream
         const void* xo = x;
         int pro = xpro;
@@ -619,7 +595,7 @@ int linear_bwd(const D& d, const Scratch& sc, const void* dy, int Nout, const vo
         }
         bf_operand Bo = op_plain(xo, Kin, BF_LAY_XC);
         if (pro == BF_PRO_NONE) {
-            const int trc = tail->gemm(d.dtype, Nout, Kin, d.N, dy, Nout, xo, Kin, dW, 1, db, ss);
+            const int trc = bf_gemm_tokred(d.dtype, Nout, Kin, d.N, dy, Nout, xo, Kin, dW, 1, db, sc.tokred_ws, sc.tokred_floats, ss);
             if (trc <= 0) return trc;
         }
         if (pro != BF_PRO_NONE) op_affine(Bo, pro, xsc, xsh, d.S, Kin);
@@ -627,6 +603,7 @@ int linear_bwd(const D& d, const Scratch& sc, const void* dy, int Nout, const vo
         e.colsum = db;                       // bias gradient = colsum(dy), fused into the same pass over dy
         return bf_gemm(d.dtype, Nout, Kin, (int)d.N, &A, &Bo, &e, splitk_for(Nout, Kin, d.N), ss);
     }));
+    if (last) TRY(fk.flush());                   // deferred mode: the stage's one fork, ahead of its last kernel on the caller's stream
     if (fu) return dgrad_inbwd(d, dy, Nout, w_c, Kin, dxn, *fu, st);
     {
         bf_operand A = op_plain(dy, Nout, BF_LAY_KC);
@@ -709,9 +686,8 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
         dbr = sc.t4;
     }
     const InFuse fu2{sv.o, nullptr, dO, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, sc.in_ws2};      // don @ ... then norm2's backward -> dO
-    SideTail tail(sc.tokred_ws, sc.tokred_floats);
     TRY(outproj_bwd(d, sc, dbr, sv.on, sv.wout_s, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr,
-                    sv.alpha, sv.mc, g->output_head_w, g->output_head_b, nullptr, g->gamma, nullptr, nullptr, don, st, fk, &tail, &fu2,
+                    sv.alpha, sv.mc, g->output_head_w, g->output_head_b, nullptr, g->gamma, nullptr, nullptr, don, st, fk, &fu2,
                     side_fs ? drop : nullptr, d.T, sc.t4));
     ReduceJobs jobs;        // parameter-gradient reductions, all launched together at the end
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws2, (int)d.F, d.E, p->norm2_w, p->norm2_b, nullptr, 1, g->norm2_w, g->norm2_b, nullptr, nullptr, nullptr, nullptr};
@@ -726,8 +702,7 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
     }
     void* dxn = sc.t1;      // don is dead
     const InFuse fu1{x, dout, dx, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, sc.in_ws};             // dqkv @ W_in, then norm1's backward + residual
-    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, sv.xn, d.E, BF_PRO_NONE, nullptr, nullptr, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk, &tail, &fu1));
-    TRY(side_tail_finish(tail, fk.tail_stream()));      // behind the stage's last weight-gradient GEMM on its stream: no fork of its own
+    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, sv.xn, d.E, BF_PRO_NONE, nullptr, nullptr, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk, &fu1, true));
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws, (int)d.F, d.E, p->norm1_w, p->norm1_b, nullptr, 1, g->norm1_w, g->norm1_b, nullptr, nullptr, nullptr, nullptr};
     TRY(launch_reduce_jobs(jobs, st));
     return fk.join();
@@ -872,7 +847,6 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     // dx1 = t1b, dbr = e5, dqkv = t3, s1) is written once per call, so the critical path below never recycles one under them.
     Fork fk(st, true, g_scratch_parity);
     if (fk.deferred) TRY(side_join_pending(st, fk.set));      // the stage before the previous one used this scratch set
-    SideTail tail(sc.tokred_ws, sc.tokred_floats);
     // out = x1 + gamma_mlp * IN(z)
     void* dz = sc.t1;
     ReduceJobs jobs;        // parameter-gradient reductions, all launched together at the end
@@ -892,7 +866,7 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
         bf_epilogue e; memset(&e, 0, sizeof(e));
         e.aux_mode = BF_AUX_DGELU; e.aux = sv.pre; e.ld_aux = 4L * d.E; e.out_mode = BF_OUT_STORE;
         static const bool use_t = []() { const char* v = getenv("BF_FC2_DGRAD_T"); return !(v && v[0] == '0'); }();
-        TRY(linear_bwd(d, sc, dz, d.E, sv.hid, 4 * d.E, BF_PRO_NONE, nullptr, nullptr, w2_c, g->fc2_w, g->fc2_b, dpre, &e, st, fk, &tail, nullptr,
+        TRY(linear_bwd(d, sc, dz, d.E, sv.hid, 4 * d.E, BF_PRO_NONE, nullptr, nullptr, w2_c, g->fc2_w, g->fc2_b, dpre, &e, st, fk, nullptr, false,
                        (!f32 && use_t) ? sv.w2t_c : nullptr));
     }
     // fc1: pre = x1 @ W1^T + b1 ; dx1 = dout + dpre @ W1
@@ -900,7 +874,7 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     {
         bf_epilogue e; memset(&e, 0, sizeof(e));
         e.aux_mode = BF_AUX_ADD; e.aux = dout; e.ld_aux = d.E; e.out_mode = BF_OUT_STORE;
-        TRY(linear_bwd(d, sc, dpre, 4 * d.E, sv.x1, d.E, BF_PRO_NONE, nullptr, nullptr, w1_c, g->fc1_w, g->fc1_b, dx1, &e, st, fk, &tail));
+        TRY(linear_bwd(d, sc, dpre, 4 * d.E, sv.x1, d.E, BF_PRO_NONE, nullptr, nullptr, w1_c, g->fc1_w, g->fc1_b, dx1, &e, st, fk));
     }
     // folded out-projection
     void* don = sc.e6;
@@ -915,7 +889,7 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     TRY(outproj_bwd(d, sc, dbr, sv.on, sv.wout_s, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att,
                     d.feat_scale ? p->low_freq_scalar : nullptr, d.feat_scale ? p->high_freq_scalar : nullptr, sv.alpha, sv.mc,
                     g->output_head_w, g->output_head_b, g->norm2_b, g->gamma_att, d.feat_scale ? g->low_freq_scalar : nullptr,
-                    d.feat_scale ? g->high_freq_scalar : nullptr, don, st, fk, &tail, &fu2, side_fs ? drop_att : nullptr, 1, sc.e5));
+                    d.feat_scale ? g->high_freq_scalar : nullptr, don, st, fk, &fu2, side_fs ? drop_att : nullptr, 1, sc.e5));
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws2, (int)d.F, d.E, p->norm2_w, p->norm2_b, nullptr, 1, g->norm2_w, g->norm2_b, nullptr, nullptr, nullptr, nullptr};
     void* dqkv = sc.t3;
     {
@@ -933,8 +907,7 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     }
     void* dxn = sc.e6;      // don is dead (it was only read on this stream)
     const InFuse fu1{x, dx1, dx, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, sc.in_ws};              // dqkv @ W_in, then norm1's backward + residual
-    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, sv.xn, d.E, BF_PRO_NONE, nullptr, nullptr, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk, &tail, &fu1));
-    TRY(side_tail_finish(tail, fk.tail_stream()));      // behind the stage's last weight-gradient GEMM on its stream: no fork of its own
+    TRY(linear_bwd(d, sc, dqkv, 3 * d.E, sv.xn, d.E, BF_PRO_NONE, nullptr, nullptr, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk, &fu1, true));
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws, (int)d.F, d.E, p->norm1_w, p->norm1_b, nullptr, 1, g->norm1_w, g->norm1_b, nullptr, nullptr, nullptr, nullptr};
     TRY(launch_reduce_jobs(jobs, st));
     return fk.join();
