@@ -60,6 +60,34 @@ __device__ __forceinline__ float quad_max(float v) {
 }
 
 struct Geo { long nseq; int L; long inner, outer_stride, inner_stride, tok_stride; };
+// Where problem pr = sequence * heads + head starts.  pr is wave-uniform (the wave index comes through readfirstlane), so this is scalar
+// work; 32-bit on purpose: a 64-bit division by a run-time value is a ~60-instruction routine, and the kernels used to run four of them
+// per problem in VECTOR registers (the host checks nseq * heads < 2^31).
+struct Prob { long tok0; int head; };
+__device__ __forceinline__ Prob locate(const Geo& g, int heads, long pr) {
+    const unsigned p = (unsigned)pr, hd = (unsigned)heads, inner = (unsigned)g.inner;
+    const unsigned s = p / hd, head = p - s * hd;
+    const unsigned q = s / inner, r = s - q * inner;
+    return Prob{(long)q * g.outer_stride + (long)r * g.inner_stride, (int)head};
+}
+// Totals over the 16 lanes of a row of sixteen values, value v landing in lane v of the row: four halving exchange steps (mirror,
+// half-mirror, xor 2, xor 1 -- one DPP add per surviving value: 8 + 4 + 2 + 1) instead of sixteen full row sums and sixteen selects.
+// In each step a lane keeps the half of its values whose index bit matches its own lane bit and receives its partner's copy of it.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float keep, float send) {
+    return keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_scatter_sum(const float (&p)[16], int i16) {
+    const bool b3 = i16 & 8, b2 = i16 & 4, b1 = i16 & 2, b0 = i16 & 1;
+    float a[8], b[4], c[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = dpp_add<0x140>(b3 ? p[8 + j] : p[j], b3 ? p[j] : p[8 + j]);          // row_mirror: partner 15 - i
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = dpp_add<0x141>(b2 ? a[4 + j] : a[j], b2 ? a[j] : a[4 + j]);          // row_half_mirror: partner i ^ 7
+#pragma unroll
+    for (int j = 0; j < 2; ++j) c[j] = dpp_add<0x4E>(b1 ? b[2 + j] : b[j], b1 ? b[j] : b[2 + j]);           // quad_perm [2,3,0,1]: partner i ^ 2
+    return dpp_add<0xB1>(b0 ? c[1] : c[0], b0 ? c[0] : c[1]);                                                // quad_perm [1,0,3,2]: partner i ^ 1
+}
 struct Par { const float *qw, *qb, *kw, *kb, *emb, *hscale; };
 struct Grd { float *dqw, *dqb, *dkw, *dkb, *demb, *dhscale; };
 
@@ -172,6 +200,49 @@ __device__ __forceinline__ void scores_softmax(const bf16x8 (&kf)[NB][KS], const
             }
     }
 }
+// The same with everything lane-constant precomputed by the caller (the backward runs it per problem in a VALU-bound loop): the T5
+// bucket offsets eidx of this lane's (query, key) pairs, the key mask as an additive 0 / -inf, the (query, key) validity mask as a
+// 0 / 1 factor.  emb is an LDS table [32][16] (zeros when the block has no bias table): no branch per element.
+template <int NB, int KS>
+__device__ __forceinline__ void scores_softmax_pre(const bf16x8 (&kf)[NB][KS], const bf16x8 (&qf)[NB][KS], const float* emb, const int (&eidx)[NB][NB][4],
+                                                   const float (&mneg)[NB][NB][4], const float (&mk)[NB][NB][4], const float* hscale, int head, int L,
+                                                   float (&P)[NB][NB][4], float (&A)[NB][NB][4]) {
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+        for (int ib = 0; ib < NB; ++ib) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jb][s], qf[ib][s], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[jb][ib][r] = acc[r] + emb[eidx[jb][ib][r] + head] + mneg[jb][ib][r];
+        }
+    const float invL = 1.0f / (float)L;
+    const float hs = hscale ? hscale[head] : 1.f;
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, P[jb][ib][r]);
+        m = quad_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float e = __expf(P[jb][ib][r] - m); P[jb][ib][r] = e; sum += e; }
+        const float inv = 1.f / quad_sum(sum);
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pr = P[jb][ib][r] * inv;
+                P[jb][ib][r] = pr;
+                A[jb][ib][r] = (hscale ? invL + (pr - invL) * hs : pr) * mk[jb][ib][r];
+            }
+    }
+}
 // registers (key blocks x 4) of one query block -> the B operand whose k-slot (g, jj) is key 4g+jj / 16+4g+jj-4
 template <int NB>
 __device__ __forceinline__ bf16x8 pack_keys(const float (&X)[NB][NB][4], int ib) {
@@ -222,12 +293,11 @@ __device__ __forceinline__ void stage_tile(const bf16* __restrict__ base, long r
 // q / k / v rows of one problem in the MFMA operand layout: lane (i = l & 15, g = l >> 4) holds channels 32*s + 8*g .. +7 of row i
 template <int NB, int KS> struct FwdRows { bf16x8 q[NB][KS], k[NB][KS], v[NB][KS]; };
 template <int NB, int KS>
-__device__ __forceinline__ void load_fwd_rows(FwdRows<NB, KS>& r, const bf16* __restrict__ qkv, const Geo& g, int heads, long pr, int lane) {
+__device__ __forceinline__ void load_fwd_rows(FwdRows<NB, KS>& r, const bf16* __restrict__ qkv, const Geo& g, int heads, const Prob& at, int lane) {
     constexpr int D = 32 * KS;
     const int E = heads * D;
-    const long s = pr / heads;
-    const int head = (int)(pr % heads);
-    const long tok0 = (s / g.inner) * g.outer_stride + (s % g.inner) * g.inner_stride;
+    const int head = at.head;
+    const long tok0 = at.tok0;
     const int gq = lane >> 4, i16 = lane & 15;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -254,7 +324,7 @@ __global__ void __launch_bounds__(256) attn_fwd_mfma(const bf16* __restrict__ qk
     __shared__ __attribute__((aligned(16))) float s_par[4 * 32 * KS];   // qw | qb | kw | kb
     __shared__ float s_emb[32 * 16];
     __shared__ float s_hsc[16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;      // wave-uniform: scalar problem bookkeeping
     bf16* vt = smem_fwd + wave * (16 * NB * LD);
     for (int i = threadIdx.x; i < 32 * 16; i += blockDim.x) {
         const int t = i >> 4, h = i & 15;
@@ -273,12 +343,14 @@ __global__ void __launch_bounds__(256) attn_fwd_mfma(const bf16* __restrict__ qk
     const long pstep = (long)gridDim.x * wpb;
     long pr = (long)blockIdx.x * wpb + wave;
     FwdRows<NB, KS> cur, nxt;
-    if (pr < nprob) load_fwd_rows<NB, KS>(cur, qkv, g, heads, pr, lane);
+    Prob at = locate(g, heads, pr < nprob ? pr : 0), at_next = at;
+    if (pr < nprob) load_fwd_rows<NB, KS>(cur, qkv, g, heads, at, lane);
     for (; pr < nprob; pr += pstep) {
-        const long s = pr / heads;
-        const int head = (int)(pr % heads);
-        const long tok0 = (s / g.inner) * g.outer_stride + (s % g.inner) * g.inner_stride;
-        if (PREFETCH && pr + pstep < nprob) load_fwd_rows<NB, KS>(nxt, qkv, g, heads, pr + pstep, lane);
+        const int head = at.head;
+        const long tok0 = at.tok0;
+        const bool more = pr + pstep < nprob;
+        if (more) at_next = locate(g, heads, pr + pstep);
+        if (PREFETCH && more) load_fwd_rows<NB, KS>(nxt, qkv, g, heads, at_next, lane);
         bf16x4 old[NB][NT16];
         if (accumulate) {
 #pragma unroll
@@ -341,7 +413,8 @@ __global__ void __launch_bounds__(256) attn_fwd_mfma(const bf16* __restrict__ qk
         }
         wsync();   // before the next problem overwrites the V tile
         if (PREFETCH) cur = nxt;
-        else if (pr + pstep < nprob) load_fwd_rows<NB, KS>(cur, qkv, g, heads, pr + pstep, lane);
+        else if (more) load_fwd_rows<NB, KS>(cur, qkv, g, heads, at_next, lane);
+        at = at_next;
     }
 }
 
@@ -395,7 +468,7 @@ __global__ void __launch_bounds__(64 * WPB) attn_fwd_axial_mfma(const bf16* __re
                 const Geo& g = isH ? gH : gW;
                 const long seq = (long)frame * (isH ? w : h) + idx;
                 FwdRows<NB, KS> cur;
-                load_fwd_rows<NB, KS>(cur, qkv, g, heads, seq * heads + head, lane);
+                load_fwd_rows<NB, KS>(cur, qkv, g, heads, locate(g, heads, seq * heads + head), lane);
                 bf16x8 qf[NB][KS], kf[NB][KS];
                 {
                     float x[KS][8];
@@ -528,13 +601,12 @@ template <int NB, int KS> struct RawRows { bf16x8 q[NB][KS], k[NB][KS], v[NB][KS
 template <int NB, int KS> struct OldRows { bf16x8 q[NB][KS], k[NB][KS]; bf16x4 v[NB][2 * KS]; };
 
 template <int NB, int KS>
-__device__ __forceinline__ void load_raw(RawRows<NB, KS>& r, const bf16* __restrict__ qkv, const bf16* __restrict__ dout, const Geo& g, int heads, long pr,
+__device__ __forceinline__ void load_raw(RawRows<NB, KS>& r, const bf16* __restrict__ qkv, const bf16* __restrict__ dout, const Geo& g, int heads, const Prob& at,
                                          int lane) {
     constexpr int D = 32 * KS;
     const int E = heads * D;
-    const long s = pr / heads;
-    const int head = (int)(pr % heads);
-    const long tok0 = (s / g.inner) * g.outer_stride + (s % g.inner) * g.inner_stride;
+    const int head = at.head;
+    const long tok0 = at.tok0;
     const int gq = lane >> 4, i16 = lane & 15;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -564,7 +636,7 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
     __shared__ __attribute__((aligned(16))) float s_par[4 * 32 * KS];   // qw | qb | kw | kb
     __shared__ float s_emb[32 * 16];
     __shared__ float s_hsc[16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;      // provably wave-uniform: problem bookkeeping in SGPRs
     // per-wave: Qn, Kn, dO tiles [R][LD] bf16; A^T and dS^T tiles [R][LDP] bf16 ([key j][query i]); fp32 re-layout buffer aliases the tiles
     constexpr int PER_WAVE = 3 * R * LD + 2 * R * LDP;
     static_assert(3 * R * LD * 2 >= R * LDF * 4, "re-layout buffer must fit in the operand tiles");
@@ -611,12 +683,28 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
             for (int r = 0; r < 4; ++r) a_emb[jb][ib][r] = 0.f;
     long pr = (long)blockIdx.x * wpb + wave;
     RawRows<NB, KS> cur, nxt;
-    if (pr < nprob) load_raw<NB, KS>(cur, qkv, dout, g, heads, pr, lane);
+    Prob at = locate(g, heads, pr < nprob ? pr : 0), at_next = at;
+    if (pr < nprob) load_raw<NB, KS>(cur, qkv, dout, g, heads, at, lane);
+    // lane-constant masks and T5 bucket offsets of this lane's (query, key) pairs: once, not per problem
+    float mk[NB][NB][4], mneg[NB][NB][4];
+    int eidx[NB][NB][4];
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+        for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * ib + i16, j = 16 * jb + 4 * gq + r;
+                mk[jb][ib][r] = (i < L && j < L) ? 1.f : 0.f;
+                mneg[jb][ib][r] = j < L ? 0.f : -INFINITY;
+                eidx[jb][ib][r] = t5b(i - j) * 16;
+            }
     for (; pr < nprob; pr += pstep) {
-        const long s = pr / heads;
-        const int head = (int)(pr % heads);
-        const long tok0 = (s / g.inner) * g.outer_stride + (s % g.inner) * g.inner_stride;
-        if (PREFETCH && pr + pstep < nprob) load_raw<NB, KS>(nxt, qkv, dout, g, heads, pr + pstep, lane);
+        const int head = at.head;
+        const long tok0 = at.tok0;
+        const bool more = pr + pstep < nprob;
+        if (more) at_next = locate(g, heads, pr + pstep);
+        if (PREFETCH && more) load_raw<NB, KS>(nxt, qkv, dout, g, heads, at_next, lane);
         // gradient rows this problem accumulates into (second axial pass): issued now, consumed at the very end
         OldRows<NB, KS> old;
         if (accumulate) {
@@ -662,7 +750,7 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
             }
         }
         float P[NB][NB][4], A[NB][NB][4], dA[NB][NB][4];
-        scores_softmax<NB, KS>(kf, qf, p.emb ? s_emb : nullptr, 16, p.hscale ? s_hsc : nullptr, head, L, lane, P, A);
+        scores_softmax_pre<NB, KS>(kf, qf, s_emb, eidx, mneg, mk, p.hscale ? s_hsc : nullptr, head, L, P, A);
         // dA^T[j][i] = sum_e V[j][e] dO[i][e] * out_scale
         const float hs = s_hsc[head];
         const float invL = 1.0f / (float)L;
@@ -676,8 +764,7 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
                 for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[jb][ks], df[ib][ks], acc, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * ib + i16, j = 16 * jb + 4 * gq + r;
-                    float v = (i < L && j < L) ? acc[r] * out_scale : 0.f;
+                    float v = acc[r] * out_scale * mk[jb][ib][r];
                     if (p.hscale) { dhs += (P[jb][ib][r] - invL) * v; v *= hs; }
                     dA[jb][ib][r] = v;     // now dP
                 }
@@ -696,11 +783,11 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = 16 * ib + i16, j = 16 * jb + 4 * gq + r;
-                    const float v = (i < L && j < L) ? P[jb][ib][r] * (dA[jb][ib][r] - dot) : 0.f;
+                    const float v = P[jb][ib][r] * (dA[jb][ib][r] - dot) * mk[jb][ib][r];
                     dA[jb][ib][r] = v;     // now dS
                     if (one_head) a_emb[jb][ib][r] += v;
-                    else if (gr.demb && i < L && j < L) atomicAdd(&s_demb[t5b(i - j) * 16 + head], v);
-                    if (i >= L) A[jb][ib][r] = 0.f;
+                    else if (gr.demb && i < L && j < L) atomicAdd(&s_demb[eidx[jb][ib][r] + head], v);
+                    // (A of a query row >= L is already zero: scores_softmax_pre masks it)
                     // transposed copies [key j][query i] for the products that reduce over queries
                     at_t[j * LDP + i] = (bf16)A[jb][ib][r];
                     ds_t[j * LDP + i] = (bf16)v;
@@ -812,19 +899,25 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
                     }
                 }
             }
+            {   // value v = 16 part KS + (dw: 8 ks + j | db: 8 KS + 8 ks + j) ends in lane v & 15 of the row, slot v >> 4: KS groups of sixteen
+                float flat[16 * KS];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
+                for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int vw = ((2 * part) * KS + ks) * 8 + j, vb = ((2 * part + 1) * KS + ks) * 8 + j;
-                    const float tw = row16_sum(pw[ks][j]), tb = row16_sum(pb[ks][j]);
-                    if (i16 == (vw & 15)) a_ln[vw >> 4] += tw;
-                    if (i16 == (vb & 15)) a_ln[vb >> 4] += tb;
+                    for (int j = 0; j < 8; ++j) { flat[8 * ks + j] = pw[ks][j]; flat[8 * KS + 8 * ks + j] = pb[ks][j]; }
+#pragma unroll
+                for (int gi = 0; gi < KS; ++gi) {
+                    float grp[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) grp[q] = flat[16 * gi + q];
+                    a_ln[part * KS + gi] += row16_scatter_sum(grp, i16);
                 }
+            }
             wsync();
         }
         if (PREFETCH) cur = nxt;
-        else if (pr + pstep < nprob) load_raw<NB, KS>(cur, qkv, dout, g, heads, pr + pstep, lane);
+        else if (more) load_raw<NB, KS>(cur, qkv, dout, g, heads, at_next, lane);
+        at = at_next;
     }
     // ---- flush parameter gradients.  Thousands of waves adding to the same few hundred addresses serialise at the
     // memory side, so: block reduce in LDS -> ONE row of plain stores per block into the workspace (summed by
@@ -887,6 +980,7 @@ int go_fwd(const bf16* qkv, bf16* out, Geo g, int heads, Par p, float out_scale,
     const int wpb = 4;
     const size_t shm = (size_t)wpb * 16 * NB * (D + 16) * sizeof(bf16);
     const long nprob = g.nseq * heads;
+    BF_REQUIRE(nprob < (1L << 31) && g.inner < (1L << 31), "attention: problem count must fit 31 bits");
     // measured (tools/attn_bench.py): 2 workgroups per CU of look-ahead waves beat 8 of plain ones (18.7 vs 21.0 us at the bench shape)
     static const int bpc = []() { const char* v = getenv("BF_ATTN_FWD_BPC"); return v ? atoi(v) : 2; }();
     const int grid = (int)std::min<long>((nprob + wpb - 1) / wpb, 256L * bpc);
@@ -902,6 +996,7 @@ int go_bwd(const bf16* qkv, const bf16* dout, bf16* dqkv, Geo g, int heads, Par 
     const size_t shm = (size_t)wpb * (3 * R * (D + 16) + 2 * R * 40) * sizeof(bf16);
     if (int rc = set_lds(attn_bwd_mfma<NB, KS>, shm)) return rc;
     const long nprob = g.nseq * heads;
+    BF_REQUIRE(nprob < (1L << 31) && g.inner < (1L << 31), "attention: problem count must fit 31 bits");
     const int nvals = 4 * D + 32 * heads + heads;
     // persistent waves: one resident set of workgroups (what the register / LDS budget admits per CU), each wave loops over problems
     static int resident = 0;       // per instantiation

@@ -16,6 +16,9 @@
 #include "gemm_common.h"
 #include <stdlib.h>
 
+int bf_gemm_pair_scaled(int M, int N, int K, const bf_operand* A, const bf_operand* B, const bf_epilogue* E, void* out2, const float* rowfac,
+                        int rows_per_group, hipStream_t st);
+
 namespace {
 using namespace bfgemm;
 
@@ -265,6 +268,7 @@ struct PairArgs {
     const bf16* x; const bf16* add; bf16* out; long ldx;
     const float* mean; const float* rstd; const float* w; float* ws;
     const float* fscale; int fdiv;
+    bf16* out2;                         // MODE 1, optional: out2 = out * fscale[row / fdiv] (the stochastic-depth-scaled copy the next kernels read)
 };
 
 // LDS-DMA with a wave-uniform 64-bit base in SGPRs and a per-lane 32-bit byte offset: one offset register serves every piece of a wave
@@ -398,6 +402,13 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
                 for (int q = 0; q < 8; ++q) o[q] = (bf16)v[i][q];
             }
             *reinterpret_cast<bf16x8*>(a.out + (row0 + 16 * i) * a.ldx + col0) = o;
+            if (a.out2) {                            // the scaled copy is the scaled ROUNDED value: what a separate pass over `out` would write
+                const float m = a.fscale[(row0 + 16 * i) / a.fdiv];
+                bf16x8 o2;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o2[q] = (bf16)((float)o[q] * m);
+                *reinterpret_cast<bf16x8*>(a.out2 + (row0 + 16 * i) * a.ldx + col0) = o2;
+            }
         }
     } else {
         const int fidx = fidx0 + GRP;
@@ -511,7 +522,7 @@ extern "C" int bf_gemm_inbwd_frames(int dtype, int M, int N, int K, const void* 
         PairArgs a;      // an even number of frames: two frames per workgroup, LDS-DMA ping-pong
         a.A = (const bf16*)A; a.lda = lda; a.B = (const bf16*)B; a.ldb = ldb; a.N = N; a.nk = K / PK; a.nt = N / PN;
         a.x = (const bf16*)x; a.add = (const bf16*)add; a.out = (bf16*)out; a.ldx = N;
-        a.mean = mean; a.rstd = rstd; a.w = w; a.ws = ws; a.fscale = fscale; a.fdiv = fdiv > 0 ? fdiv : 1;
+        a.mean = mean; a.rstd = rstd; a.w = w; a.ws = ws; a.fscale = fscale; a.fdiv = fdiv > 0 ? fdiv : 1; a.out2 = nullptr;
         BfProfScope prof((hipStream_t)stream, "gemm_pair<inbwd>", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * N * (add ? 3 : 2)));
         return launch_pair<0>(a, M, (hipStream_t)stream);
     }
@@ -533,6 +544,12 @@ extern "C" int bf_gemm_inbwd_frames(int dtype, int M, int N, int K, const void* 
 // out[M][N] = A[M][K] @ B[K][N] (+ add) on the frame-pair kernel: A K-contiguous, B outer-contiguous (a weight [out][in] used as the
 // data gradient's operand), 288-row tiles.  0 = handled, 1 = not covered, < 0 = error.
 int bf_gemm_pair_try(int M, int N, int K, const bf_operand* A, const bf_operand* B, const bf_epilogue* E, hipStream_t st) {
+    return bf_gemm_pair_scaled(M, N, K, A, B, E, nullptr, nullptr, 1, st);
+}
+// ... with an optional second output out2[m][:] = C[m][:] * rowfac[m / rows_per_group] (library-internal: the gradient entering a branch
+// under stochastic depth, written by the kernel that produces the gradient instead of by a pass of its own)
+int bf_gemm_pair_scaled(int M, int N, int K, const bf_operand* A, const bf_operand* B, const bf_epilogue* E, void* out2, const float* rowfac,
+                        int rows_per_group, hipStream_t st) {
     if (A->layout != BF_LAY_KC || B->layout != BF_LAY_XC || A->pro != BF_PRO_NONE || B->pro != BF_PRO_NONE) return 1;
     if (A->gw > 0 || A->seglen > 0 || B->gw > 0 || B->seglen > 0 || E->gw > 0 || E->seglen > 0) return 1;
     if (E->out_mode != BF_OUT_STORE || E->colsum || E->bias || E->colscale || E->rowscale || E->gelu_out) return 1;
@@ -542,7 +559,9 @@ int bf_gemm_pair_try(int M, int N, int K, const bf_operand* A, const bf_operand*
     PairArgs a;
     a.A = (const bf16*)A->p; a.lda = A->ld; a.B = (const bf16*)B->p; a.ldb = B->ld; a.N = N; a.nk = K / PK; a.nt = N / PN;
     a.x = nullptr; a.add = E->aux_mode == BF_AUX_ADD ? (const bf16*)E->aux : nullptr; a.out = (bf16*)E->c; a.ldx = N;
-    a.mean = nullptr; a.rstd = nullptr; a.w = nullptr; a.ws = nullptr; a.fscale = nullptr; a.fdiv = 1;
+    a.mean = nullptr; a.rstd = nullptr; a.w = nullptr; a.ws = nullptr; a.fscale = rowfac; a.fdiv = rows_per_group > 0 ? rows_per_group : 1;
+    a.out2 = rowfac ? (bf16*)out2 : nullptr;
+    if (a.out2 && ((uintptr_t)out2 & 15)) return 1;
     BfProfScope prof(st, a.add ? "gemm_pair<add>" : "gemm_pair<plain>", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * N * (a.add ? 2 : 1)));
     return launch_pair<1>(a, M, st);
 }

@@ -542,6 +542,11 @@ int dgrad_inbwd(const D& d, const void* dy, int Kdim, const void* w_xc, int Nout
     TRY(bf_gemm(d.dtype, (int)d.N, Nout, Kdim, &A, &Bo, &e, 1, st));
     return bf_in_bwd_partials(d.dtype, tmp, f.x, f.add, f.dx, (int)d.F, (int)d.S, Nout, f.mean, f.rstd, f.w, f.b, nullptr, 1, 0, f.ws, st);
 }
+#ifdef BF_EXPERIMENTS
+bool no_dbr2() { static const bool v = getenv("BF_NO_DBR2") != nullptr; return v; }
+#else
+constexpr bool no_dbr2() { return false; }
+#endif
 bool side_frame_scale() { static const bool on = []() { const char* v = getenv("BF_SIDE_FRAME_SCALE"); return v && atoi(v) != 0; }(); return on; }
 // backward of the folded out-projection: param grads + don = (dout * alpha) @ W
 int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on, const void* w_s,
@@ -583,7 +588,8 @@ int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on,
 // backward of y = affine(x) @ W^T + b:  dW += dy^T affine(x), db += colsum(dy), dxn = dy @ W
 int linear_bwd(const D& d, const Scratch& sc, const void* dy, int Nout, const void* x, int Kin, int xpro, const float* xsc, const float* xsh,
                const void* w_c, float* dW, float* db, void* dxn, const bf_epilogue* dx_epi, hipStream_t st, Fork& fk, const InFuse* fu = nullptr,
-               bool last = false, const void* w_t = nullptr) {      // w_t: the weight transposed ([Kin][Nout], K-contiguous for the data gradient)
+               bool last = false, const void* w_t = nullptr, void* scaled_out = nullptr, const float* rowfac = nullptr, int rpg = 1,
+               bool* scaled_done = nullptr) {      // w_t: the weight transposed ([Kin][Nout], K-contiguous for the data gradient)
     TRY(fk.run([=](hipStream_t ss) -> int {      // weight gradient: side stream
         const void* xo = x;
         int pro = xpro;
@@ -610,6 +616,11 @@ int linear_bwd(const D& d, const Scratch& sc, const void* dy, int Nout, const vo
         bf_operand Bo = w_t ? op_plain(w_t, Nout, BF_LAY_KC) : op_plain(w_c, Kin, BF_LAY_XC);      // K-contiguous: the streaming kernel's form
         bf_epilogue e = dx_epi ? *dx_epi : epi_store(dxn, Kin);
         e.c = dxn; e.ldc = Kin;
+        if (scaled_out && rowfac && d.dtype == BF_DTYPE_BF16) {      // the row-scaled copy of dxn from the same kernel, where its shape is covered
+            const int rc = bf_gemm_pair_scaled((int)d.N, Kin, Nout, &A, &Bo, &e, scaled_out, rowfac, rpg, st);
+            if (rc < 0) return rc;
+            if (rc == 0) { if (scaled_done) *scaled_done = true; return 0; }
+        }
         TRY(bf_gemm(d.dtype, (int)d.N, Kin, Nout, &A, &Bo, &e, 1, st));
     }
     return 0;
@@ -871,16 +882,20 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     }
     // fc1: pre = x1 @ W1^T + b1 ; dx1 = dout + dpre @ W1
     void* dx1 = sc.t1b;
+    bool dbr_done = false;
     {
         bf_epilogue e; memset(&e, 0, sizeof(e));
         e.aux_mode = BF_AUX_ADD; e.aux = dout; e.ld_aux = d.E; e.out_mode = BF_OUT_STORE;
-        TRY(linear_bwd(d, sc, dpre, 4 * d.E, sv.x1, d.E, BF_PRO_NONE, nullptr, nullptr, w1_c, g->fc1_w, g->fc1_b, dx1, &e, st, fk));
+        // ... and, under stochastic depth, the gradient entering the attention branch (drop_att[f] * dx1) as the kernel's second output
+        TRY(linear_bwd(d, sc, dpre, 4 * d.E, sv.x1, d.E, BF_PRO_NONE, nullptr, nullptr, w1_c, g->fc1_w, g->fc1_b, dx1, &e, st, fk, nullptr, false, nullptr,
+                       (drop_att && !side_frame_scale() && !no_dbr2()) ? sc.e5 : nullptr, drop_att, (int)d.S, &dbr_done));
     }
     // folded out-projection
     void* don = sc.e6;
     const void* dbr = dx1;  // gradient entering the attention branch (dx1 itself continues down the residual)
     const bool side_fs = side_frame_scale();
-    if (drop_att && !side_fs) {
+    if (dbr_done) dbr = sc.e5;
+    else if (drop_att && !side_fs) {
         TRY(bf_frame_scale(d.dtype, dx1, drop_att, 1, sc.e5, d.N, (int)d.S, d.E, st));
         dbr = sc.e5;
     }
