@@ -130,7 +130,7 @@ template <typename T>
 __global__ void __launch_bounds__(NT) attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, SeqGeo g, int heads, int d,
                                                      AttnParams p, float out_scale, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int L = g.L, ldd = d + 1, E = heads * d;
     const int per_wave = 3 * L * ldd + L * (L + 1) + 2 * L;
     float* q = smem + wave * per_wave;
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(NT) attn_bwd_kernel(const T* __restrict__ qkv,
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float s_demb[32 * 16];     // [bucket][head] (heads <= 16), block-reduced
     __shared__ float s_dhs[16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int L = g.L, ldd = d + 1, E = heads * d, lds = L + 1;
     const int per_wave = 6 * L * ldd + 2 * L * lds + 2 * L;
     float* q = smem + wave * per_wave;      // xhat_q

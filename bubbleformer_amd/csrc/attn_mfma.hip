@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(64 * WPB) attn_fwd_axial_mfma(const bf16* __re
     __shared__ __attribute__((aligned(16))) float s_par[4 * 32 * KS];   // qw | qb | kw | kb
     __shared__ float s_emb[32 * 16];
     __shared__ float s_hsx[16], s_hsy[16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;      // wave-uniform: scalar sequence bookkeeping
     bf16* vt = smem_ax + wave * (16 * LD);
     bf16* ot = smem_ax + wpb * (16 * LD);                                 // [h * w][DP]
     for (int i = threadIdx.x; i < 32 * 16; i += blockDim.x) {
@@ -458,7 +458,7 @@ __global__ void __launch_bounds__(64 * WPB) attn_fwd_axial_mfma(const bf16* __re
     const int RW = (h + wpb - 1) / wpb, RH = (w + wpb - 1) / wpb;         // rounds per phase (uniform over the waves: barriers)
     const long ntile = (long)frames * heads;
     for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-        const int frame = (int)(tile / heads), head = (int)(tile % heads);
+        const int frame = (int)((unsigned)tile / (unsigned)heads), head = (int)((unsigned)tile - (unsigned)frame * (unsigned)heads);      // (< 2^31 tiles: host-checked)
         for (int k = 0; k < RW + RH; ++k) {
             const bool isH = k >= RW;
             const int idx = wave + (isH ? k - RW : k) * wpb;

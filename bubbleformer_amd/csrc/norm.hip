@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(NT) in_stats_merge_kernel(const float* __restr
                                                            float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ sc,
                                                            float* __restrict__ sh) {
     __shared__ float red[2][4][64];
-    const int l = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int l = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = blockIdx.x * 64 + l, f = blockIdx.y;
     const bool cv = c < C;
     const float2* pp = reinterpret_cast<const float2*>(part) + (long)f * nsl * C + (cv ? c : 0);
@@ -501,7 +501,7 @@ __global__ void __launch_bounds__(NT_) in_bwd_slice_kernel(const T* __restrict__
 // grid (ceil(C/64), frames), 256 threads = 64 channels x 4 slice lanes
 __global__ void __launch_bounds__(NT) in_slice_sum_kernel(const float* __restrict__ part, int C, int nsl, float* __restrict__ tot) {
     __shared__ float red[2][4][64];
-    const int l = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int l = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = blockIdx.x * 64 + l, f = blockIdx.y;
     const bool cv = c < C;
     const float2* pp = reinterpret_cast<const float2*>(part) + (long)f * nsl * C + (cv ? c : 0);

@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(NT) pm2nchw_kernel(const float* __restrict__ p
     __shared__ float red[NT / 64][2];
     const int f = blockIdx.y;
     const int H = 2 * h, W = 2 * w;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int co = 0; co < Co; ++co) {
         float num = 0.f, den = 0.f;
         for (int px = blockIdx.x * NT + threadIdx.x; px < h * w; px += gridDim.x * NT) {
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(NT) debed_last_kernel(const bf16* __restrict__
                                                        const bf16* __restrict__ wc, float* __restrict__ pred, const float* __restrict__ y,
                                                        float* __restrict__ lossbuf, int Co, int h, int w) {
     constexpr int Ci = 32 * KS;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, lg = lane >> 4;
     const int f = blockIdx.y;
     const int GF = h * w / 16;                                      // groups per frame
@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(NT) debed_last_bwd_kernel(const float* __restr
                                                            int Co, int h, int w, float* __restrict__ part, int perm) {
     constexpr int Ci = 16 * T;
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, lg = lane >> 4;
     const int f = blockIdx.y;
     const int GF = h * w / 16;
