@@ -426,7 +426,7 @@ extern "C" int bf_attn_axial_norm_fwd(int dtype, const void* qkv, void* out, voi
                                       float* rstd, float* sc, float* sh, bf_stream_t stream) {
     BF_REQUIRE(qkv && out && out_n && qw && qb && kw && kb && norm_w && norm_b && mean && rstd && sc && sh && frames > 0 && h > 0 && w > 0,
                "bf_attn_axial_norm_fwd: bad arguments");
-    static const bool off = []() { const char* v = getenv("BF_ATTN_AXIAL_NORM"); return v && atoi(v) == 0; }();
+    static const bool off = bf_knob("BF_ATTN_AXIAL_NORM", 1) == 0;
     if (off || !use_mfma(dtype, d) || frames >= (1L << 24)) return 1;
     BfProfScope prof((hipStream_t)stream, "attn_fwd", 4.0 * frames * heads * h * w * (h + w) * d, (double)frames * h * w * heads * d * 2.0 * 5.0);
     return bf_attn_axial_fwd_mfma(qkv, out, (int)frames, h, w, heads, d, qw, qb, kw, kb, emb, hscale_x, hscale_y, norm_w, norm_b, out_n, mean, rstd, sc,

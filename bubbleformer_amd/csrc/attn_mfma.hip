@@ -982,7 +982,7 @@ int go_fwd(const bf16* qkv, bf16* out, Geo g, int heads, Par p, float out_scale,
     const long nprob = g.nseq * heads;
     BF_REQUIRE(nprob < (1L << 31) && g.inner < (1L << 31), "attention: problem count must fit 31 bits");
     // measured (tools/attn_bench.py): 2 workgroups per CU of look-ahead waves beat 8 of plain ones (18.7 vs 21.0 us at the bench shape)
-    static const int bpc = []() { const char* v = getenv("BF_ATTN_FWD_BPC"); return v ? atoi(v) : 2; }();
+    static const int bpc = bf_knob("BF_ATTN_FWD_BPC", 2);
     const int grid = (int)std::min<long>((nprob + wpb - 1) / wpb, 256L * bpc);
     hipLaunchKernelGGL((attn_fwd_mfma<NB, KS>), dim3(grid), dim3(wpb * 64), shm, st, qkv, out, g, heads, p, out_scale, accumulate);
     BF_CHECK_LAUNCH();
@@ -1005,7 +1005,7 @@ int go_bwd(const bf16* qkv, const bf16* dout, bf16* dqkv, Geo g, int heads, Par 
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, attn_bwd_mfma<NB, KS>, wpb * 64, shm) != hipSuccess || per_cu < 1) per_cu = 1;
-        static const int bpc = []() { const char* v = getenv("BF_ATTN_BWD_BPC"); return v ? atoi(v) : 0; }();
+        static const int bpc = bf_knob("BF_ATTN_BWD_BPC", 0);
         if (bpc > 0) per_cu = bpc;
         resident = cus * per_cu;
     }
@@ -1046,13 +1046,13 @@ int bf_attn_fwd_mfma(const void* qkv, void* out, long nseq, int L, long inner, l
 int bf_attn_axial_fwd_mfma(const void* qkv, void* out, int frames, int h, int w, int heads, int d, const float* qw, const float* qb, const float* kw,
                            const float* kb, const float* emb, const float* hscale_x, const float* hscale_y, const float* nw, const float* nb,
                            void* out_n, float* mean, float* rstd, float* sc, float* sh, hipStream_t st) {
-    static const bool off = []() { const char* v = getenv("BF_ATTN_AXIAL_FUSED"); return v && atoi(v) == 0; }();
+    static const bool off = bf_knob("BF_ATTN_AXIAL_FUSED", 1) == 0;
     if (off || h > 16 || w > 16 || h < 1 || w < 1 || d % 32 || d > 128 || heads > 16) return 1;
     Par p{qw, qb, kw, kb, emb, hscale_x};
     const long ntile = (long)frames * heads;
     // few (frame, head) tiles (inference at batch 1-2: 96-192 on 256 CUs): 12 waves per workgroup run the h row sequences in ONE round and
     // the w column sequences in one more instead of three each -- the launch is a chain of dependent ~2 us rounds, not throughput
-    static const int wpb_env = []() { const char* v = getenv("BF_ATTN_AXIAL_WPB"); return v ? atoi(v) : 0; }();
+    static const int wpb_env = bf_knob("BF_ATTN_AXIAL_WPB", 0);
     const int ks = d / 32, wpb = (wpb_env == 4 || wpb_env == 12) ? wpb_env : (ntile <= 256 ? 12 : 4);
     const bool norm = nw != nullptr;
     const size_t tile = ((size_t)h * w * (d + 8) + 7) & ~(size_t)7;

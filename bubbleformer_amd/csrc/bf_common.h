@@ -56,6 +56,15 @@ int bf_frame_scale(int dtype, const void* z, const float* m, int fdiv, void* out
 int bf_gemm_pair_scaled(int M, int N, int K, const bf_operand* A, const bf_operand* B, const bf_epilogue* E, void* out2, const float* rowfac,
                         int rows_per_group, hipStream_t st);
 
+// Experiment knobs (tile-shape sweeps, ablations, A/B switches) exist ONLY in builds made with `make EXTRA=-DBF_EXPERIMENTS`:
+// a shipped library reads no environment variable on any launch path and runs the measured defaults.
+#ifdef BF_EXPERIMENTS
+#include <stdlib.h>
+inline int bf_knob(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#else
+constexpr int bf_knob(const char*, int dflt) { return dflt; }
+#endif
+
 int bf_fail(hipError_t e, const char* file, int line);
 int bf_fail_msg(const char* msg, const char* file, int line);
 

@@ -440,7 +440,7 @@ extern "C" int bf_frame_linear(int dtype, int frames, int S, int K, int N, const
     a.xw = next_w; a.xb = next_b; a.xn = (bf16*)out_n; a.ldx = ldn;
     hipStream_t st = (hipStream_t)stream;
     // widest column block that still gives every CU a workgroup (a frame's operand is shared by the N / BN workgroups of the frame)
-    static const int force = []() { const char* v = getenv("BF_FRAME_NTC"); return v ? atoi(v) : 0; }();
+    static const int force = bf_knob("BF_FRAME_NTC", 0);
     int ntc = 1;
     for (int c : {3, 2}) if (N % (32 * c) == 0 && (long)frames * (N / (32 * c)) >= 180) { ntc = c; break; }
     if (force >= 1 && force <= 3 && N % (32 * force) == 0) ntc = force;

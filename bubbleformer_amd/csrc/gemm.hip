@@ -370,10 +370,10 @@ int launch(int M, int N, int K, const bf_operand* A, const bf_operand* B, const 
     const int kper = bf_cdiv(ktiles, splitk) * BK;
     splitk = bf_cdiv(K, kper);
     const int nt = bf_cdiv(N, BN);
-    static const int small_env = []() { const char* v = getenv("BF_GEMM_SMALL"); return v ? atoi(v) : -1; }();
+    static const int small_env = bf_knob("BF_GEMM_SMALL", -1);
     // measured: with 8-wave workgroups the 128 x 128 tile beats 64 x 128 even on grids of < 2 workgroups per CU
     // ... except where 128-row tiles leave most CUs without a workgroup (the patch stages at batch 1: 18-72 row tiles): 64-row tiles then
-    static const int few_env = []() { const char* v = getenv("BF_GEMM_FEW_TILES"); return v ? atoi(v) : 100; }();
+    static const int few_env = bf_knob("BF_GEMM_FEW_TILES", 100);
     const bool few = splitk <= 1 && (long)bf_cdiv(M, 128) * nt < few_env && M > 64;
     const bool small = small_env >= 0 ? (small_env != 0 && M > 64) : (M <= 64 || few);
     const int bm = small ? 64 : 128;
@@ -381,8 +381,8 @@ int launch(int M, int N, int K, const bf_operand* A, const bf_operand* B, const 
     dim3 grid((unsigned)((long)mt * nt * splitk));
     const bool ax = A->layout == BF_LAY_XC, bx = B->layout == BF_LAY_XC;
     const double es = sizeof(T);
-    static const int dbg = []() { const char* v = getenv("BF_GEMM_DEBUG"); return v ? atoi(v) : 0; }();
-    static const int w8env = []() { const char* v = getenv("BF_GEMM_WAVES"); return v ? atoi(v) : 0; }();
+    static const int dbg = bf_knob("BF_GEMM_DEBUG", 0);
+    static const int w8env = bf_knob("BF_GEMM_WAVES", 0);
     // measured (tools/gemm_bench.py, MI355X): with one register stage, 8 waves of TM x 2 tiles (<= 128 VGPRs: two 8-wave
     // workgroups per CU) win on every shape of this model
     const bool w8 = sizeof(T) == 2 && (w8env == 8 || w8env == 0);
@@ -394,7 +394,7 @@ int launch(int M, int N, int K, const bf_operand* A, const bf_operand* B, const 
                      (double)M * K * es + (double)N * K * es + (double)M * N * (E->out_mode == BF_OUT_STORE ? es : 4.0) +
                          (E->aux_mode != BF_AUX_NONE ? (double)M * N * es : 0.0));
     const bool ap = A->pro != BF_PRO_NONE, bp = B->pro != BF_PRO_NONE;
-    static const int st_env = []() { const char* v = getenv("BF_GEMM_STAGES"); return v ? atoi(v) : 0; }();
+    static const int st_env = bf_knob("BF_GEMM_STAGES", 0);
     const bool s1 = st_env == 1;
 #define BF_GEMM_GO2(AX, BX, AP, BP, NS)                                                                                       \
     do {                                                                                                                      \

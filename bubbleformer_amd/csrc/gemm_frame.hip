@@ -502,10 +502,8 @@ int launch_pair(const PairArgs& a, int M, hipStream_t st) {
     return 0;
 }
 bool pair_shape_ok(int M, int N, int K, int64_t lda, int64_t ldb) {
-#ifdef BF_EXPERIMENTS
-    static const bool off = []() { const char* v = getenv("BF_PAIR"); return v && atoi(v) == 0; }();      // A/B against the kernels it replaces
+    static const bool off = bf_knob("BF_PAIR", 1) == 0;      // A/B against the kernels it replaces
     if (off) return false;
-#endif
     return M > 0 && M % PM == 0 && N > 0 && N % PN == 0 && K >= PK && K % PK == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
            (long)PM * lda * 2 < (1L << 31) && (long)PK * ldb * 2 < (1L << 31);
 }
@@ -516,7 +514,7 @@ extern "C" int bf_gemm_inbwd_frames(int dtype, int M, int N, int K, const void* 
                                     const void* add, void* out, int S, const float* mean, const float* rstd, const float* w, float* ws,
                                     const float* fscale, int fdiv, bf_stream_t stream) {
     BF_REQUIRE(A && B && x && out && mean && rstd && w, "bf_gemm_inbwd_frames: null pointer");
-    static const bool off = []() { const char* v = getenv("BF_FUSE_INBWD"); return v && atoi(v) == 0; }();
+    static const bool off = bf_knob("BF_FUSE_INBWD", 1) == 0;
     if (off || dtype != BF_DTYPE_BF16 || S != FM || M <= 0 || M % FM || N <= 0 || N % FN || K < FK || K % FK || lda % 8 || ldb % 8) return 1;
     if (pair_shape_ok(M, N, K, lda, ldb) && (((uintptr_t)A | (uintptr_t)B | (uintptr_t)x | (uintptr_t)add | (uintptr_t)out) & 15) == 0) {
         PairArgs a;      // an even number of frames: two frames per workgroup, LDS-DMA ping-pong

@@ -508,7 +508,6 @@ __global__ void __launch_bounds__(512) stream_pp_kernel(StreamArgs a) {
     }
 }
 
-int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 
 int num_cus() {
     static const int n = []() {
@@ -523,7 +522,7 @@ int num_cus() {
 
 // 0 = handled, 1 = shape / feature not covered (the caller's tile kernel runs), < 0 = error
 int bf_gemm_stream_try(int M, int N, int K, const bf_operand* A, const bf_operand* B, const bf_epilogue* E, hipStream_t st) {
-    static const int enabled = env_int("BF_GEMM_STREAM", 1);
+    static const int enabled = bf_knob("BF_GEMM_STREAM", 1);
     if (!enabled) return 1;
     if (A->layout != BF_LAY_KC || B->layout != BF_LAY_KC || A->pro != BF_PRO_NONE || B->pro != BF_PRO_NONE) return 1;
     if (A->gw > 0 || A->seglen > 0 || B->gw > 0 || B->seglen > 0 || E->gw > 0 || E->seglen > 0) return 1;
@@ -533,7 +532,7 @@ int bf_gemm_stream_try(int M, int N, int K, const bf_operand* A, const bf_operan
     // eaten by streaming the weight chunk too (6 instead of 4 DMA pieces per wave and step, ~65 cycles of wave time each).  Longer K
     // (fc2 forward, K = 1536): only the ping-pong form applies, 36 us against 40 us for the 128 x 128 tile kernel.  BF_STREAM_PP=1 / 0
     // forces one form where both apply.
-    static const int pp_env = env_int("BF_STREAM_PP", -1);
+    static const int pp_env = bf_knob("BF_STREAM_PP", -1);
     if (M % BM || N % BNB || K % BK || K < 2 * BK) return 1;
     const bool ws_ok = K >= 4 * BK && K <= 6 * BK;
     const bool use_pp = pp_env == 1 || !ws_ok;
@@ -547,9 +546,9 @@ int bf_gemm_stream_try(int M, int N, int K, const bf_operand* A, const bf_operan
     a.bias = E->bias; a.colscale = E->colscale; a.colshift = E->colshift; a.rowscale = E->rowscale; a.rpg = E->rows_per_group > 0 ? E->rows_per_group : 1;
     a.aux_mode = E->aux_mode; a.aux = (const bf16*)E->aux; a.ld_aux = E->ld_aux; a.gelu_out = (bf16*)E->gelu_out;
     a.KS = K / BK; a.mt = M / BM; a.nb = N / BNB;
-    static const int dbg = env_int("BF_STREAM_DEBUG", 0);
+    static const int dbg = bf_knob("BF_STREAM_DEBUG", 0);
     a.dbg = dbg;
-    static const int stagger = env_int("BF_STREAM_STAGGER", 1);
+    static const int stagger = bf_knob("BF_STREAM_STAGGER", 1);
     a.stagger = stagger;
     const int grid = (num_cus() / 8) * 8;
     if (a.nb > grid / 8) return 1;                    // a team (one workgroup per column block) must fit one XCD

@@ -384,7 +384,6 @@ __global__ void __launch_bounds__(256) tokred_reduce_kernel(const float* __restr
     }
 }
 
-int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 constexpr int MAX_SLICES = 16;
 
 }  // namespace
@@ -398,10 +397,8 @@ extern "C" int64_t bf_gemm_tokred_ws_floats(int Nout, int Kin, int64_t M) {
 extern "C" int bf_gemm_tokred(int dtype, int Nout, int Kin, int64_t M, const void* dy, int64_t ldy, const void* x, int64_t ldx, float* out,
                               int accumulate, float* colsum, float* ws, int64_t ws_floats, bf_stream_t stream) {
     if (dtype != BF_DTYPE_BF16) return 1;
-#ifdef BF_EXPERIMENTS
-    static const int skip_env = env_int("BF_TOKRED_SKIP", 0);      // timing experiment (results wrong): the step without its weight-gradient GEMMs
+    static const int skip_env = bf_knob("BF_TOKRED_SKIP", 0);      // timing experiment (results wrong): the step without its weight-gradient GEMMs
     if (skip_env) return 0;
-#endif
     const bool pp = Nout % 192 == 0 && Kin % PTN == 0 && M % HR == 0 && M >= 4 * HR;
     if (!pp && (Nout % TB || Kin % TB || M % BK || M < BK)) return 1;
     if (ldy % 8 || ldx % 8) return 1;
@@ -417,13 +414,9 @@ extern "C" int bf_gemm_tokred(int dtype, int Nout, int Kin, int64_t M, const voi
     // gemm_frame.hip); both queues end up equally long, so what counts is the sum of their CU-time.  Measured in the step (targets of
     // 48 / 64 / 80 / 96 / 128 workgroups: 681 / 693 / 701 / 707 / 699 samples/s): ~96, from which the slice count follows per shape
     // (QKV 6 tiles x 16, fc1 / fc2 8 x 12, out-projection 4 tiles of 192 x 192 x 16).
-#ifdef BF_EXPERIMENTS
-    static const int slices_env = env_int("BF_TOKRED_SLICES", 0);      // sweeps: a fixed slice count / tile height / workgroup target
-    static const int tile_env = env_int("BF_TOKRED_TILE", 0);
-    static const int wgs_env = env_int("BF_TOKRED_WGS", 96);
-#else
-    constexpr int slices_env = 0, tile_env = 0, wgs_env = 96;
-#endif
+    static const int slices_env = bf_knob("BF_TOKRED_SLICES", 0);      // sweeps: a fixed slice count / tile height / workgroup target
+    static const int tile_env = bf_knob("BF_TOKRED_TILE", 0);
+    static const int wgs_env = bf_knob("BF_TOKRED_WGS", 96);
     if (pp) {
         const long halves = M / HR;
         const int tiles_k0 = Kin / PTN;

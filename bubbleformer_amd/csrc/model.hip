@@ -75,7 +75,7 @@ int splitk_for(int M, int N, long K) {
     // sweep (tools/dw_sweep.py) prefers ~64/sqrt(tiles) slices, but inside the full step that loses 5% (A/B on the bench: 351 vs
     // 369 samples/s) to the rule below.
     const long tiles = (long)bf_cdiv(M, 128) * bf_cdiv(N, 128);
-    static const long target = []() { const char* v = getenv("BF_SPLITK_TARGET"); return v ? atol(v) : 256L; }();
+    static const long target = bf_knob("BF_SPLITK_TARGET", 256);
     long s = (target + tiles / 2) / tiles;   // ~one wave of tiles over 256 CUs; more slices lose to atomic traffic in the full step
     const long kt = (K + 63) / 64;
     if (s > kt / 4) s = kt / 4;                         // at least 4 K-steps per slice
@@ -106,23 +106,19 @@ struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = 
 bool g_side_defer = false;
 SideStream* side_stream() {
     static SideStream tab[64];
-    static const bool enabled = []() { const char* v = getenv("BF_SIDE_STREAM"); return !(v && atoi(v) == 0); }();
+    static const bool enabled = bf_knob("BF_SIDE_STREAM", 1) != 0;
     if (!enabled) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     SideStream& s = tab[dev];
     if (!s.st && !s.failed) {
-        // the weight-gradient work has slack, the caller's stream is the critical path: lowest priority by default (+0.3-0.5 % measured
-        // at 8 hardware queues; BF_SIDE_PRIO=0 normal, 2 highest: -4 %)
-        static const int prio_env = []() { const char* v = getenv("BF_SIDE_PRIO"); return v ? atoi(v) : 1; }();
+        // lowest priority: the caller's stream is the one a consumer waits on (round 2: +0.3-0.5 % against normal priority; round 3: no
+        // difference between lowest, normal and highest)
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // lo = least urgent (numerically greatest)
-        const int prio = prio_env == 1 ? lo : prio_env == 2 ? hi : 0;
-        // the two streams are on one device: the events need no system-scope fence (an L2 write-back + invalidate at every fork / join;
-        // BF_EVENT_FENCE=1 restores it)
-        static const bool sysfence = []() { const char* v = getenv("BF_EVENT_FENCE"); return v && atoi(v) != 0; }();
-        const unsigned ef = hipEventDisableTiming | (sysfence ? 0u : hipEventDisableSystemFence);
-        if (hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&s.fork, ef) != hipSuccess ||
+        // the two streams are on one device: the events need no system-scope fence (an L2 write-back + invalidate at every fork / join)
+        const unsigned ef = hipEventDisableTiming | hipEventDisableSystemFence;
+        if (hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, lo) != hipSuccess || hipEventCreateWithFlags(&s.fork, ef) != hipSuccess ||
             hipEventCreateWithFlags(&s.join, ef) != hipSuccess || hipEventCreateWithFlags(&s.tail[0], ef) != hipSuccess ||
             hipEventCreateWithFlags(&s.tail[1], ef) != hipSuccess) { s.failed = true; s.st = nullptr; }
     }
@@ -542,23 +538,13 @@ int dgrad_inbwd(const D& d, const void* dy, int Kdim, const void* w_xc, int Nout
     TRY(bf_gemm(d.dtype, (int)d.N, Nout, Kdim, &A, &Bo, &e, 1, st));
     return bf_in_bwd_partials(d.dtype, tmp, f.x, f.add, f.dx, (int)d.F, (int)d.S, Nout, f.mean, f.rstd, f.w, f.b, nullptr, 1, 0, f.ws, st);
 }
-#ifdef BF_EXPERIMENTS
-bool no_dbr2() { static const bool v = getenv("BF_NO_DBR2") != nullptr; return v; }
-#else
-constexpr bool no_dbr2() { return false; }
-#endif
-bool side_frame_scale() { static const bool on = []() { const char* v = getenv("BF_SIDE_FRAME_SCALE"); return v && atoi(v) != 0; }(); return on; }
 // backward of the folded out-projection: param grads + don = (dout * alpha) @ W
 int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on, const void* w_s,
                 const float* W, const float* bias, const float* nb, const float* gamma, const float* lo, const float* hi,
                 const float* alpha, const float* mc, float* dW, float* dbias, float* dnb, float* dgamma, float* dlo, float* dhi,
-                void* don, hipStream_t st, Fork& fk, const InFuse* fu = nullptr, const float* drop = nullptr, int fdiv = 1, void* dbr = nullptr) {
-    // drop (stochastic depth): the branch gradient is drop[f / fdiv] * dout.  The data-gradient path applies the factor inside its own
-    // kernel (fu->fscale / the GEMM epilogue's row factor); the parameter-gradient side needs the scaled tensor itself and makes it, on
-    // the SIDE stream, into `dbr` -- the caller's stream no longer pays a 2U pass and a fork bubble per stage for it.
-    TRY(fk.run([=](hipStream_t ss) -> int {           // parameter-gradient side: (scale,) G GEMM, finalize
+                void* don, hipStream_t st, Fork& fk, const InFuse* fu = nullptr) {
+    TRY(fk.run([=](hipStream_t ss) -> int {           // parameter-gradient side: G GEMM, finalize
         const void* dsrc = dout;
-        if (drop) { TRY(bf_frame_scale(d.dtype, dout, drop, fdiv, dbr, d.N, (int)d.S, d.E, ss)); dsrc = dbr; }
         // G[n][k] = sum_m dout[m][n] * on[m][k]; `on` is the normalised operand the forward saved; dbeta = colsum(dout) from the same pass
         const int trc = bf_gemm_tokred(d.dtype, d.E, d.E, d.N, dsrc, d.E, on, d.E, sc.G, 0, sc.csum, sc.tokred_ws, sc.tokred_floats, ss);
         if (trc < 0) return trc;
@@ -575,12 +561,11 @@ int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on,
         BF_CHECK_LAUNCH();
         return 0;
     }));
-    if (fu) { InFuse f2 = *fu; f2.fscale = drop; f2.fdiv = fdiv; return dgrad_inbwd(d, dout, d.E, w_s, d.E, don, f2, st); }      // ... followed by norm2's backward
+    if (fu) return dgrad_inbwd(d, dout, d.E, w_s, d.E, don, *fu, st);      // ... followed by norm2's backward
     {   // don = (dout * alpha) @ W = dout @ (diag(alpha) W): the scaled weight was written by the forward's parameter prep
         bf_operand A = op_plain(dout, d.E, BF_LAY_KC);
         bf_operand Bo = op_plain(w_s, d.E, BF_LAY_XC);
         bf_epilogue e = epi_store(don, d.E);
-        if (drop) { e.rowscale = drop; e.rows_per_group = (int)(d.S * fdiv); }
         TRY(bf_gemm(d.dtype, (int)d.N, d.E, d.E, &A, &Bo, &e, 1, st));
     }
     return 0;
@@ -686,20 +671,16 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
     void* don = sc.t1;      // [N][E]
     void* dO = sc.t1b;      // [N][E]
     void* dqkv = sc.t3;     // [N][3E]
-    // branch = drop[b] * (...): scale the incoming gradient once (2U pass), the rest is unchanged.  BF_SIDE_FRAME_SCALE=1 applies the
-    // factor inside the out-projection's backward kernels instead and makes the scaled tensor on the side stream (see outproj_bwd):
-    // 22 launches and fork bubbles fewer on the caller's stream, and SLOWER end to end (632 vs 649 samples/s: the side work of the stage
-    // starts a kernel earlier and lands on the fc2 / whole-frame data-gradient kernels, 65 -> 80 us and 41 -> 47 us) -- not the default.
+    // branch = drop[b] * (...): scale the incoming gradient once (2U pass), the rest is unchanged (making the scaled tensor on the side
+    // stream instead was measured twice and lost: EXPERIMENTS.md)
     const void* dbr = dout;
-    const bool side_fs = side_frame_scale();
-    if (drop && !side_fs) {
+    if (drop) {
         TRY(bf_frame_scale(d.dtype, dout, drop, d.T, sc.t4, d.N, (int)d.S, d.E, st));
         dbr = sc.t4;
     }
     const InFuse fu2{sv.o, nullptr, dO, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, sc.in_ws2};      // don @ ... then norm2's backward -> dO
     TRY(outproj_bwd(d, sc, dbr, sv.on, sv.wout_s, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr,
-                    sv.alpha, sv.mc, g->output_head_w, g->output_head_b, nullptr, g->gamma, nullptr, nullptr, don, st, fk, &fu2,
-                    side_fs ? drop : nullptr, d.T, sc.t4));
+                    sv.alpha, sv.mc, g->output_head_w, g->output_head_b, nullptr, g->gamma, nullptr, nullptr, don, st, fk, &fu2));
     ReduceJobs jobs;        // parameter-gradient reductions, all launched together at the end
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws2, (int)d.F, d.E, p->norm2_w, p->norm2_b, nullptr, 1, g->norm2_w, g->norm2_b, nullptr, nullptr, nullptr, nullptr};
     {
@@ -876,7 +857,7 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     {
         bf_epilogue e; memset(&e, 0, sizeof(e));
         e.aux_mode = BF_AUX_DGELU; e.aux = sv.pre; e.ld_aux = 4L * d.E; e.out_mode = BF_OUT_STORE;
-        static const bool use_t = []() { const char* v = getenv("BF_FC2_DGRAD_T"); return !(v && v[0] == '0'); }();
+        static const bool use_t = bf_knob("BF_FC2_DGRAD_T", 1) != 0;      // K-contiguous transposed weight: the weight-stationary ring kernel's form
         TRY(linear_bwd(d, sc, dz, d.E, sv.hid, 4 * d.E, BF_PRO_NONE, nullptr, nullptr, w2_c, g->fc2_w, g->fc2_b, dpre, &e, st, fk, nullptr, false,
                        (!f32 && use_t) ? sv.w2t_c : nullptr));
     }
@@ -888,14 +869,13 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
         e.aux_mode = BF_AUX_ADD; e.aux = dout; e.ld_aux = d.E; e.out_mode = BF_OUT_STORE;
         // ... and, under stochastic depth, the gradient entering the attention branch (drop_att[f] * dx1) as the kernel's second output
         TRY(linear_bwd(d, sc, dpre, 4 * d.E, sv.x1, d.E, BF_PRO_NONE, nullptr, nullptr, w1_c, g->fc1_w, g->fc1_b, dx1, &e, st, fk, nullptr, false, nullptr,
-                       (drop_att && !side_frame_scale() && !no_dbr2()) ? sc.e5 : nullptr, drop_att, (int)d.S, &dbr_done));
+                       drop_att ? sc.e5 : nullptr, drop_att, (int)d.S, &dbr_done));
     }
     // folded out-projection
     void* don = sc.e6;
     const void* dbr = dx1;  // gradient entering the attention branch (dx1 itself continues down the residual)
-    const bool side_fs = side_frame_scale();
     if (dbr_done) dbr = sc.e5;
-    else if (drop_att && !side_fs) {
+    else if (drop_att) {
         TRY(bf_frame_scale(d.dtype, dx1, drop_att, 1, sc.e5, d.N, (int)d.S, d.E, st));
         dbr = sc.e5;
     }
@@ -904,7 +884,7 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     TRY(outproj_bwd(d, sc, dbr, sv.on, sv.wout_s, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma_att,
                     d.feat_scale ? p->low_freq_scalar : nullptr, d.feat_scale ? p->high_freq_scalar : nullptr, sv.alpha, sv.mc,
                     g->output_head_w, g->output_head_b, g->norm2_b, g->gamma_att, d.feat_scale ? g->low_freq_scalar : nullptr,
-                    d.feat_scale ? g->high_freq_scalar : nullptr, don, st, fk, &fu2, side_fs ? drop_att : nullptr, 1, sc.e5));
+                    d.feat_scale ? g->high_freq_scalar : nullptr, don, st, fk, &fu2));
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws2, (int)d.F, d.E, p->norm2_w, p->norm2_b, nullptr, 1, g->norm2_w, g->norm2_b, nullptr, nullptr, nullptr, nullptr};
     void* dqkv = sc.t3;
     {
@@ -1165,7 +1145,7 @@ extern "C" int bf_embed_fwd(const bf_dims* dims, const bf_embed_params* p, const
             // patch rows and the K = 16 contraction in one streaming pass where it applies, else im2col + GEMM
             // ... which also leaves the InstanceNorm slice partials of its output (no second read of the 226 MB map for the statistics)
             const int S0 = sv.gh[0] * sv.gw[0];
-            static const bool part_on = []() { const char* v = getenv("BF_EMBED_STATS"); return !(v && v[0] == '0'); }();
+            static const bool part_on = bf_knob("BF_EMBED_STATS", 1) != 0;
             const bool part_ok = part_on && n > 1 && bf_in_ws_floats(d.dtype, (int)d.F, S0, sv.C[0]) >= (int64_t)2 * d.F * sv.C[0] * (1 + (S0 + 255) / 256);      // the sliced workspace holds 256-row slices
             const int rc = bf_embed_first(d.dtype, x, wc, sv.patches, sv.y[0], (int)d.F, sv.C[0], d.cin, H / 2, W / 2, sv.Kp,
                                           part_ok ? sc.in_ws + (size_t)2 * d.F * sv.C[0] : nullptr, st);

@@ -516,7 +516,7 @@ extern "C" int bf_debed_last(int dtype, const void* act, const float* sc, const 
     BF_REQUIRE(!y || lossbuf, "bf_debed_last: loss buffer missing");
     // shapes the streaming kernel does not take (the caller falls back to GEMM + bf_pm2nchw): not an error
     if (dtype != BF_DTYPE_BF16 || Np != 16 || Co > 4 || Ci % 32 != 0 || Ci > 128 || w % 16 != 0) return 1;
-    static const bool off = []() { const char* v = getenv("BF_DEBED_LAST"); return v && v[0] == '0'; }();
+    static const bool off = bf_knob("BF_DEBED_LAST", 1) == 0;
     if (off) return 1;
     const int GF = h * w / 16;
     dim3 grid(bf_cdiv(GF, (NT / 64) * DL_GPW), frames);
@@ -535,12 +535,12 @@ static int debed_last_bwd_launch(int dtype, const float* dpred, const float* pre
                                  bf_stream_t stream) {
     BF_REQUIRE(wc && dpm && dact && (dpred || (pred && y && coef)) && frames > 0 && Ci > 0 && Co > 0 && h > 0 && w > 0, "bf_debed_last_bwd: bad arguments");
     if (dtype != BF_DTYPE_BF16 || Np != 16 || Co > 4 || Ci % 32 != 0 || Ci > 128 || w % 16 != 0) return 1;      // caller keeps bf_nchw2pm + GEMM
-    static const bool off = []() { const char* v = getenv("BF_DEBED_LAST_BWD"); return v && v[0] == '0'; }();
+    static const bool off = bf_knob("BF_DEBED_LAST_BWD", 1) == 0;
     if (off) return 1;
     const int GF = h * w / 16;
     dim3 grid(bf_cdiv(GF, (NT / 64) * DL_GPW), frames);
     hipStream_t st = (hipStream_t)stream;
-    static const int perm = []() { const char* v = getenv("BF_DL_PERM"); return v ? atoi(v) : 1; }();
+    static const int perm = bf_knob("BF_DL_PERM", 1);
     const double P = (double)frames * h * w;
     BfProfScope prof(st, "patch16", 2.0 * P * Ci * 16, P * (2.0 * Ci + 32.0 + 16.0 * Co * (dpred ? 1 : 2)));
 #define DLB(T) hipLaunchKernelGGL(debed_last_bwd_kernel<T>, grid, dim3(NT), 0, st, dpred, pred, y, coef, gscale, (const bf16*)wc, (bf16*)dpm, (bf16*)dact, Co, h, w, part, perm)
@@ -562,7 +562,7 @@ extern "C" int bf_debed_last_bwd(int dtype, const float* dpred, const float* pre
 extern "C" int bf_embed_first(int dtype, const float* x, const void* wc, void* patches, void* y0, int frames, int C0, int cin, int h2, int w2,
                               int Kp, float* stat_part, bf_stream_t stream) {
     BF_REQUIRE(x && wc && patches && y0, "bf_embed_first: null pointer");
-    static const bool off = []() { const char* v = getenv("BF_EMBED_FIRST"); return v && v[0] == '0'; }();
+    static const bool off = bf_knob("BF_EMBED_FIRST", 1) == 0;
     if (off) return 1;
     return debed_last_bwd_launch(dtype, x, nullptr, nullptr, nullptr, nullptr, wc, patches, y0, frames, C0, cin, h2, w2, Kp, stat_part, stream);
 }
