@@ -15,6 +15,7 @@
 // <= 168 VGPRs and 80 KB of LDS so that two workgroups share a CU.  bf16 only (the fp32 parity mode keeps the separate kernels).
 #include "gemm_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 int bf_gemm_pair_scaled(int M, int N, int K, const bf_operand* A, const bf_operand* B, const bf_epilogue* E, void* out2, const float* rowfac,
                         int rows_per_group, hipStream_t st);
@@ -331,11 +332,33 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
     if constexpr (GRP == 1) __builtin_amdgcn_s_barrier();          // one barrier behind waves 0-3 from here on
 
     int slot = 0;
-    for (int s = 0; s < nk; ++s) {
+    // epilogue operands that come by plain loads (the residual gradient rows, the frame's statistics and the norm weight): requested at
+    // the top of the LAST K-step, so that they travel under its fragment reads and MFMAs (the last step is a separate instance of the
+    // step body: nothing is carried through the loop in registers)
+    uint4 ad[9];
+    float mu[8], rs[8], ww[8];
+    const int fidx = fidx0 + GRP;
+    const long pbase = MODE == 0 ? (long)fidx * a.N + col0 : 0;
+    auto kstep = [&](auto last_tag, int s) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_tag)::value;
         // ======== load segment: fragments of step s; DMA of step s + 2 into the slot that held step s - 1 (every wave finished reading
         // it before the barrier that ended ITS load segment of s - 1); the counted wait for this wave's pieces of step s + 1
         const bf16* cA = reinterpret_cast<const bf16*>(smem + (size_t)slot * PSLOT_BYTES);
         const bf16* cB = reinterpret_cast<const bf16*>(smem + (size_t)slot * PSLOT_BYTES + PA_BYTES);
+        if constexpr (LAST) {
+            if (a.add) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) ad[i] = *reinterpret_cast<const uint4*>(a.add + (row0 + 16 * i) * a.ldx + col0);
+            }
+            if constexpr (MODE == 0) {
+                const float4 m0 = *reinterpret_cast<const float4*>(a.mean + pbase), m1 = *reinterpret_cast<const float4*>(a.mean + pbase + 4);
+                const float4 r0 = *reinterpret_cast<const float4*>(a.rstd + pbase), r1 = *reinterpret_cast<const float4*>(a.rstd + pbase + 4);
+                const float4 w0 = *reinterpret_cast<const float4*>(a.w + col0), w1 = *reinterpret_cast<const float4*>(a.w + col0 + 4);
+                mu[0] = m0.x; mu[1] = m0.y; mu[2] = m0.z; mu[3] = m0.w; mu[4] = m1.x; mu[5] = m1.y; mu[6] = m1.z; mu[7] = m1.w;
+                rs[0] = r0.x; rs[1] = r0.y; rs[2] = r0.z; rs[3] = r0.w; rs[4] = r1.x; rs[5] = r1.y; rs[6] = r1.z; rs[7] = r1.w;
+                ww[0] = w0.x; ww[1] = w0.y; ww[2] = w0.z; ww[3] = w0.w; ww[4] = w1.x; ww[5] = w1.y; ww[6] = w1.z; ww[7] = w1.w;
+            }
+        }
         bf16x8 fa[2][9], fb[2][2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -345,14 +368,15 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
             for (int j = 0; j < 2; ++j) fb[kk][j] = frag_bf16<true, PN>(cB, 32 * w4 + 16 * j, 32 * kk, lane);
         }
         const int sl2 = slot == 0 ? 2 : slot - 1;
-        if (s + 2 < nk) { issue(sl2); wait_vm<PG>(); }
-        else if (MODE == 0 && s == nk - 1) {        // last step: the x rows land under its MFMAs (waited for before the barrier that ends them)
+        if constexpr (!LAST) {
+            if (s + 2 < nk) { issue(sl2); wait_vm<PG>(); }
+            else wait_vm<0>();
+        } else if constexpr (MODE == 0) {           // last step: the x rows land under its MFMAs (waited for before the barrier that ends them)
             xslot = GRP == 0 ? sl2 : (slot == PNSLOT - 1 ? 0 : slot + 1);
             const unsigned dst = __builtin_amdgcn_readfirstlane(ring + (unsigned)xslot * (unsigned)PSLOT_BYTES + (unsigned)w4 * 1024u);
 #pragma unroll
             for (int t = 0; t < 9; ++t) glds16_s(sX + t * pieceX, voffX, dst + (unsigned)t * 4096u);
         }
-        else wait_vm<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the reads are done before the barrier: the slot may be refilled after it
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -364,10 +388,12 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (MODE == 0 && GRP == 1 && s == nk - 1) wait_vm<0>();    // this wave's x pieces: visible to the workgroup after the barrier below
+        if (LAST && MODE == 0 && GRP == 1) wait_vm<0>();           // this wave's x pieces: visible to the workgroup after the barrier below
         __builtin_amdgcn_s_barrier();
         slot = slot == PNSLOT - 1 ? 0 : slot + 1;
-    }
+    };
+    for (int s = 0; s + 1 < nk; ++s) kstep(std::false_type{}, s);
+    kstep(std::true_type{}, nk - 1);
     if constexpr (GRP == 0) {
         if constexpr (MODE == 0) wait_vm<0>();                      // ... and likewise for waves 0-3
         __builtin_amdgcn_s_barrier();                               // pairs with the extra barrier of waves 4-7: everybody's x pieces have landed
@@ -385,11 +411,6 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
             v[i][r] = __uint_as_float(sw[0]); v[i][4 + r] = __uint_as_float(sw[1]);
         }
     if constexpr (MODE == 1) {
-        uint4 ad[9];
-        if (a.add) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) ad[i] = *reinterpret_cast<const uint4*>(a.add + (row0 + 16 * i) * a.ldx + col0);
-        }
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             bf16x8 o;
@@ -411,28 +432,12 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
             }
         }
     } else {
-        const int fidx = fidx0 + GRP;
         if (a.fscale) {                              // dy of this frame carries its stochastic-depth factor
             const float m = a.fscale[fidx / a.fdiv];
 #pragma unroll
             for (int i = 0; i < 9; ++i)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[i][q] *= m;
-        }
-        const long pbase = (long)fidx * a.N + col0;
-        float mu[8], rs[8], ww[8];
-        {
-            const float4 m0 = *reinterpret_cast<const float4*>(a.mean + pbase), m1 = *reinterpret_cast<const float4*>(a.mean + pbase + 4);
-            const float4 r0 = *reinterpret_cast<const float4*>(a.rstd + pbase), r1 = *reinterpret_cast<const float4*>(a.rstd + pbase + 4);
-            const float4 w0 = *reinterpret_cast<const float4*>(a.w + col0), w1 = *reinterpret_cast<const float4*>(a.w + col0 + 4);
-            mu[0] = m0.x; mu[1] = m0.y; mu[2] = m0.z; mu[3] = m0.w; mu[4] = m1.x; mu[5] = m1.y; mu[6] = m1.z; mu[7] = m1.w;
-            rs[0] = r0.x; rs[1] = r0.y; rs[2] = r0.z; rs[3] = r0.w; rs[4] = r1.x; rs[5] = r1.y; rs[6] = r1.z; rs[7] = r1.w;
-            ww[0] = w0.x; ww[1] = w0.y; ww[2] = w0.z; ww[3] = w0.w; ww[4] = w1.x; ww[5] = w1.y; ww[6] = w1.z; ww[7] = w1.w;
-        }
-        uint4 ad[9];
-        if (a.add) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) ad[i] = *reinterpret_cast<const uint4*>(a.add + (row0 + 16 * i) * a.ldx + col0);
         }
         bf16x8 xr[9];                                // this lane's rows 16 i + li, columns 32 w4 + c8 .. + 7 of the staged frame
         {
