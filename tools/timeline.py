@@ -26,6 +26,9 @@ def short(n):
     m = re.search(r"stream_pp_kernel<(\d), (true|false)", n) or re.search(r"stream_pp_kernelILi(\d)ELb([01])", n)
     if m:
         return "stream_pp<%s>" % ("gelu2" if m.group(2) in ("true", "1") else {"0": "plain", "1": "add", "2": "dgelu"}[m.group(1)])
+    m = re.search(r"gemm_pair_kernel<(\d)>", n)
+    if m:
+        return "gemm_pair<inbwd>" if m.group(1) == "0" else "gemm_pair<add>"
     if "tokred_pp_reduce" in n:
         return "tokred_reduce"
     for key in ("tokred_pp_kernel", "tokred_reduce", "tokred_kernel", "gemm_inbwd_frames", "attn_fwd_axial_mfma", "attn_bwd_mfma", "attn_fwd_mfma", "in_bwd_slice", "in_stats_slice", "in_stats_merge", "in_slice_sum", "in_bwd_kernel",
