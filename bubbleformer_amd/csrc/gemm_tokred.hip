@@ -249,6 +249,84 @@ __global__ void __launch_bounds__(256) tokred_pp_reduce_kernel(const float* __re
     }
 }
 
+// ================================================================================================ narrow form: Kin = 16 (the first embed stage's weight gradient)
+// dW[C][16] = sum_p dy[p][C] * x[p][16] over ~1.2 M pixel rows (HMLPEmbed stage 0, layers/patching.py:36-44: Conv2d k2s2 on 4 fields = 16
+// patch values; autograd of it).  Six MFMAs per 32 pixels against 7 KB of operands: a pure stream.  On the 128 x 128 split-K tile kernel
+// 7/8 of the weight tile was padding and the launch took 287 us at the END of the step, when nothing else is left to overlap with.  Here
+// every wave is its own pipeline: it pulls 32-pixel tiles (dy rows and patch rows are contiguous in memory: 6 + 1 DMA pieces, lane-linear
+// LDS image) into a private two-tile ring, reads them back transposed (ds_read_b64_tr_b16: the reduction index of both operands is the
+// row) and keeps dW[C][16] in C/16 accumulator tiles.  No barrier in the loop; partial results are summed per workgroup through LDS, written
+// to a slab row per workgroup and added in workgroup order by a tiny second kernel: bit-reproducible, no float atomics.
+constexpr int NW_TILE = 32;                         // pixels per tile
+template <int CT>                                   // CT = C / 16 column tiles of dy (6 for the 96-channel stage)
+__global__ void __launch_bounds__(256) tokred_narrow_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, long tiles_total, float* __restrict__ slab) {
+    constexpr int C = 16 * CT, DYB = NW_TILE * C * 2, XB = NW_TILE * 16 * 2, TB_ = DYB + XB;      // bytes of one staged tile: dy rows | patch rows
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long nwaves = (long)gridDim.x * 4, w = (long)blockIdx.x * 4 + wave;
+    const long t_beg = tiles_total * w / nwaves, t_end = tiles_total * (w + 1) / nwaves;
+    char* mine = smem + (size_t)wave * 2 * TB_;
+    const unsigned lds0 = lds_addr(mine);
+    // DMA: a tile's dy rows are NW_TILE * C * 2 contiguous bytes (DYB / 1024 pieces), its patch rows 1 KB (one piece)
+    auto issue = [&](long t, int slot) {
+        const char* gd = reinterpret_cast<const char*>(dy) + t * DYB + lane * 16;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)slot * (unsigned)TB_);
+#pragma unroll
+        for (int pce = 0; pce < DYB / 1024; ++pce) glds16(gd + pce * 1024, dst + (unsigned)pce * 1024u);
+        glds16(reinterpret_cast<const char*>(x) + t * XB + lane * 16, dst + (unsigned)DYB);
+    };
+    constexpr int PCS = DYB / 1024 + 1;
+    f32x4 acc[CT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // transposing reads: lane 16 g + 4 q + p supplies row 8 g + q (lo) / 8 g + 4 + q (hi), columns c0 + 4 p .. + 3
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const unsigned offD = (unsigned)((8 * g + q) * (C * 2) + 8 * pp), offX = (unsigned)(DYB + (8 * g + q) * 32 + 8 * pp);
+    auto trf = [&](unsigned addr, unsigned hi_off) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(uintptr_t)addr);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(uintptr_t)(addr + hi_off));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, r);
+    };
+    if (t_beg < t_end) issue(t_beg, 0);
+    int slot = 0;
+    for (long t = t_beg; t < t_end; ++t) {
+        if (t + 1 < t_end) { issue(t + 1, slot ^ 1); wait_vm<PCS>(); } else wait_vm<0>();
+        const unsigned tb = lds0 + (unsigned)slot * (unsigned)TB_;
+        const bf16x8 fx = trf(tb + offX, 4 * 32);
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            const bf16x8 fd = trf(tb + offD + (unsigned)(i * 32), 4 * C * 2);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx, fd, acc[i], 0, 0, 0);      // acc[i][r]: dW[16 i + (lane & 15)][4 (lane >> 4) + r]
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads of this slot are done before the next iteration's DMA may refill it
+        slot ^= 1;
+    }
+    // ---- the workgroup's four partial results -> one slab row [C][16], summed in wave order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);                // [4 waves][C][16]
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+        *reinterpret_cast<float4*>(red + ((size_t)wave * C + 16 * i + (lane & 15)) * 16 + 4 * (lane >> 4)) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+    __syncthreads();
+    for (int e = tid; e < C * 16; e += 256) {
+        float v = red[e];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) v += red[(size_t)k * C * 16 + e];
+        slab[(size_t)blockIdx.x * C * 16 + e] = v;
+    }
+}
+// out[C][ldo] (+)= sum over the workgroup rows of the slab, in workgroup order
+__global__ void __launch_bounds__(256) tokred_narrow_reduce_kernel(const float* __restrict__ slab, int rows, int C, float* __restrict__ out, int ldo, int accumulate) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= C * 16) return;
+    float v = 0.f;
+    for (int r = 0; r < rows; ++r) v += slab[(size_t)r * C * 16 + e];
+    float* o = out + (size_t)(e >> 4) * ldo + (e & 15);
+    *o = accumulate ? *o + v : v;
+}
+
 // ================================================================================================ 128 x 128 kernel (other shapes)
 constexpr int TB = 128;            // output tile edge
 constexpr int BK = 64;             // tokens per K-step
@@ -484,5 +562,30 @@ extern "C" int bf_gemm_tokred(int dtype, int Nout, int Kin, int64_t M, const voi
         hipLaunchKernelGGL(tokred_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, cslab, ns, n, Nout, out, colsum, accumulate);
         BF_CHECK_LAUNCH();
     }
+    return 0;
+}
+
+// dW[C][16 of ldo] (+)= dy[P][C]^T x[P][16]: both operands dense row-major bf16 (ldy == C, ldx == 16), P a multiple of 32.  Library-internal
+// (the first embed stage's weight gradient); 0 = handled, 1 = shape not covered.  ws: 256 * C * 16 floats.
+int bf_tokred_narrow(int dtype, int C, int64_t P, const void* dy, const void* x, float* out, int ldo, int accumulate, float* ws, int64_t ws_floats,
+                     hipStream_t st) {
+    static const bool off = bf_knob("BF_TOKRED_NARROW", 1) == 0;
+    if (off || dtype != BF_DTYPE_BF16 || (C != 96 && C != 64 && C != 32) || P <= 0 || P % NW_TILE || ldo < 16) return 1;
+    if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)ws) & 15) return 1;
+    const int wgs = 256;
+    if (ws_floats < (int64_t)wgs * C * 16) return 1;
+    const long tiles = P / NW_TILE;
+    BfProfScope prof(st, "tokred_narrow_kernel", 2.0 * C * 16 * (double)P, (double)P * (C + 16) * 2.0);
+#define BF_NARROW_GO(CTV)                                                                                                               \
+    do {                                                                                                                                \
+        constexpr int lds_bytes = 4 * 2 * (NW_TILE * 16 * CTV * 2 + NW_TILE * 16 * 2);                                                  \
+        static_assert(lds_bytes >= 4 * 16 * CTV * 16 * 4, "the reduction buffer aliases the tile rings");                               \
+        hipLaunchKernelGGL(tokred_narrow_kernel<CTV>, dim3(wgs), dim3(256), lds_bytes, st, (const bf16*)dy, (const bf16*)x, tiles, ws); \
+    } while (0)
+    if (C == 96) BF_NARROW_GO(6); else if (C == 64) BF_NARROW_GO(4); else BF_NARROW_GO(2);
+#undef BF_NARROW_GO
+    BF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(tokred_narrow_reduce_kernel, dim3(bf_cdiv(C * 16, 256)), dim3(256), 0, st, ws, wgs, C, out, ldo, accumulate);
+    BF_CHECK_LAUNCH();
     return 0;
 }

@@ -1241,11 +1241,16 @@ extern "C" int bf_embed_bwd(const bf_dims* dims, const bf_embed_params* p, const
     {   // stage 0
         TRY(fk.join());
         if (dx_in) TRY(fk.begin(&ss)); else ss = st;      // nothing left to overlap with when the input needs no gradient
-        ZERO_ON(ss, sc.wg, (size_t)sv.C[0] * sv.Kp * 4);
-        bf_operand A = op_plain(dy, sv.C[0], BF_LAY_XC);
-        bf_operand Bo = op_plain(sv.patches, sv.Kp, BF_LAY_XC);
-        bf_epilogue e = epi_atomic(sc.wg, sv.Kp);
-        TRY(bf_gemm(d.dtype, sv.C[0], sv.Kp, (int)sv.P[0], &A, &Bo, &e, splitk_for(sv.C[0], sv.Kp, sv.P[0]), ss));
+        // dWprep[co][k] = sum_p dy[p][co] * patch[p][k]: a 16-wide stream where it applies (the LAST kernel of the step: nothing to hide behind)
+        const int nrc = sv.Kp == 16 ? bf_tokred_narrow(d.dtype, sv.C[0], sv.P[0], dy, sv.patches, sc.wg, sv.Kp, 0, sc.tokred_ws, sc.tokred_floats, ss) : 1;
+        if (nrc < 0) return nrc;
+        if (nrc == 1) {
+            ZERO_ON(ss, sc.wg, (size_t)sv.C[0] * sv.Kp * 4);
+            bf_operand A = op_plain(dy, sv.C[0], BF_LAY_XC);
+            bf_operand Bo = op_plain(sv.patches, sv.Kp, BF_LAY_XC);
+            bf_epilogue e = epi_atomic(sc.wg, sv.Kp);
+            TRY(bf_gemm(d.dtype, sv.C[0], sv.Kp, (int)sv.P[0], &A, &Bo, &e, splitk_for(sv.C[0], sv.Kp, sv.P[0]), ss));
+        }
         TRY(bf_wgrad_unprep(0, sc.wg, g->conv_w[0], sv.C[0], 4 * d.cin, sv.Kp, 0, ss));
         if (dx_in) {
             void* dpatch = sc.t1;
