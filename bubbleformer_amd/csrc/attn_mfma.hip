@@ -153,54 +153,8 @@ __device__ __forceinline__ void affine_frag(const float (&xh)[KS][8], const floa
 }
 
 // scores^T for all (key block, query block) pairs -> softmax over keys -> P (and the rescaled A) in registers.
-// sc[jb][ib][r]: lane (i = 16*ib + (l & 15)) x key j = 16*jb + 4*(l >> 4) + r
-template <int NB, int KS>
-__device__ __forceinline__ void scores_softmax(const bf16x8 (&kf)[NB][KS], const bf16x8 (&qf)[NB][KS], const float* emb, int emb_ld,
-                                               const float* hscale, int head, int L, int lane, float (&P)[NB][NB][4], float (&A)[NB][NB][4]) {
-    const int g = lane >> 4, i16 = lane & 15;
-#pragma unroll
-    for (int jb = 0; jb < NB; ++jb)
-#pragma unroll
-        for (int ib = 0; ib < NB; ++ib) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jb][s], qf[ib][s], acc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * ib + i16, j = 16 * jb + 4 * g + r;
-                float v = acc[r];
-                if (emb) v += emb[t5b(i - j) * emb_ld + head];
-                P[jb][ib][r] = j < L ? v : -INFINITY;
-            }
-        }
-    const float invL = 1.0f / (float)L;
-    const float hs = hscale ? hscale[head] : 1.f;
-#pragma unroll
-    for (int ib = 0; ib < NB; ++ib) {
-        float m = -INFINITY;
-#pragma unroll
-        for (int jb = 0; jb < NB; ++jb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) m = fmaxf(m, P[jb][ib][r]);
-        m = quad_max(m);
-        float sum = 0.f;
-#pragma unroll
-        for (int jb = 0; jb < NB; ++jb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const float e = __expf(P[jb][ib][r] - m); P[jb][ib][r] = e; sum += e; }
-        const float inv = 1.f / quad_sum(sum);
-#pragma unroll
-        for (int jb = 0; jb < NB; ++jb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int j = 16 * jb + 4 * g + r;
-                const float pr = P[jb][ib][r] * inv;
-                P[jb][ib][r] = pr;
-                A[jb][ib][r] = j < L ? (hscale ? invL + (pr - invL) * hs : pr) : 0.f;
-            }
-    }
-}
-// The same with everything lane-constant precomputed by the caller (the backward runs it per problem in a VALU-bound loop): the T5
+// sc[jb][ib][r]: lane (i = 16*ib + (l & 15)) x key j = 16*jb + 4*(l >> 4) + r.  Everything lane-constant is precomputed by the caller
+// (the kernels run this per problem in VALU-bound loops): the T5
 // bucket offsets eidx of this lane's (query, key) pairs, the key mask as an additive 0 / -inf, the (query, key) validity mask as a
 // 0 / 1 factor.  emb is an LDS table [32][16] (zeros when the block has no bias table): no branch per element.
 template <int NB, int KS>
@@ -242,6 +196,22 @@ __device__ __forceinline__ void scores_softmax_pre(const bf16x8 (&kf)[NB][KS], c
                 A[jb][ib][r] = (hscale ? invL + (pr - invL) * hs : pr) * mk[jb][ib][r];
             }
     }
+}
+// the lane constants scores_softmax_pre takes, for sequences of length L
+template <int NB>
+__device__ __forceinline__ void lane_masks(int L, int lane, float (&mk)[NB][NB][4], float (&mneg)[NB][NB][4], int (&eidx)[NB][NB][4]) {
+    const int gq = lane >> 4, i16 = lane & 15;
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+        for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * ib + i16, j = 16 * jb + 4 * gq + r;
+                mk[jb][ib][r] = (i < L && j < L) ? 1.f : 0.f;
+                mneg[jb][ib][r] = j < L ? 0.f : -INFINITY;
+                eidx[jb][ib][r] = t5b(i - j) * 16;
+            }
 }
 // registers (key blocks x 4) of one query block -> the B operand whose k-slot (g, jj) is key 4g+jj / 16+4g+jj-4
 template <int NB>
@@ -345,6 +315,9 @@ __global__ void __launch_bounds__(256) attn_fwd_mfma(const bf16* __restrict__ qk
     FwdRows<NB, KS> cur, nxt;
     Prob at = locate(g, heads, pr < nprob ? pr : 0), at_next = at;
     if (pr < nprob) load_fwd_rows<NB, KS>(cur, qkv, g, heads, at, lane);
+    float mk[NB][NB][4], mneg[NB][NB][4];
+    int eidx[NB][NB][4];
+    lane_masks<NB>(L, lane, mk, mneg, eidx);
     for (; pr < nprob; pr += pstep) {
         const int head = at.head;
         const long tok0 = at.tok0;
@@ -389,7 +362,7 @@ __global__ void __launch_bounds__(256) attn_fwd_mfma(const bf16* __restrict__ qk
             }
         }
         float P[NB][NB][4], A[NB][NB][4];
-        scores_softmax<NB, KS>(kf, qf, p.emb ? s_emb : nullptr, 16, p.hscale ? s_hsc : nullptr, head, L, lane, P, A);
+        scores_softmax_pre<NB, KS>(kf, qf, s_emb, eidx, mneg, mk, p.hscale ? s_hsc : nullptr, head, L, P, A);
         wsync();   // V tile visible to the wave
 #pragma unroll
         for (int ib = 0; ib < NB; ++ib) {
@@ -456,6 +429,10 @@ __global__ void __launch_bounds__(64 * WPB) attn_fwd_axial_mfma(const bf16* __re
     const int gq = lane >> 4, i16 = lane & 15;
     const Geo gW{(long)frames * h, w, 1, w, 0, 1}, gH{(long)frames * w, h, w, S, 1, w};
     const int RW = (h + wpb - 1) / wpb, RH = (w + wpb - 1) / wpb;         // rounds per phase (uniform over the waves: barriers)
+    float mkW[NB][NB][4], mnegW[NB][NB][4], mkH[NB][NB][4], mnegH[NB][NB][4];      // lane constants of the two passes (sequence lengths w and h)
+    int eidxW[NB][NB][4], eidxH[NB][NB][4];
+    lane_masks<NB>(w, lane, mkW, mnegW, eidxW);
+    lane_masks<NB>(h, lane, mkH, mnegH, eidxH);
     const long ntile = (long)frames * heads;
     for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
         const int frame = (int)((unsigned)tile / (unsigned)heads), head = (int)((unsigned)tile - (unsigned)frame * (unsigned)heads);      // (< 2^31 tiles: host-checked)
@@ -495,7 +472,8 @@ __global__ void __launch_bounds__(64 * WPB) attn_fwd_axial_mfma(const bf16* __re
                     }
                 }
                 float P[NB][NB][4], A[NB][NB][4];
-                scores_softmax<NB, KS>(kf, qf, p.emb ? s_emb : nullptr, 16, isH ? (hscale_y ? s_hsy : nullptr) : (p.hscale ? s_hsx : nullptr), head, L, lane, P, A);
+                if (isH) scores_softmax_pre<NB, KS>(kf, qf, s_emb, eidxH, mnegH, mkH, hscale_y ? s_hsy : nullptr, head, L, P, A);
+                else scores_softmax_pre<NB, KS>(kf, qf, s_emb, eidxW, mnegW, mkW, p.hscale ? s_hsx : nullptr, head, L, P, A);
                 wsync();   // V tile visible to the wave
                 const bf16x8 pa = pack_keys<NB>(A, 0);
 #pragma unroll
@@ -688,17 +666,7 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
     // lane-constant masks and T5 bucket offsets of this lane's (query, key) pairs: once, not per problem
     float mk[NB][NB][4], mneg[NB][NB][4];
     int eidx[NB][NB][4];
-#pragma unroll
-    for (int jb = 0; jb < NB; ++jb)
-#pragma unroll
-        for (int ib = 0; ib < NB; ++ib)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * ib + i16, j = 16 * jb + 4 * gq + r;
-                mk[jb][ib][r] = (i < L && j < L) ? 1.f : 0.f;
-                mneg[jb][ib][r] = j < L ? 0.f : -INFINITY;
-                eidx[jb][ib][r] = t5b(i - j) * 16;
-            }
+    lane_masks<NB>(L, lane, mk, mneg, eidx);
     for (; pr < nprob; pr += pstep) {
         const int head = at.head;
         const long tok0 = at.tok0;
