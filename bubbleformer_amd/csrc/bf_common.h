@@ -52,9 +52,9 @@ int bf_in_stats_apply(int dtype, const void* x, int frames, int S, int C, const 
 int bf_wprep_multi(int dtype, int n, const int* mode, const float* const* src, void* const* dst, const int* R, const int* K, const int* Kp, hipStream_t st);
 int bf_frame_scale(int dtype, const void* z, const float* m, int fdiv, void* out, long nrows, int S, int C, hipStream_t st);
 
-// narrow weight-gradient stream dW[C][16] = dy^T x (gemm_tokred.hip; internal): 0 = handled, 1 = shape not covered
-int bf_tokred_narrow(int dtype, int C, int64_t P, const void* dy, const void* x, float* out, int ldo, int accumulate, float* ws, int64_t ws_floats,
-                     hipStream_t st);
+// narrow weight-gradient stream dW[C][16] = act(wide)^T narrow, or its transpose (gemm_tokred.hip; internal): 0 = handled, 1 = shape not covered
+int bf_tokred_narrow(int dtype, int C, int64_t P, const void* wide, const void* narrow, float* out, int ldo, int accumulate, int transposed,
+                     const float* sc, const float* sh, int64_t rows_per_frame, float* ws, int64_t ws_floats, hipStream_t st);
 // frame-pair data-gradient GEMM with a second, row-scaled output (gemm_frame.hip; internal): 0 = handled, 1 = shape not covered
 int bf_gemm_pair_scaled(int M, int N, int K, const bf_operand* A, const bf_operand* B, const bf_epilogue* E, void* out2, const float* rowfac,
                         int rows_per_group, hipStream_t st);

@@ -258,8 +258,12 @@ __global__ void __launch_bounds__(256) tokred_pp_reduce_kernel(const float* __re
 // row) and keeps dW[C][16] in C/16 accumulator tiles.  No barrier in the loop; partial results are summed per workgroup through LDS, written
 // to a slab row per workgroup and added in workgroup order by a tiny second kernel: bit-reproducible, no float atomics.
 constexpr int NW_TILE = 32;                         // pixels per tile
-template <int CT>                                   // CT = C / 16 column tiles of dy (6 for the 96-channel stage)
-__global__ void __launch_bounds__(256) tokred_narrow_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, long tiles_total, float* __restrict__ slab) {
+// PRO: the wide operand is an activation map that enters as gelu(y * sc[frame][c] + sh[frame][c]) (the InstanceNorm + GELU in front of
+// the last debed stage, layers/patching.py:92-104: that stage's weight gradient, with the roles of the operands swapped) -- applied to the
+// fragments in registers, 8 pixels of one channel per lane, the frame's scale / shift reloaded only when a wave's tiles cross a frame.
+template <int CT, bool PRO>                         // CT = C / 16 column tiles of dy (6 for the 96-channel stages)
+__global__ void __launch_bounds__(256) tokred_narrow_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, long tiles_total, float* __restrict__ slab,
+                                                          const float* __restrict__ psc, const float* __restrict__ psh, int tiles_per_frame) {
     constexpr int C = 16 * CT, DYB = NW_TILE * C * 2, XB = NW_TILE * 16 * 2, TB_ = DYB + XB;      // bytes of one staged tile: dy rows | patch rows
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -291,13 +295,27 @@ __global__ void __launch_bounds__(256) tokred_narrow_kernel(const bf16* __restri
     };
     if (t_beg < t_end) issue(t_beg, 0);
     int slot = 0;
+    float scv[CT], shv[CT];
+    long frame = -1;
     for (long t = t_beg; t < t_end; ++t) {
+        if constexpr (PRO) {
+            const long f = t / tiles_per_frame;          // wave-uniform
+            if (f != frame) {
+                frame = f;
+#pragma unroll
+                for (int i = 0; i < CT; ++i) { scv[i] = psc[f * C + 16 * i + (lane & 15)]; shv[i] = psh ? psh[f * C + 16 * i + (lane & 15)] : 0.f; }
+            }
+        }
         if (t + 1 < t_end) { issue(t + 1, slot ^ 1); wait_vm<PCS>(); } else wait_vm<0>();
         const unsigned tb = lds0 + (unsigned)slot * (unsigned)TB_;
         const bf16x8 fx = trf(tb + offX, 4 * 32);
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
-            const bf16x8 fd = trf(tb + offD + (unsigned)(i * 32), 4 * C * 2);
+            bf16x8 fd = trf(tb + offD + (unsigned)(i * 32), 4 * C * 2);
+            if constexpr (PRO) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fd[j] = (bf16)gelu_fast(fmaf((float)fd[j], scv[i], shv[i]));
+            }
             acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx, fd, acc[i], 0, 0, 0);      // acc[i][r]: dW[16 i + (lane & 15)][4 (lane >> 4) + r]
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads of this slot are done before the next iteration's DMA may refill it
@@ -318,12 +336,13 @@ __global__ void __launch_bounds__(256) tokred_narrow_kernel(const bf16* __restri
     }
 }
 // out[C][ldo] (+)= sum over the workgroup rows of the slab, in workgroup order
-__global__ void __launch_bounds__(256) tokred_narrow_reduce_kernel(const float* __restrict__ slab, int rows, int C, float* __restrict__ out, int ldo, int accumulate) {
+__global__ void __launch_bounds__(256) tokred_narrow_reduce_kernel(const float* __restrict__ slab, int rows, int C, float* __restrict__ out, int ldo, int accumulate,
+                                                                   int transposed) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= C * 16) return;
     float v = 0.f;
     for (int r = 0; r < rows; ++r) v += slab[(size_t)r * C * 16 + e];
-    float* o = out + (size_t)(e >> 4) * ldo + (e & 15);
+    float* o = transposed ? out + (size_t)(e & 15) * ldo + (e >> 4) : out + (size_t)(e >> 4) * ldo + (e & 15);      // transposed: out[16][C]
     *o = accumulate ? *o + v : v;
 }
 
@@ -565,27 +584,32 @@ extern "C" int bf_gemm_tokred(int dtype, int Nout, int Kin, int64_t M, const voi
     return 0;
 }
 
-// dW[C][16 of ldo] (+)= dy[P][C]^T x[P][16]: both operands dense row-major bf16 (ldy == C, ldx == 16), P a multiple of 32.  Library-internal
-// (the first embed stage's weight gradient); 0 = handled, 1 = shape not covered.  ws: 256 * C * 16 floats.
-int bf_tokred_narrow(int dtype, int C, int64_t P, const void* dy, const void* x, float* out, int ldo, int accumulate, float* ws, int64_t ws_floats,
-                     hipStream_t st) {
+// dW[C][16 of ldo] (+)= act(wide[P][C])^T narrow[P][16] -- or its transpose out[16][C of ldo] -- both operands dense row-major bf16
+// (row lengths C and 16), P a multiple of 32.  act = identity, or gelu(wide * sc[frame][c] + sh[frame][c]) with rows_per_frame rows per
+// frame (a multiple of 32).  Library-internal (the first embed / last debed stage's weight gradient); 0 = handled, 1 = shape not covered.
+// ws: 256 * C * 16 floats.
+int bf_tokred_narrow(int dtype, int C, int64_t P, const void* wide, const void* narrow, float* out, int ldo, int accumulate, int transposed,
+                     const float* sc, const float* sh, int64_t rows_per_frame, float* ws, int64_t ws_floats, hipStream_t st) {
     static const bool off = bf_knob("BF_TOKRED_NARROW", 1) == 0;
-    if (off || dtype != BF_DTYPE_BF16 || (C != 96 && C != 64 && C != 32) || P <= 0 || P % NW_TILE || ldo < 16) return 1;
-    if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)ws) & 15) return 1;
+    if (off || dtype != BF_DTYPE_BF16 || (C != 96 && C != 64 && C != 32) || P <= 0 || P % NW_TILE || ldo < (transposed ? C : 16)) return 1;
+    if (((uintptr_t)wide | (uintptr_t)narrow | (uintptr_t)ws) & 15) return 1;
+    if (sc && (rows_per_frame <= 0 || rows_per_frame % NW_TILE)) return 1;
     const int wgs = 256;
     if (ws_floats < (int64_t)wgs * C * 16) return 1;
     const long tiles = P / NW_TILE;
-    BfProfScope prof(st, "tokred_narrow_kernel", 2.0 * C * 16 * (double)P, (double)P * (C + 16) * 2.0);
+    const int tpf = sc ? (int)(rows_per_frame / NW_TILE) : 1;
+    BfProfScope prof(st, sc ? "tokred_narrow_kernel<gelu>" : "tokred_narrow_kernel", 2.0 * C * 16 * (double)P, (double)P * (C + 16) * 2.0);
 #define BF_NARROW_GO(CTV)                                                                                                               \
     do {                                                                                                                                \
         constexpr int lds_bytes = 4 * 2 * (NW_TILE * 16 * CTV * 2 + NW_TILE * 16 * 2);                                                  \
         static_assert(lds_bytes >= 4 * 16 * CTV * 16 * 4, "the reduction buffer aliases the tile rings");                               \
-        hipLaunchKernelGGL(tokred_narrow_kernel<CTV>, dim3(wgs), dim3(256), lds_bytes, st, (const bf16*)dy, (const bf16*)x, tiles, ws); \
+        if (sc) hipLaunchKernelGGL((tokred_narrow_kernel<CTV, true>), dim3(wgs), dim3(256), lds_bytes, st, (const bf16*)wide, (const bf16*)narrow, tiles, ws, sc, sh, tpf); \
+        else hipLaunchKernelGGL((tokred_narrow_kernel<CTV, false>), dim3(wgs), dim3(256), lds_bytes, st, (const bf16*)wide, (const bf16*)narrow, tiles, ws, sc, sh, tpf); \
     } while (0)
     if (C == 96) BF_NARROW_GO(6); else if (C == 64) BF_NARROW_GO(4); else BF_NARROW_GO(2);
 #undef BF_NARROW_GO
     BF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(tokred_narrow_reduce_kernel, dim3(bf_cdiv(C * 16, 256)), dim3(256), 0, st, ws, wgs, C, out, ldo, accumulate);
+    hipLaunchKernelGGL(tokred_narrow_reduce_kernel, dim3(bf_cdiv(C * 16, 256)), dim3(256), 0, st, ws, wgs, C, out, ldo, accumulate, transposed);
     BF_CHECK_LAUNCH();
     return 0;
 }

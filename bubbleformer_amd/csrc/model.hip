@@ -1242,7 +1242,7 @@ extern "C" int bf_embed_bwd(const bf_dims* dims, const bf_embed_params* p, const
         TRY(fk.join());
         if (dx_in) TRY(fk.begin(&ss)); else ss = st;      // nothing left to overlap with when the input needs no gradient
         // dWprep[co][k] = sum_p dy[p][co] * patch[p][k]: a 16-wide stream where it applies (the LAST kernel of the step: nothing to hide behind)
-        const int nrc = sv.Kp == 16 ? bf_tokred_narrow(d.dtype, sv.C[0], sv.P[0], dy, sv.patches, sc.wg, sv.Kp, 0, sc.tokred_ws, sc.tokred_floats, ss) : 1;
+        const int nrc = sv.Kp == 16 ? bf_tokred_narrow(d.dtype, sv.C[0], sv.P[0], dy, sv.patches, sc.wg, sv.Kp, 0, 0, nullptr, nullptr, 0, sc.tokred_ws, sc.tokred_floats, ss) : 1;
         if (nrc < 0) return nrc;
         if (nrc == 1) {
             ZERO_ON(ss, sc.wg, (size_t)sv.C[0] * sv.Kp * 4);
@@ -1345,8 +1345,13 @@ extern "C" int bf_debed_bwd(const bf_dims* dims, const bf_debed_params* p, const
             if (rc < 0) return rc;
             if (rc == 1) TRY(bf_nchw2pm(d.dtype, dpred, pred, target, sv.coef, loss_scale, dpm, (int)d.F, co, sv.gh[i], sv.gw[i], sv.Np, st));
             TRY(fk.begin(&ss));
-            ZERO_ON(ss, sc.wg, (size_t)sv.Np * cin * 4);
-            {   // wg[n][ci] = sum_p dpm[p][n] * act[p][ci]
+            // wg[n][ci] = sum_p dpm[p][n] * act[p][ci]: the 16-wide stream (transposed output, InstanceNorm + GELU applied to the map's
+            // fragments in registers) where it applies
+            const int nrc = (sv.Np == 16 && i > 0) ? bf_tokred_narrow(d.dtype, cin, sv.Pin[i], ain, dpm, sc.wg, cin, 0, 1, sv.sc[i - 1], sv.sh[i - 1], rpf,
+                                                                      sc.tokred_ws, sc.tokred_floats, ss) : 1;
+            if (nrc < 0) return nrc;
+            if (nrc == 1) {
+                ZERO_ON(ss, sc.wg, (size_t)sv.Np * cin * 4);
                 bf_operand A = op_plain(dpm, sv.Np, BF_LAY_XC);
                 bf_operand Bo = op_plain(ain, cin, BF_LAY_XC);
                 if (i > 0) op_affine(Bo, BF_PRO_AFFINE_GELU, sv.sc[i - 1], sv.sh[i - 1], rpf, cin);
