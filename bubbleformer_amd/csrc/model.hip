@@ -229,6 +229,19 @@ __global__ void outproj_finalize_kernel(const float* __restrict__ G, const float
                                         float* __restrict__ dlo, float* __restrict__ dhi, int E) {
     __shared__ float red[4];
     __shared__ float s_dmc, s_alpha;
+    if ((int)blockIdx.x >= E) {      // extra workgroups (feature scaling only): dnb[k] += sum_n dmc[n] * W[n][k], 64 columns each -- dmc[n] =
+        // csum[n] * gamma[n] * (lo[n] - hi[n]) needs nothing the row workgroups compute, and one writer per column replaces E x E float
+        // atomics on E addresses (the launch took 14 us with them; and norm2.bias's gradient was order-dependent)
+        __shared__ float part[4][64];
+        const int k = ((int)blockIdx.x - E) * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+        float a = 0.f;
+        if (k < E)
+            for (int n = q; n < E; n += 4) a = fmaf(csum[n] * gamma[n] * (lo[n] - hi[n]), W[(long)n * E + k], a);
+        part[q][threadIdx.x & 63] = a;
+        __syncthreads();
+        if (q == 0 && k < E) dnb[k] += (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        return;
+    }
     const int n = blockIdx.x;
     float acc = 0.f;
     for (int k = threadIdx.x; k < E; k += blockDim.x) acc += W[(long)n * E + k] * G[(long)n * E + k];
@@ -256,7 +269,7 @@ __global__ void outproj_finalize_kernel(const float* __restrict__ G, const float
     const float dmc = s_dmc, alpha = s_alpha;
     for (int k = threadIdx.x; k < E; k += blockDim.x) {
         float v = alpha * G[(long)n * E + k];
-        if (lo) { v += dmc * nb[k]; atomicAdd(dnb + k, dmc * W[(long)n * E + k]); }
+        if (lo) v += dmc * nb[k];
         dW[(long)n * E + k] += v;
     }
 }
@@ -556,8 +569,8 @@ int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on,
             e.colsum = sc.csum;                  // dbeta = colsum(dout), fused into the same pass over dout
             TRY(bf_gemm(d.dtype, d.E, d.E, (int)d.N, &A, &Bo, &e, splitk_for(d.E, d.E, d.N), ss));
         }
-        hipLaunchKernelGGL(outproj_finalize_kernel, dim3(d.E), dim3(256), 0, ss, sc.G, sc.csum, W, bias, nb, gamma, lo, hi, mc, dW, dbias, dnb,
-                           dgamma, dlo, dhi, d.E);
+        hipLaunchKernelGGL(outproj_finalize_kernel, dim3(d.E + (lo ? bf_cdiv(d.E, 64) : 0)), dim3(256), 0, ss, sc.G, sc.csum, W, bias, nb, gamma, lo, hi, mc,
+                           dW, dbias, dnb, dgamma, dlo, dhi, d.E);
         BF_CHECK_LAUNCH();
         return 0;
     }));
