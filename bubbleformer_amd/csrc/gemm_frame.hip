@@ -270,6 +270,7 @@ struct PairArgs {
     const float* mean; const float* rstd; const float* w; float* ws;
     const float* fscale; int fdiv;
     bf16* out2;                         // MODE 1, optional: out2 = out * fscale[row / fdiv] (the stochastic-depth-scaled copy the next kernels read)
+    int whole;                          // MODE 0: 1 = the tile is ONE frame of 288 tokens (24 x 12 grids: BASELINE configs[3]) instead of two of 144
 };
 
 // LDS-DMA with a wave-uniform 64-bit base in SGPRs and a per-lane 32-bit byte offset: one offset register serves every piece of a wave
@@ -337,7 +338,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
     // step body: nothing is carried through the loop in registers)
     uint4 ad[9];
     float mu[8], rs[8], ww[8];
-    const int fidx = fidx0 + GRP;
+    const int fidx = (MODE == 0 && a.whole) ? fidx0 : fidx0 + GRP;
     const long pbase = MODE == 0 ? (long)fidx * a.N + col0 : 0;
     auto kstep = [&](auto last_tag, int s) __attribute__((always_inline)) {
         constexpr bool LAST = decltype(last_tag)::value;
@@ -460,12 +461,26 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) { s1[q] = row16_sum(s1[q]); s2[q] = row16_sum(s2[q]); }
-        if (li == 0 && a.ws) {                       // per-frame partials for the affine-parameter gradients (param_reduce.h)
+        if (a.whole) {                               // one 288-token frame per tile: the two wave groups hold its two halves -- exchange the
+            // half sums through the other ring slot (every slot is free here; the x rows sit in xslot), group 0's first for both: same bits
+            const int cslot = slot == 0 ? PNSLOT - 1 : slot - 1;      // the last step's operand slot: neither group's x slot
+            float* ex = reinterpret_cast<float*>(smem + (size_t)cslot * PSLOT_BYTES) + ((GRP * 4 + w4) * 4 + lg) * 16;
+            if (li == 0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { ex[q] = s1[q]; ex[8 + q] = s2[q]; }
+            }
+            __syncthreads();
+            const float* e0 = reinterpret_cast<const float*>(smem + (size_t)cslot * PSLOT_BYTES) + ((0 * 4 + w4) * 4 + lg) * 16;
+            const float* e1 = e0 + 4 * 4 * 16;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { s1[q] = e0[q] + e1[q]; s2[q] = e0[8 + q] + e1[8 + q]; }
+        }
+        if (li == 0 && a.ws && (GRP == 0 || !a.whole)) {      // per-frame partials for the affine-parameter gradients (param_reduce.h)
             float* wp = a.ws + pbase * 2;
 #pragma unroll
             for (int q = 0; q < 8; q += 2) *reinterpret_cast<float4*>(wp + 2 * q) = make_float4(s1[q], s2[q], s1[q + 1], s2[q + 1]);
         }
-        constexpr float invS = 1.f / 144.f;
+        const float invS = a.whole ? 1.f / 288.f : 1.f / 144.f;
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const bf16x8 x8 = xr[i];
@@ -490,8 +505,9 @@ __global__ void __launch_bounds__(512) gemm_pair_kernel(PairArgs a) {
     const int seq = xcd_remap(blockIdx.x, gridDim.x);       // the column blocks of a frame pair run back to back on one XCD: its rows come through one L2
     const int fp = seq / a.nt;
     const int m0 = fp * PM, n0 = (seq - fp * a.nt) * PN;
-    if (wave < 4) pair_body<MODE, 0>(a, smem, lane, wave, m0, n0, 2 * fp);
-    else pair_body<MODE, 1>(a, smem, lane, wave - 4, m0, n0, 2 * fp);
+    const int f0 = (MODE == 0 && a.whole) ? fp : 2 * fp;
+    if (wave < 4) pair_body<MODE, 0>(a, smem, lane, wave, m0, n0, f0);
+    else pair_body<MODE, 1>(a, smem, lane, wave - 4, m0, n0, f0);
 }
 
 template <int MODE>
@@ -520,15 +536,17 @@ extern "C" int bf_gemm_inbwd_frames(int dtype, int M, int N, int K, const void* 
                                     const float* fscale, int fdiv, bf_stream_t stream) {
     BF_REQUIRE(A && B && x && out && mean && rstd && w, "bf_gemm_inbwd_frames: null pointer");
     static const bool off = bf_knob("BF_FUSE_INBWD", 1) == 0;
-    if (off || dtype != BF_DTYPE_BF16 || S != FM || M <= 0 || M % FM || N <= 0 || N % FN || K < FK || K % FK || lda % 8 || ldb % 8) return 1;
+    if (off || dtype != BF_DTYPE_BF16 || (S != FM && S != PM) || M <= 0 || M % S || N <= 0 || N % FN || K < FK || K % FK || lda % 8 || ldb % 8) return 1;
     if (pair_shape_ok(M, N, K, lda, ldb) && (((uintptr_t)A | (uintptr_t)B | (uintptr_t)x | (uintptr_t)add | (uintptr_t)out) & 15) == 0) {
-        PairArgs a;      // an even number of frames: two frames per workgroup, LDS-DMA ping-pong
+        PairArgs a;      // an even number of 144-token frames (two per workgroup) or 288-token frames (one per workgroup): LDS-DMA ping-pong
+        a.whole = S == PM;
         a.A = (const bf16*)A; a.lda = lda; a.B = (const bf16*)B; a.ldb = ldb; a.N = N; a.nk = K / PK; a.nt = N / PN;
         a.x = (const bf16*)x; a.add = (const bf16*)add; a.out = (bf16*)out; a.ldx = N;
         a.mean = mean; a.rstd = rstd; a.w = w; a.ws = ws; a.fscale = fscale; a.fdiv = fdiv > 0 ? fdiv : 1; a.out2 = nullptr;
         BfProfScope prof((hipStream_t)stream, "gemm_pair<inbwd>", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * N * (add ? 3 : 2)));
         return launch_pair<0>(a, M, (hipStream_t)stream);
     }
+    if (S != FM) return 1;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_inbwd_frames_kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr != hipSuccess) return bf_fail(attr, __FILE__, __LINE__);
@@ -563,7 +581,7 @@ int bf_gemm_pair_scaled(int M, int N, int K, const bf_operand* A, const bf_opera
     a.A = (const bf16*)A->p; a.lda = A->ld; a.B = (const bf16*)B->p; a.ldb = B->ld; a.N = N; a.nk = K / PK; a.nt = N / PN;
     a.x = nullptr; a.add = E->aux_mode == BF_AUX_ADD ? (const bf16*)E->aux : nullptr; a.out = (bf16*)E->c; a.ldx = N;
     a.mean = nullptr; a.rstd = nullptr; a.w = nullptr; a.ws = nullptr; a.fscale = rowfac; a.fdiv = rows_per_group > 0 ? rows_per_group : 1;
-    a.out2 = rowfac ? (bf16*)out2 : nullptr;
+    a.out2 = rowfac ? (bf16*)out2 : nullptr; a.whole = 0;
     if (a.out2 && ((uintptr_t)out2 & 15)) return 1;
     BfProfScope prof(st, a.add ? "gemm_pair<add>" : "gemm_pair<plain>", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * N * (a.add ? 2 : 1)));
     return launch_pair<1>(a, M, st);

@@ -408,8 +408,14 @@ def test_gemm_inbwd_frames_at_the_bench_size(K):
     _check_gemm_inbwd_frames(K, 128, 1152, 384, True)
 
 
-def _check_gemm_inbwd_frames(K, Fr, Kd, N, with_add):
-    S = 144
+@pytest.mark.parametrize("Kd,N,with_add", [(1152, 384, True), (384, 128, False)])
+def test_gemm_inbwd_whole_288_token_frames(K, Kd, N, with_add):
+    """Frames of 288 tokens (24 x 12 grids: BASELINE configs[3]) are ONE tile of the frame-pair kernel: the two wave groups hold the
+    frame's halves and exchange their column sums through LDS."""
+    _check_gemm_inbwd_frames(K, 5, Kd, N, with_add, S=288)
+
+
+def _check_gemm_inbwd_frames(K, Fr, Kd, N, with_add, S=144):
     M = Fr * S
     g = torch.Generator(device="cuda").manual_seed(21)
     A = (torch.randn(M, Kd, device="cuda", generator=g) * 0.5).bfloat16()
@@ -448,7 +454,7 @@ def _check_gemm_inbwd_frames(K, Fr, Kd, N, with_add):
     (y2 * (dy * mrow).view(Fr, S, N)).sum().backward()
     assert _rel(dx3.double(), xr2.grad.view(M, N) + (add.double() if with_add else 0.0)) < 6e-3
     # shapes outside the whole-frame form are refused, not mis-computed
-    assert K.gemm_inbwd_frames(A[:S * 2], W, x.view(M, N)[:S * 2], 72, mean, rstd, w) is None
+    assert K.gemm_inbwd_frames(A[:144 * 2], W, x.view(M, N)[:144 * 2], 72, mean, rstd, w) is None
     assert K.gemm_inbwd_frames(A.float(), W.float(), x.view(M, N).float(), S, mean, rstd, w) is None
 
 
