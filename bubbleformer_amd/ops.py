@@ -282,9 +282,21 @@ def trunk_eval_applies(tok: torch.Tensor) -> bool:
     BF_TRUNK_EVAL_MAX_FRAMES frames (default 96).  The whole-frame kernels are built for few frames: measured eval forward, 16x192x192 clips,
     batch 1 / 2 / 4 / 8 / 16: 2.23 / 1.83 / 2.76 / 4.67 / 8.97 ms against 3.20 / 2.37 / 3.02 / 4.09 / 7.71 ms for the stage forwards (eager) --
     from 128 frames on the streaming GEMMs of the training-shaped forward win (one workgroup per CU pays its prologue and epilogue serially)."""
-    return (tok.is_cuda and tok.dtype == torch.bfloat16 and tok.dim() == 5 and tok.shape[2] * tok.shape[3] == 144 and tok.shape[4] == 384
-            and tok.shape[2] <= 16 and tok.shape[3] <= 16 and tok.shape[1] <= 32 and os.environ.get("BF_TRUNK_EVAL", "1") != "0"
-            and tok.shape[0] * tok.shape[1] <= int(os.environ.get("BF_TRUNK_EVAL_MAX_FRAMES", "96")))
+    ok = (tok.is_cuda and tok.dtype == torch.bfloat16 and tok.dim() == 5 and tok.shape[2] * tok.shape[3] == 144 and tok.shape[4] == 384
+          and tok.shape[2] <= 16 and tok.shape[3] <= 16 and tok.shape[1] <= 32 and os.environ.get("BF_TRUNK_EVAL", "1") != "0"
+          and tok.shape[0] * tok.shape[1] <= int(os.environ.get("BF_TRUNK_EVAL_MAX_FRAMES", "96")))
+    if (not ok and tok.is_cuda and tok.dtype == torch.bfloat16 and tok.dim() == 5 and tok.shape[0] * tok.shape[1] <= 96
+            and os.environ.get("BF_TRUNK_EVAL", "1") != "0" and not _SLOW_EVAL_WARNED):
+        # few frames but not the shape the whole-frame kernels are built for (144-token frames, E = 384): say so once instead of silently
+        # running the training-shaped stage forwards (about 1.6x slower per rollout step at batch 1)
+        _SLOW_EVAL_WARNED.append(True)
+        import warnings
+        warnings.warn("bubbleformer_amd: eval forward of a %s token tensor takes the stage-by-stage path; the whole-frame inference kernels "
+                      "cover 144-token frames with embed_dim 384 only" % (tuple(tok.shape),), RuntimeWarning, stacklevel=3)
+    return ok
+
+
+_SLOW_EVAL_WARNED: list = []
 
 
 def _stage_param_shapes(kind: str, E: int, heads: int) -> dict:
