@@ -32,7 +32,7 @@ int get_dims(const bf_dims* s, D* o) {
     o->dtype = s->dtype; o->B = s->B; o->T = s->T; o->h = s->h; o->w = s->w; o->E = s->E; o->heads = s->heads;
     o->attn_scale = s->attn_scale; o->feat_scale = s->feat_scale; o->patch = s->patch; o->cin = s->cin; o->cout = s->cout;
     o->nfluid = s->nfluid;
-    if (o->B < 1 || o->T < 1 || o->h < 1 || o->w < 1 || o->E < 8 || o->heads < 1 || o->E % o->heads)
+    if (o->B < 1 || o->T < 1 || o->h < 1 || o->w < 1 || o->E < 8 || o->E > 1024 || o->heads < 1 || o->E % o->heads)
         return bf_fail_msg("dims: bad sizes", __FILE__, __LINE__);
     if (o->dtype != BF_DTYPE_F32 && o->dtype != BF_DTYPE_BF16) return bf_fail_msg("dims: bad dtype", __FILE__, __LINE__);
     o->F = (long)o->B * o->T; o->S = (long)o->h * o->w; o->N = o->F * o->S; o->d = o->E / o->heads;
@@ -233,10 +233,22 @@ __global__ void outproj_finalize_kernel(const float* __restrict__ G, const float
         // csum[n] * gamma[n] * (lo[n] - hi[n]) needs nothing the row workgroups compute, and one writer per column replaces E x E float
         // atomics on E addresses (the launch took 14 us with them; and norm2.bias's gradient was order-dependent)
         __shared__ float part[4][64];
+        __shared__ float coef[1024];           // dmc[n] (E <= 1024: host-checked)
+        for (int n = threadIdx.x; n < E; n += blockDim.x) coef[n] = csum[n] * gamma[n] * (lo[n] - hi[n]);
+        __syncthreads();
         const int k = ((int)blockIdx.x - E) * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
         float a = 0.f;
-        if (k < E)
-            for (int n = q; n < E; n += 4) a = fmaf(csum[n] * gamma[n] * (lo[n] - hi[n]), W[(long)n * E + k], a);
+        if (k < E) {
+            int n = q;
+            for (; n + 28 < E; n += 32) {      // eight rows of W in flight per thread (a load-then-add loop pays a round trip per row)
+                float wv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) wv[u] = W[(long)(n + 4 * u) * E + k];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a = fmaf(coef[n + 4 * u], wv[u], a);
+            }
+            for (; n < E; n += 4) a = fmaf(coef[n], W[(long)n * E + k], a);
+        }
         part[q][threadIdx.x & 63] = a;
         __syncthreads();
         if (q == 0 && k < E) dnb[k] += (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
