@@ -34,7 +34,7 @@ struct StreamArgs {
     const bf16* A; long lda; const bf16* W; long ldw; bf16* C; long ldc;
     const float* bias; const float* colscale; const float* colshift; const float* rowscale; int rpg;
     int aux_mode; const bf16* aux; long ld_aux; bf16* gelu_out;
-    int KS, mt, nb;
+    int KS, mt, nb, ng;       // K chunks, 256-row tiles, column blocks per team, column groups (nb * ng blocks in all)
     int stagger;
     int dbg;      // timing experiments (BF_STREAM_DEBUG): 1 no DMA waits, 2 every tile reads the rows of tile 0, 4 no LDS reads / MFMA, 8 no stores
 };
@@ -69,8 +69,10 @@ __global__ void __launch_bounds__(512) stream_gemm_kernel(StreamArgs a) {
     const int tpx = wpx / a.nb;                       // teams per XCD (host guarantees >= 1)
     if (j >= tpx * a.nb) return;
     const int team = xl * tpx + j / a.nb, nteams = 8 * tpx;
-    const int c_nb = j % a.nb;
-    const int t_beg = (int)((long)a.mt * team / nteams), t_end = (int)((long)a.mt * (team + 1) / nteams);
+    // column groups (team_split): team t holds group t % ng and is the (t / ng)-th of that group's teams, which share the row tiles
+    const int grp = team % a.ng, rank = team / a.ng, gteams = (nteams - grp + a.ng - 1) / a.ng;
+    const int c_nb = grp * a.nb + j % a.nb;
+    const int t_beg = (int)((long)a.mt * rank / gteams), t_end = (int)((long)a.mt * (rank + 1) / gteams);
     if (t_beg >= t_end) return;
     const int total_steps = (t_end - t_beg) * KS;
 
@@ -303,8 +305,9 @@ __global__ void __launch_bounds__(512) stream_pp_kernel(StreamArgs a) {
     const int tpx = wpx / a.nb;
     if (j >= tpx * a.nb) return;
     const int team = xl * tpx + j / a.nb, nteams = 8 * tpx;
-    const int c_nb = j % a.nb;
-    const int t_beg = (int)((long)a.mt * team / nteams), t_end = (int)((long)a.mt * (team + 1) / nteams);
+    const int grp = team % a.ng, rank = team / a.ng, gteams = (nteams - grp + a.ng - 1) / a.ng;
+    const int c_nb = grp * a.nb + j % a.nb;
+    const int t_beg = (int)((long)a.mt * rank / gteams), t_end = (int)((long)a.mt * (rank + 1) / gteams);
     if (t_beg >= t_end) return;
     const int total_steps = (t_end - t_beg) * KS;
 
@@ -518,6 +521,26 @@ int num_cus() {
     return n;
 }
 
+// A team is one workgroup per column block of ONE column group, on one XCD (wpx workgroups each).  All NB blocks in one team is the
+// least re-reading of the token rows, but 12 blocks (N = 1536: fc1, the fc2 data gradient) leave room for 2 teams of 12 on an XCD's 32
+// workgroups: 16 teams for 72 row tiles = 5 tiles for some, with a quarter of the CUs unused.  Two groups of 6 blocks: 5 teams per XCD,
+// 20 per group, 4 tiles at most.  Pick the split with the shortest longest run; ties go to fewer groups (fewer reads of the rows).
+bool team_split(int NB, int mt, int wpx, int* nb, int* ng) {
+    static const int force = bf_knob("BF_STREAM_GROUPS", 0);
+    int best = 0, best_cost = 0;
+    for (int g = 1; g <= NB; ++g) {
+        if (NB % g || NB / g > wpx || (force > 0 && g != force)) continue;
+        const int nteams = 8 * (wpx / (NB / g));
+        if (nteams < g) continue;                              // every group needs a team
+        const int fewest = nteams / g;                         // teams of the last group
+        const int cost = (mt + fewest - 1) / fewest;
+        if (!best || cost < best_cost) { best = g; best_cost = cost; }
+    }
+    if (!best) return false;
+    *ng = best; *nb = NB / best;
+    return true;
+}
+
 }  // namespace
 
 // 0 = handled, 1 = shape / feature not covered (the caller's tile kernel runs), < 0 = error
@@ -545,13 +568,13 @@ int bf_gemm_stream_try(int M, int N, int K, const bf_operand* A, const bf_operan
     a.A = (const bf16*)A->p; a.lda = A->ld; a.W = (const bf16*)B->p; a.ldw = B->ld; a.C = (bf16*)E->c; a.ldc = E->ldc;
     a.bias = E->bias; a.colscale = E->colscale; a.colshift = E->colshift; a.rowscale = E->rowscale; a.rpg = E->rows_per_group > 0 ? E->rows_per_group : 1;
     a.aux_mode = E->aux_mode; a.aux = (const bf16*)E->aux; a.ld_aux = E->ld_aux; a.gelu_out = (bf16*)E->gelu_out;
-    a.KS = K / BK; a.mt = M / BM; a.nb = N / BNB;
+    a.KS = K / BK; a.mt = M / BM;
+    const int grid = (num_cus() / 8) * 8;
+    if (!team_split(N / BNB, a.mt, grid / 8, &a.nb, &a.ng)) return 1;
     static const int dbg = bf_knob("BF_STREAM_DEBUG", 0);
     a.dbg = dbg;
     static const int stagger = bf_knob("BF_STREAM_STAGGER", 1);
     a.stagger = stagger;
-    const int grid = (num_cus() / 8) * 8;
-    if (a.nb > grid / 8) return 1;                    // a team (one workgroup per column block) must fit one XCD
     const int lds_bytes = a.KS * CHUNK * 2 + NSLOT * ACHUNK * 2;
     static thread_local char pname[64];
     snprintf(pname, sizeof(pname), use_pp ? "stream_pp<%s>" : "stream_gemm<%s>", E->gelu_out ? "gelu2" : E->aux_mode == BF_AUX_ADD ? "add" : E->aux_mode == BF_AUX_DGELU ? "dgelu" : "plain");

@@ -231,7 +231,7 @@ __global__ void outproj_finalize_kernel(const float* __restrict__ G, const float
     __shared__ float s_dmc, s_alpha;
     if ((int)blockIdx.x >= E) {      // extra workgroups (feature scaling only): dnb[k] += sum_n dmc[n] * W[n][k], 64 columns each -- dmc[n] =
         // csum[n] * gamma[n] * (lo[n] - hi[n]) needs nothing the row workgroups compute, and one writer per column replaces E x E float
-        // atomics on E addresses (the launch took 14 us with them; and norm2.bias's gradient was order-dependent)
+        // atomics on E addresses (the launch took 14 us with them)
         __shared__ float part[4][64];
         __shared__ float coef[1024];           // dmc[n] (E <= 1024: host-checked)
         for (int n = threadIdx.x; n < E; n += blockDim.x) coef[n] = csum[n] * gamma[n] * (lo[n] - hi[n]);
@@ -251,7 +251,9 @@ __global__ void outproj_finalize_kernel(const float* __restrict__ G, const float
         }
         part[q][threadIdx.x & 63] = a;
         __syncthreads();
-        if (q == 0 && k < E) dnb[k] += (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        // one atomic per column: the caller's stream adds norm2's own bias gradient to the same addresses at the same time (the stage's
+        // InReduceJob) -- two addends on a zeroed slot give the same bits in either order, a plain += could lose one of them
+        if (q == 0 && k < E) atomicAdd(dnb + k, (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
         return;
     }
     const int n = blockIdx.x;
@@ -1251,6 +1253,24 @@ extern "C" int bf_embed_bwd(const bf_dims* dims, const bf_embed_params* p, const
             TRY(bf_gemm(d.dtype, sv.C[i], K4, (int)sv.P[i], &A, &Bo, &e, splitk_for(sv.C[i], K4, sv.P[i]), ss));
         }
         TRY(bf_wgrad_unprep(1, sc.wg, g->conv_w[i], sv.C[i], K4, K4, 0, ss));
+        if (i == 1 && !dx_in) {
+            // Nothing but sums over pixels is wanted behind this stage's data gradient (GELU', the stage-0 InstanceNorm backward, the
+            // stage-0 weight gradient): one pass that keeps the gradient map in registers (embed_tail.hip).  Its partials and the
+            // prepared-layout gradient live in the token-reduction workspace, which no side-stream kernel of this call touches.
+            static const bool tail_on = bf_knob("BF_EMBED_TAIL", 1) != 0;
+            const int64_t need = bf_embed_tail_ws_floats((int)d.F, sv.gh[1], sv.gw[1], cp, sv.Kp);
+            if (tail_on && need > 0 && need + (int64_t)cp * sv.Kp <= sc.tokred_floats) {
+                float* dwprep = sc.tokred_ws + need;
+                const int trc = bf_embed_tail_bwd(d.dtype, dy, sv.wc[1], sv.y[0], sv.patches, sv.wc[0], sv.sc[0], sv.sh[0], sv.mean[0], sv.rstd[0],
+                                                  p->in_w[0], dwprep, g->in_w[0], g->in_b[0], (int)d.F, sv.gh[1], sv.gw[1], sv.C[1], cp, sv.Kp,
+                                                  sc.tokred_ws, need, s);
+                if (trc < 0) return trc;
+                if (trc == 0) {
+                    TRY(bf_wgrad_unprep(0, dwprep, g->conv_w[0], sv.C[0], 4 * d.cin, sv.Kp, 0, st));
+                    return fk.join();
+                }
+            }
+        }
         void* dact = buf(i - 1);
         {   // d(act patch)[p][k] = sum_co dy[p][co] * Wprep[co][k], scattered back to the input grid
             bf_operand A = op_plain(dy, sv.C[i], BF_LAY_KC);

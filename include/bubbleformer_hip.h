@@ -219,6 +219,17 @@ int bf_embed_first(int dtype, const float* x, const void* wc, void* patches, voi
  * bf_in_stats_merge_slices(..., rows = 256, ws) with ws + 2*frames*C0 == stat_part (the layout bf_in_stats uses for long frames). */
 int bf_in_stats_merge_slices(int dtype, int frames, int S, int C, int rows, const float* w, const float* b, const float* g, int gdiv,
                              const float* gb, float* mean, float* rstd, float* sc, float* sh, float* ws, bf_stream_t stream);
+/* The tail of the HMLPEmbed backward when the input needs no gradient (layers/patching.py:24-56 under autograd): the stage-1 data
+ * gradient dy1 [frames*gh1*gw1][C1] times w1c [C1][4*C0] (the stage-1 weight, columns (2*ky + kx)*C0 + c), GELU', the stage-0 InstanceNorm
+ * backward and the stage-0 weight gradient in one pass that never writes the [frames*4*gh1*gw1][C0] gradient map.  y0: raw stage-0
+ * output, patches [..][Kp] (bf_embed_first), w0c [C0][Kp], sc / sh / mean / rstd [frames][C0] of the stage-0 InstanceNorm, in_w its
+ * weight.  dwprep [C0][Kp] is WRITTEN (bf_wgrad_unprep folds it into the gradient), d_in_w / d_in_b [C0] are accumulated (optional).
+ * ws: bf_embed_tail_ws_floats floats.  Returns 1 (nothing launched) for shapes it does not take: fp32, C0 != 96, C1 not in {96, 192}, Kp != 16,
+ * gw1 % 16, gh1*gw1 % 128, or a workspace that is too small. */
+int64_t bf_embed_tail_ws_floats(int frames, int gh1, int gw1, int C0, int Kp);
+int bf_embed_tail_bwd(int dtype, const void* dy1, const void* w1c, const void* y0, const void* patches, const void* w0c, const float* sc,
+                      const float* sh, const float* mean, const float* rstd, const float* in_w, float* dwprep, float* d_in_w, float* d_in_b,
+                      int frames, int gh1, int gw1, int C1, int C0, int Kp, float* ws, int64_t ws_floats, bf_stream_t stream);
 int bf_lploss_finalize(const float* lossbuf, int frames, int Co, float* loss, float* coef, bf_stream_t stream);
 int bf_nchw2pm(int dtype, const float* dpred, const float* pred, const float* y, const float* coef, const float* gscale,
                void* dpm, int frames, int Co, int h, int w, int Np, bf_stream_t stream);

@@ -76,12 +76,12 @@ def test_gemm_dW_layout_tn_splitk_prologue(K, dtype, splitk):
 
 
 @pytest.mark.parametrize("M,N,K_", [(256 * 3, 128 * 5, 384), (256 * 20, 1152, 384), (256 * 5, 384, 256), (256 * 9, 256, 320), (18432, 1536, 384),
-                                    (256, 128, 128), (256 * 7, 384, 1536), (256 * 31, 768, 64 * 11)])
+                                    (256, 128, 128), (256 * 7, 384, 1536), (256 * 31, 768, 64 * 11), (256 * 18, 1536, 384)])
 @pytest.mark.parametrize("variant", ["plain", "gelu2", "add_cs", "add", "dgelu"])
 def test_gemm_stream_weight_stationary(K, M, N, K_, variant):
     """The persistent LDS-DMA streaming kernel (gemm_stream.hip, ping-pong form) takes these bf16 shapes: every epilogue variant against
     fp32 torch on the same bf16 operands; 2 .. 24 K-steps (ring wrap inside and across tiles), one and many tiles per workgroup, a
-    single-tile launch."""
+    single-tile launch; 18 row tiles x 12 column blocks is the case the column blocks are dealt to two groups of teams (team_split)."""
     from bubbleformer_amd import _lib as L
     if variant != "plain" and M == 18432:
         pytest.skip("full-size shape once")
@@ -773,3 +773,52 @@ def test_embed_first_stage_one_pass_with_statistics(cin, h2, w2):
     assert _rel(got[0], yf.mean(1)) < 1e-5 and _rel(got[1], (yf.var(1, unbiased=False) + 1e-5).rsqrt()) < 1e-5
     for a, r in zip(got, ref):
         assert _rel(a, r) < 1e-5
+
+
+@pytest.mark.parametrize("Fr,gh1,gw1,C1", [(3, 8, 16, 96), (2, 12, 32, 192), (5, 48, 48, 96)])
+def test_embed_backward_tail_one_pass(Fr, gh1, gw1, C1):
+    """bf_embed_tail_bwd (embed_tail.hip): the stage-1 data gradient, GELU', the stage-0 InstanceNorm backward and the stage-0 weight
+    gradient without the stage-0 gradient map, against autograd through  patches @ W0^T -> InstanceNorm -> GELU -> <. , dact>  in fp32
+    (layers/patching.py:24-56); dact is the plain product dy1 @ W1 scattered to the 2x2 positions.  One / two / six tiles per wave,
+    one and several runs per frame, 16-row blocks in the middle of an image row (gw1 = 32, 48)."""
+    from bubbleformer_amd import _lib as L
+    from bubbleformer_amd.ops import _p, _stream
+    lib = L.lib()
+    C0, Kp = 96, 16
+    g = torch.Generator(device="cuda").manual_seed(37)
+    S1, S0 = gh1 * gw1, 4 * gh1 * gw1
+    patches = (torch.randn(Fr * S0, Kp, device="cuda", generator=g) + 0.3).bfloat16()
+    W0 = (torch.randn(C0, Kp, device="cuda", generator=g) / 3).bfloat16()
+    W1 = (torch.randn(C1, 4 * C0, device="cuda", generator=g) / 8).bfloat16()
+    dy1 = torch.randn(Fr * S1, C1, device="cuda", generator=g).bfloat16()
+    in_w, in_b = 1 + 0.2 * torch.randn(C0, device="cuda", generator=g), 0.3 * torch.randn(C0, device="cuda", generator=g)
+    y0 = (patches.float() @ W0.float().t()).bfloat16()                       # what bf_embed_first stores
+    yf = y0.float().view(Fr, S0, C0)
+    mean, rstd = yf.mean(1).contiguous(), (yf.var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    sc = (rstd * in_w).contiguous()
+    sh = (in_b - mean * sc).contiguous()
+    # reference: upstream gradient on the stage-0 grid, then autograd
+    dact = (dy1.double() @ W1.double()).view(Fr, gh1, gw1, 2, 2, C0).permute(0, 1, 3, 2, 4, 5).reshape(Fr, S0, C0)      # pixel (2y + ky, 2x + kx)
+    W0r = W0.double().requires_grad_(True)
+    wr, br = in_w.double().requires_grad_(True), in_b.double().requires_grad_(True)
+    y = (patches.double() @ W0r.t()).view(Fr, S0, C0)
+    xh = (y - y.mean(1, keepdim=True)) / (y.var(1, unbiased=False, keepdim=True) + 1e-5).sqrt()
+    (torch.nn.functional.gelu(xh * wr + br) * dact).sum().backward()
+    nws = lib.bf_embed_tail_ws_floats(Fr, gh1, gw1, C0, Kp)
+    assert nws > 0
+    ws = torch.full((nws,), float("nan"), device="cuda")
+    dwprep = torch.full((C0, Kp), float("nan"), device="cuda")
+    dw, db = torch.full((C0,), 2.0, device="cuda"), torch.full((C0,), -1.0, device="cuda")       # accumulated into
+    args = [_p(t) for t in (dy1, W1, y0, patches, W0, sc, sh, mean, rstd, in_w, dwprep, dw, db)]
+    L.check(lib.bf_embed_tail_bwd(1, *args, Fr, gh1, gw1, C1, C0, Kp, _p(ws), nws, _stream()), "embed_tail_bwd")
+    assert torch.isfinite(dwprep).all()
+    # bf16 operands of the pixel contraction (dd, 2^-9 each), the polynomial gelu' and the bf16 rounding of the stored y0
+    assert _rel(dwprep, W0r.grad) < 1e-2
+    assert _rel(dw - 2.0, wr.grad) < 1e-2 and _rel(db + 1.0, br.grad) < 1e-2
+    first = dwprep.clone()
+    L.check(lib.bf_embed_tail_bwd(1, *args, Fr, gh1, gw1, C1, C0, Kp, _p(ws), nws, _stream()), "embed_tail_bwd")
+    assert torch.equal(first, dwprep)                      # fixed summation order: bit-reproducible
+    # declined shapes: nothing launched
+    assert lib.bf_embed_tail_bwd(0, *args, Fr, gh1, gw1, C1, C0, Kp, _p(ws), nws, _stream()) == 1        # fp32
+    assert lib.bf_embed_tail_bwd(1, *args, Fr, gh1, gw1 + 8, C1, C0, Kp, _p(ws), nws, _stream()) == 1    # gw1 % 16
+    assert lib.bf_embed_tail_bwd(1, *args, Fr, gh1, gw1, C1, C0, Kp, _p(ws), nws - 1, _stream()) == 1    # workspace too small

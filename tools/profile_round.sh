@@ -11,7 +11,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/pmc_write.log || { tail -5 $OUT/pmc_write.log; exit 1; }
 cd $ROOT
 python3 tools/rocprof_summary.py $OUT/trace $OUT/pmc_fetch $OUT/pmc_write --out $OUT/${R} > /dev/null
-python3 tools/timeline.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) --out $OUT/${R}_timeline.md > /dev/null
+python3 tools/timeline.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) --out $OUT/${R}_timeline.md --anatomy $OUT/${R}_step_anatomy.txt > /dev/null
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/${R}_rocprofv3_kernel_stats.csv
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write
 ls -la $OUT; head -12 $OUT/${R}_kernel_stats.md

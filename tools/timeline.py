@@ -43,11 +43,24 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("trace")
     ap.add_argument("--out")
+    ap.add_argument("--anatomy", help="also write ONE steady-state step launch by launch (queue, start, duration, workgroups) to this file")
     a = ap.parse_args()
-    rows = [(int(r["Queue_Id"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in csv.DictReader(open(a.trace))]
+    raw = list(csv.DictReader(open(a.trace)))
+    rows = [(int(r["Queue_Id"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]),
+             int(r.get("Grid_Size_X", 0) or 0) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
+             // max(1, int(r.get("Workgroup_Size_X", 1) or 1) * int(r.get("Workgroup_Size_Y", 1) or 1) * int(r.get("Workgroup_Size_Z", 1) or 1))) for r in raw]
     rows.sort(key=lambda r: r[1])
     opt = [i for i, r in enumerate(rows) if r[3] == "adamw"]
     first, last = opt[len(opt) // 3], opt[-3]                     # steady-state steps
+    if a.anatomy:
+        mid = opt[len(opt) // 2]
+        one = rows[mid + 1:opt[len(opt) // 2 + 1] + 1]
+        t0 = one[0][1]
+        qs = sorted({r[0] for r in one}, key=lambda q: -sum(1 for r in one if r[0] == q))
+        with open(a.anatomy, "w") as f:
+            f.write("# one steady-state step, launch by launch: queue (0 = caller's stream), start us, duration us, workgroups, kernel\n")
+            for r in one:
+                f.write("%d %9.1f %8.1f %7d  %s\n" % (qs.index(r[0]), (r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, r[4], r[3]))
     seg = rows[first + 1:last + 1]
     nsteps = opt.index(last) - opt.index(first)
     lines = []
