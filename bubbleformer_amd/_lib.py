@@ -101,6 +101,8 @@ SIGNATURES = {
     "bf_col2im_nchw": (C.c_int, [C.c_int, vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "bf_pm2nchw": (C.c_int, [fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "bf_debed_last_bwd": (C.c_int, [C.c_int, fp, fp, fp, fp, fp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "bf_debed_last_bwd_norm": (C.c_int, [C.c_int, fp, fp, fp, fp, fp, vp, vp, vp, fp, fp, fp, fp, vp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, fp, C.c_int64, vp]),
     "bf_embed_tail_ws_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "bf_embed_tail_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, fp, fp, fp, fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     fp, C.c_int64, vp]),

@@ -1383,10 +1383,20 @@ extern "C" int bf_debed_bwd(const bf_dims* dims, const bf_debed_params* p, const
         const long rpf = (long)sv.gh[i] * sv.gw[i];
         const void* ain = i == 0 ? x : sv.y[i - 1];
         void* dact = i == 0 ? dx : buf(i);
+        bool normed = false;          // dact already holds the gradient of the raw map in front of stage i-1's InstanceNorm
         if (last) {
             void* dpm = sc.t1;
+            // ... together with the InstanceNorm + GELU backward of the stage in front where that applies: the full-resolution gradient map
+            // has rank 16 and is never stored (patch.hip, debed_last_inbwd_kernel)
+            if (i > 0) {
+                const int nrc = bf_debed_last_bwd_norm(d.dtype, dpred, pred, target, sv.coef, loss_scale, sv.wc[i], dpm, ain, sv.mean[i - 1], sv.rstd[i - 1],
+                                                       p->in_w[i - 1], p->in_b[i - 1], dact, g->in_w[i - 1], g->in_b[i - 1], (int)d.F, cin, co, sv.gh[i],
+                                                       sv.gw[i], sv.Np, sc.in_ws, bf_in_ws_floats(d.dtype, (int)d.F, (int)rpf, cin), st);
+                if (nrc < 0) return nrc;
+                normed = nrc == 0;
+            }
             // the loss gradient in patch-major rows and the data gradient of the transposed convolution in one pass where it applies
-            const int rc = bf_debed_last_bwd(d.dtype, dpred, pred, target, sv.coef, loss_scale, sv.wc[i], dpm, dact, (int)d.F, cin, co, sv.gh[i], sv.gw[i], sv.Np, st);
+            const int rc = normed ? 0 : bf_debed_last_bwd(d.dtype, dpred, pred, target, sv.coef, loss_scale, sv.wc[i], dpm, dact, (int)d.F, cin, co, sv.gh[i], sv.gw[i], sv.Np, st);
             if (rc < 0) return rc;
             if (rc == 1) TRY(bf_nchw2pm(d.dtype, dpred, pred, target, sv.coef, loss_scale, dpm, (int)d.F, co, sv.gh[i], sv.gw[i], sv.Np, st));
             TRY(fk.begin(&ss));
@@ -1433,8 +1443,9 @@ extern "C" int bf_debed_bwd(const bf_dims* dims, const bf_debed_params* p, const
             }
         }
         if (i > 0) {
-            TRY(bf_in_bwd(d.dtype, dact, sv.y[i - 1], nullptr, dact, (int)d.F, (int)rpf, cin, sv.mean[i - 1], sv.rstd[i - 1], p->in_w[i - 1],
-                          p->in_b[i - 1], nullptr, 1, 1, g->in_w[i - 1], g->in_b[i - 1], nullptr, nullptr, sc.in_ws, st));
+            if (!normed)
+                TRY(bf_in_bwd(d.dtype, dact, sv.y[i - 1], nullptr, dact, (int)d.F, (int)rpf, cin, sv.mean[i - 1], sv.rstd[i - 1], p->in_w[i - 1],
+                              p->in_b[i - 1], nullptr, 1, 1, g->in_w[i - 1], g->in_b[i - 1], nullptr, nullptr, sc.in_ws, st));
             dy = dact;
         }
     }

@@ -7,6 +7,7 @@
 //   adamw                      : fused flat-buffer AdamW
 // All are bandwidth-bound; each thread moves 8..16 contiguous bytes where the layout allows.
 #include "bf_common.h"
+#include "param_reduce.h"
 
 namespace {
 constexpr int NT = 256;
@@ -287,6 +288,139 @@ __global__ void __launch_bounds__(NT) debed_last_bwd_kernel(const float* __restr
         }
     }
 }
+// The last debed stage backwards TOGETHER with the InstanceNorm + GELU in front of it (layers/patching.py:92-104 under autograd).  The
+// gradient of the 96-channel map at full patch-grid resolution (226 MB at the bench shape) has rank 16 -- dact = dpm @ wc^T -- so neither
+// pass stores it: PASS 1 forms dpm (written: the weight gradient wants it), multiplies dact by gelu'(z) in registers and leaves the
+// InstanceNorm backward's two sums per 256-row slice; PASS 2 rebuilds dact from the 16-wide rows and writes
+// dx = rstd w (dd - s1/S - xh s2/S) directly.  Against debed_last_bwd_kernel + the two-phase sliced InstanceNorm backward: one write
+// (226 MB) and two reads (452 MB) of the gradient map less.  Lane = (pixel li, channel runs 32 q + 8 lg .. +7): 16-byte loads of the
+// activation map, 16-byte stores of dx.
+struct DlInb {
+    const bf16* ymap;                   // raw output of the stage in front [P][Ci]
+    const float *mean, *rstd, *w, *b;   // its InstanceNorm: [frames][Ci], [Ci]
+    const float* tot;                   // PASS 2: {s1, s2} per (frame, channel)
+    float inv_s;                        // 1 / rows per frame
+};
+template <int T, int PASS>
+__global__ void __launch_bounds__(NT) debed_last_inbwd_kernel(const float* __restrict__ dpred, const float* __restrict__ pred, const float* __restrict__ y,
+                                                             const float* __restrict__ coef, const float* __restrict__ gscale,
+                                                             const bf16* __restrict__ wc, bf16* __restrict__ dpm, bf16* __restrict__ dx,
+                                                             int Co, int h, int w, float* __restrict__ part, DlInb nb) {
+    constexpr int Ci = 16 * T;
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
+    __shared__ float4 k1[Ci], k2[Ci];       // {sc, sh, rstd, -mean rstd} and {rstd w, s1 / S, s2 / S, -}
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int f = blockIdx.y;
+    for (int c = threadIdx.x; c < Ci; c += NT) {
+        const long o = (long)f * Ci + c;
+        const float r = nb.rstd[o], m = nb.mean[o], a = r * nb.w[c];
+        k1[c] = make_float4(a, fmaf(-m, a, nb.b[c]), r, -m * r);
+        if (PASS == 2) k2[c] = make_float4(a, nb.tot[2 * o] * nb.inv_s, nb.tot[2 * o + 1] * nb.inv_s, 0.f);
+    }
+    __syncthreads();
+    const int GF = h * w / 16;
+    const int g0 = (blockIdx.x * (NT / 64) + wave) * DL_GPW;
+    if (g0 >= GF) return;
+    const int g1 = min(g0 + DL_GPW, GF);
+    const int H = 2 * h, W = 2 * w;
+    const bool live = lg < Co;
+    s16x4 wf[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int ci = 32 * (t >> 1) + 8 * (li >> 2) + 4 * (t & 1) + (li & 3);      // lane (pixel li, group lg) gets channel 32 (k / 8) + 8 lg + k % 8 in slot k = 4 t + j
+        wf[t] = *reinterpret_cast<const s16x4*>(wc + ci * 16 + 4 * lg);
+    }
+    const float cf = (PASS == 1 && !dpred && live) ? coef[(long)f * Co + lg] * (gscale ? gscale[0] : 1.f) : 0.f;
+    struct Row { float2 r[4]; bf16x8 yv[T / 2]; bf16x4v d; };
+    auto fetch = [&](int g, Row& o) __attribute__((always_inline)) {
+        const long p = (long)f * h * w + g * 16 + li;
+#pragma unroll
+        for (int q = 0; q < T / 2; ++q) o.yv[q] = *reinterpret_cast<const bf16x8*>(nb.ymap + p * Ci + 8 * lg + 32 * q);
+        if (PASS == 2) { o.d = *reinterpret_cast<const bf16x4v*>(dpm + p * 16 + 4 * lg); return; }
+        const int px = g * 16 + li, yo = px / w, xo = px - yo * w;
+        const long oo = (((long)f * Co + lg) * H + 2 * yo) * W + 2 * xo;
+        if (!live) { o.r[0] = o.r[1] = o.r[2] = o.r[3] = make_float2(0.f, 0.f); return; }
+        if (dpred) { o.r[0] = *reinterpret_cast<const float2*>(dpred + oo); o.r[1] = *reinterpret_cast<const float2*>(dpred + oo + W); o.r[2] = o.r[3] = make_float2(0.f, 0.f); }
+        else {
+            o.r[0] = *reinterpret_cast<const float2*>(pred + oo); o.r[1] = *reinterpret_cast<const float2*>(pred + oo + W);
+            o.r[2] = *reinterpret_cast<const float2*>(y + oo); o.r[3] = *reinterpret_cast<const float2*>(y + oo + W);
+        }
+    };
+    Row cur, nxt;
+    fetch(g0, cur);
+    float s1[PASS == 1 ? 4 * T : 1], s2[PASS == 1 ? 4 * T : 1];
+    if (PASS == 1) {
+#pragma unroll
+        for (int k = 0; k < 4 * T; ++k) s1[k] = s2[k] = 0.f;
+    }
+    for (int g = g0; g < g1; ++g) {
+        if (g + 1 < g1) fetch(g + 1, nxt);
+        const long p = (long)f * h * w + g * 16 + li;
+        bf16x4v b;
+        if (PASS == 1) {
+            float v[4];
+            if (dpred) { v[0] = cur.r[0].x; v[1] = cur.r[0].y; v[2] = cur.r[1].x; v[3] = cur.r[1].y; }
+            else { v[0] = cf * (cur.r[0].x - cur.r[2].x); v[1] = cf * (cur.r[0].y - cur.r[2].y); v[2] = cf * (cur.r[1].x - cur.r[3].x); v[3] = cf * (cur.r[1].y - cur.r[3].y); }
+            b = bf16x4v{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            *reinterpret_cast<bf16x4v*>(dpm + p * 16 + 4 * lg) = b;
+        } else b = cur.d;
+        const s16x4 bs = __builtin_bit_cast(s16x4, b);
+        bf16x8 o8[T / 2];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wf[t], bs, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * t + j;
+                const float4 c1 = k1[32 * (k >> 3) + 8 * lg + (k & 7)];
+                const float yv = (float)cur.yv[k >> 3][k & 7];
+                const float dd = acc[j] * dgelu_fast(fmaf(yv, c1.x, c1.y)), xh = fmaf(yv, c1.z, c1.w);
+                if (PASS == 1) { s1[k] += dd; s2[k] = fmaf(dd, xh, s2[k]); }
+                else {
+                    const float4 c2 = k2[32 * (k >> 3) + 8 * lg + (k & 7)];
+                    o8[k >> 3][k & 7] = (bf16)(c2.x * (dd - c2.y - xh * c2.z));
+                }
+            }
+        }
+        if (PASS == 2) {
+#pragma unroll
+            for (int q = 0; q < T / 2; ++q) *reinterpret_cast<bf16x8*>(dx + p * Ci + 8 * lg + 32 * q) = o8[q];
+        }
+        cur = nxt;
+    }
+    if (PASS == 1) {      // {sum dd, sum dd xh} of this wave's slice: part[(f * nsl + sl) * Ci + c]
+        const int nsl = (GF + DL_GPW - 1) / DL_GPW, sl = g0 / DL_GPW;
+        float2* o2 = reinterpret_cast<float2*>(part) + ((long)f * nsl + sl) * Ci;
+#pragma unroll
+        for (int k = 0; k < 4 * T; ++k) {
+            float a = s1[k], b2 = s2[k];
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); b2 += __shfl_xor(b2, m, 64); }
+            if (li == 0) o2[32 * (k >> 3) + 8 * lg + (k & 7)] = make_float2(a, b2);
+        }
+    }
+}
+// tot[f][c] = sum over slices, in slice order.  grid (ceil(C / 64), frames), 256 threads = 64 channels x 4 slice lanes
+__global__ void __launch_bounds__(NT) dl_slice_sum_kernel(const float* __restrict__ part, int C, int nsl, float* __restrict__ tot) {
+    __shared__ float red[2][4][64];
+    const int l = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = blockIdx.x * 64 + l, f = blockIdx.y;
+    const bool cv = c < C;
+    const float2* pp = reinterpret_cast<const float2*>(part) + (long)f * nsl * C + (cv ? c : 0);
+    float a = 0.f, b = 0.f;
+    if (cv)
+        for (int sl = q; sl < nsl; sl += 4) { const float2 v = pp[(long)sl * C]; a += v.x; b += v.y; }
+    red[0][q][l] = a; red[1][q][l] = b;
+    __syncthreads();
+    if (q != 0 || !cv) return;
+    reinterpret_cast<float2*>(tot)[(long)f * C + c] = make_float2((red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]),
+                                                                 (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]));
+}
+__global__ void __launch_bounds__(NT) dl_param_reduce_kernel(InReduceJob j) {
+    __shared__ float red[5][4][64];
+    in_reduce_block(j, blockIdx.x, blockIdx.y, red);
+}
 // loss = sum_c mean_f sqrt(num/den);  coef[f][c] = 1 / (F * sqrt(num) * sqrt(den))   (single block)
 __global__ void lploss_finalize_kernel(const float* __restrict__ lossbuf, int F, int Co, float* __restrict__ loss, float* __restrict__ coef) {
     __shared__ float red[NT];
@@ -553,6 +687,51 @@ static int debed_last_bwd_launch(int dtype, const float* dpred, const float* pre
 extern "C" int bf_debed_last_bwd(int dtype, const float* dpred, const float* pred, const float* y, const float* coef, const float* gscale,
                                  const void* wc, void* dpm, void* dact, int frames, int Ci, int Co, int h, int w, int Np, bf_stream_t stream) {
     return debed_last_bwd_launch(dtype, dpred, pred, y, coef, gscale, wc, dpm, dact, frames, Ci, Co, h, w, Np, nullptr, stream);
+}
+
+// ... with the InstanceNorm + GELU in front of the stage folded in (debed_last_inbwd_kernel): dpm as above, dx [P][Ci] = the gradient of the
+// RAW map ymap in front of that InstanceNorm, d_in_w / d_in_b accumulated.  ws: bf_in_ws_floats(dtype, frames, h*w, Ci) floats.
+// Returns 1 (nothing launched) for the shapes bf_debed_last_bwd declines, Ci % 32, or a workspace that does not hold 256-row slices.
+extern "C" int bf_debed_last_bwd_norm(int dtype, const float* dpred, const float* pred, const float* y, const float* coef, const float* gscale,
+                                      const void* wc, void* dpm, const void* ymap, const float* mean, const float* rstd, const float* in_w,
+                                      const float* in_b, void* dx, float* d_in_w, float* d_in_b, int frames, int Ci, int Co, int h, int w, int Np,
+                                      float* ws, int64_t ws_floats, bf_stream_t stream) {
+    if (dtype != BF_DTYPE_BF16 || Np != 16 || Co > 4 || Ci % 32 != 0 || Ci > 128 || w % 16 != 0) return 1;
+    static const bool off = bf_knob("BF_DEBED_LAST_NORM", 1) == 0;
+    if (off) return 1;
+    BF_REQUIRE(wc && dpm && ymap && mean && rstd && in_w && in_b && dx && ws && (dpred || (pred && y && coef)) && frames > 0 && Co > 0 && h > 0 && w > 0,
+               "bf_debed_last_bwd_norm: bad arguments");
+    const int GF = h * w / 16, nsl = bf_cdiv(GF, DL_GPW);
+    if (ws_floats < (int64_t)2 * frames * Ci * (1 + nsl)) return 1;
+    float* tot = ws;
+    float* part = ws + (size_t)2 * frames * Ci;
+    dim3 grid(bf_cdiv(GF, (NT / 64) * DL_GPW), frames);
+    hipStream_t st = (hipStream_t)stream;
+    const double P = (double)frames * h * w;
+    const DlInb nb1{(const bf16*)ymap, mean, rstd, in_w, in_b, nullptr, 0.f};
+    const DlInb nb2{(const bf16*)ymap, mean, rstd, in_w, in_b, tot, 1.0f / (float)(h * w)};
+    {
+        BfProfScope prof(st, "debed_last_bwd<stats>", 2.0 * P * Ci * 16, P * (2.0 * Ci + 32.0 + 16.0 * Co * (dpred ? 1 : 2)));
+#define DLN(T) hipLaunchKernelGGL((debed_last_inbwd_kernel<T, 1>), grid, dim3(NT), 0, st, dpred, pred, y, coef, gscale, (const bf16*)wc, (bf16*)dpm, (bf16*)dx, Co, h, w, part, nb1)
+        switch (Ci / 32) { case 1: DLN(2); break; case 2: DLN(4); break; case 3: DLN(6); break; default: DLN(8); break; }
+#undef DLN
+        BF_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(dl_slice_sum_kernel, dim3(bf_cdiv(Ci, 64), frames), dim3(NT), 0, st, (const float*)part, Ci, nsl, tot);
+    BF_CHECK_LAUNCH();
+    {
+        BfProfScope prof(st, "debed_last_bwd<apply>", 2.0 * P * Ci * 16, P * (4.0 * Ci + 32.0));
+#define DLN(T) hipLaunchKernelGGL((debed_last_inbwd_kernel<T, 2>), grid, dim3(NT), 0, st, nullptr, nullptr, nullptr, nullptr, nullptr, (const bf16*)wc, (bf16*)dpm, (bf16*)dx, Co, h, w, nullptr, nb2)
+        switch (Ci / 32) { case 1: DLN(2); break; case 2: DLN(4); break; case 3: DLN(6); break; default: DLN(8); break; }
+#undef DLN
+        BF_CHECK_LAUNCH();
+    }
+    if (d_in_w || d_in_b) {
+        const InReduceJob j{tot, frames, Ci, in_w, in_b, nullptr, 1, d_in_w, d_in_b, nullptr, nullptr, nullptr, nullptr};
+        hipLaunchKernelGGL(dl_param_reduce_kernel, dim3(bf_cdiv(Ci, 64), bf_cdiv(frames, j.rdiv())), dim3(NT), 0, st, j);
+        BF_CHECK_LAUNCH();
+    }
+    return 0;
 }
 
 // The first HMLPEmbed stage is the same contraction (layers/patching.py:30-48, Conv2d(k=2, s=2, bias=False) on the NCHW clip): rows of 2x2

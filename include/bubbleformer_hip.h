@@ -210,6 +210,14 @@ int bf_debed_last(int dtype, const void* act, const float* sc, const float* sh, 
  * in one pass.  Same declined shapes (returns 1). */
 int bf_debed_last_bwd(int dtype, const float* dpred, const float* pred, const float* y, const float* coef, const float* gscale,
                       const void* wc, void* dpm, void* dact, int frames, int Ci, int Co, int h, int w, int Np, bf_stream_t stream);
+/* ... and with the InstanceNorm + GELU in front of the stage folded in (layers/patching.py:92-104 under autograd): dpm as above, and
+ * dx [frames*h*w][Ci] = the gradient of the RAW map ymap in front of that InstanceNorm (mean / rstd [frames][Ci], affine in_w / in_b) --
+ * two passes over ymap around the frame-wide sums, the rank-16 gradient map itself is never stored.  d_in_w / d_in_b are accumulated
+ * (optional).  ws: bf_in_ws_floats(dtype, frames, h*w, Ci) floats.  Same declined shapes (returns 1), also for a workspace too small. */
+int bf_debed_last_bwd_norm(int dtype, const float* dpred, const float* pred, const float* y, const float* coef, const float* gscale,
+                           const void* wc, void* dpm, const void* ymap, const float* mean, const float* rstd, const float* in_w,
+                           const float* in_b, void* dx, float* d_in_w, float* d_in_b, int frames, int Ci, int Co, int h, int w, int Np,
+                           float* ws, int64_t ws_floats, bf_stream_t stream);
 /* First HMLPEmbed stage (layers/patching.py:30-48: Conv2d(k=2, s=2, bias=False) on the NCHW fp32 clip) in one pass: patches [P][Kp]
  * (k = c*4 + ky*2 + kx, what bf_im2col_nchw writes; kept for the weight gradient) and y0[p][co] = sum_k patches[p][k] * wc[co][k].
  * Same kernel and declined shapes as bf_debed_last_bwd (returns 1). */

@@ -736,6 +736,58 @@ def test_debed_last_stage_backward_one_pass(Ci, Co, h, w, fused_loss):
     assert lib.bf_debed_last_bwd(0, _p(dpred), None, None, None, None, _p(wc), _p(dpm), _p(dact), Fr, Ci, Co, h, w, 16, _stream()) == 1
 
 
+@pytest.mark.parametrize("Ci,Co,h,w", [(96, 4, 96, 96), (32, 3, 6, 16), (64, 1, 5, 32), (128, 4, 3, 48)])
+@pytest.mark.parametrize("fused_loss", [False, True])
+def test_debed_last_stage_backward_with_the_norm_in_front(Ci, Co, h, w, fused_loss):
+    """bf_debed_last_bwd_norm: the last stage's data gradient, GELU' and the InstanceNorm backward of the map in front of it in two passes that
+    never store the rank-16 gradient map, against autograd in fp64 through  InstanceNorm -> GELU -> @ wc  on the same bf16 operands
+    (layers/patching.py:92-104); dpm bit-identical to bf_debed_last_bwd's.  Whole and ragged last slices (h*w / 16 groups of 16 per wave)."""
+    from bubbleformer_amd import _lib as L
+    from bubbleformer_amd.ops import _p, _stream
+    lib = L.lib()
+    Fr = 3
+    g = torch.Generator(device="cuda").manual_seed(41)
+    wc = torch.zeros(Ci, 16, device="cuda")
+    wc[:, :4 * Co] = torch.randn(Ci, 4 * Co, device="cuda", generator=g) / 4
+    wc = wc.bfloat16()
+    pred = torch.randn(Fr, Co, 2 * h, 2 * w, device="cuda", generator=g)
+    y = torch.randn(Fr, Co, 2 * h, 2 * w, device="cuda", generator=g)
+    coef = 0.5 + torch.rand(Fr, Co, device="cuda", generator=g)
+    gs = torch.tensor([0.7], device="cuda")
+    dpred = coef[:, :, None, None] * gs * (pred - y)
+    S, P = h * w, Fr * h * w
+    ymap = (torch.randn(P, Ci, device="cuda", generator=g) * 1.5 + 0.2).bfloat16()
+    in_w, in_b = 1 + 0.2 * torch.randn(Ci, device="cuda", generator=g), 0.3 * torch.randn(Ci, device="cuda", generator=g)
+    yf = ymap.float().view(Fr, S, Ci)
+    mean, rstd = yf.mean(1).contiguous(), (yf.var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    dpm = torch.full((P, 16), float("nan"), device="cuda", dtype=torch.bfloat16)
+    dx = torch.full((P, Ci), float("nan"), device="cuda", dtype=torch.bfloat16)
+    dw, db = torch.full((Ci,), 2.0, device="cuda"), torch.full((Ci,), -1.0, device="cuda")
+    nws = 2 * Fr * Ci * (1 + (S // 16 + 15) // 16)          # totals + one row of partials per 256-row slice (bf_in_ws_floats covers it for long frames)
+    ws = torch.full((nws,), float("nan"), device="cuda")
+    src = (None, _p(pred), _p(y), _p(coef), _p(gs)) if fused_loss else (_p(dpred), None, None, None, None)
+    rc = lib.bf_debed_last_bwd_norm(1, *src, _p(wc), _p(dpm), _p(ymap), _p(mean), _p(rstd), _p(in_w), _p(in_b), _p(dx), _p(dw), _p(db),
+                                    Fr, Ci, Co, h, w, 16, _p(ws), nws, _stream())
+    L.check(rc, "debed_last_bwd_norm")
+    ref_pm = torch.zeros(P, 16, device="cuda")
+    ref_pm[:, :4 * Co] = dpred.view(Fr, Co, h, 2, w, 2).permute(0, 2, 4, 1, 3, 5).reshape(P, 4 * Co)       # n = co*4 + ky*2 + kx
+    ref_pm = ref_pm.bfloat16()
+    assert torch.equal(dpm, ref_pm)
+    yr = ymap.double().view(Fr, S, Ci).requires_grad_(True)
+    wr, br = in_w.double().requires_grad_(True), in_b.double().requires_grad_(True)
+    xh = (yr - yr.mean(1, keepdim=True)) / (yr.var(1, unbiased=False, keepdim=True) + 1e-5).sqrt()
+    out = torch.nn.functional.gelu(xh * wr + br).view(P, Ci) @ wc.double()
+    (out * ref_pm.double()).sum().backward()
+    assert torch.isfinite(dx.float()).all()
+    assert _rel(dx, yr.grad.view(P, Ci)) < 6e-3          # bf16 output rounding + the polynomial gelu'
+    assert _rel(dw - 2.0, wr.grad) < 2e-3 and _rel(db + 1.0, br.grad) < 2e-3
+    # declined: fp32, and a workspace that does not hold the slices
+    assert lib.bf_debed_last_bwd_norm(0, *src, _p(wc), _p(dpm), _p(ymap), _p(mean), _p(rstd), _p(in_w), _p(in_b), _p(dx), None, None,
+                                      Fr, Ci, Co, h, w, 16, _p(ws), nws, _stream()) == 1
+    assert lib.bf_debed_last_bwd_norm(1, *src, _p(wc), _p(dpm), _p(ymap), _p(mean), _p(rstd), _p(in_w), _p(in_b), _p(dx), None, None,
+                                      Fr, Ci, Co, h, w, 16, _p(ws), 2 * Fr * Ci, _stream()) == 1
+
+
 @pytest.mark.parametrize("cin,h2,w2", [(4, 96, 96), (3, 40, 32), (4, 33, 16)])
 def test_embed_first_stage_one_pass_with_statistics(cin, h2, w2):
     """bf_embed_first: 2x2 patches of the fp32 NCHW clip x the [C0][16] convolution weight (layers/patching.py:30-48, first stage) in one
