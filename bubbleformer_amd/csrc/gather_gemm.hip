@@ -1,0 +1,333 @@
+// out[p][n] = sum_{q, c} f(map[pixel(p, q)][c]) * W[(q, c)][n] for the 2x2/stride-2 stages at E/4 = 96 channels: the HMLPEmbed
+// convolutions after the first (layers/patching.py:30-56; f = GELU(InstanceNorm affine), folded into the operand) and the data
+// gradients of the HMLPDebed transposed convolutions (layers/patching.py:92-104 under autograd; f = identity).  p runs over the coarse
+// grid [F][gh][gw], pixel(p, q) = (2y + q / 2, 2x + q % 2) on the fine grid, K = 4 * 96 = 384, N = 96.
+//
+// These are the GEMMs over the largest maps of the step (226 MB at the bench shape) with only 96 output columns: 43 FLOP per byte of
+// the map -- HBM-bound at any decent matrix rate -- and a tile-per-workgroup kernel that stages both operands through registers ran
+// them at ~2.3 TB/s.  Here the whole [96][384] weight sits in LDS (75 KB: two workgroups per CU) and is the MFMA A operand (plain
+// 16-byte LDS reads); a wave owns 32 coarse rows, fetches the map rows STRAIGHT into B-operand registers (lane = coarse row, 8
+// consecutive channels: 16-byte loads, one 2x2 position ahead of the products), applies f there -- each element exactly once --
+// and leaves through v_permlane16_swap with 8 consecutive output columns per lane (16-byte stores).  Waves never meet after the
+// weight load.
+#include "bf_common.h"
+#include <algorithm>
+
+namespace {
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+constexpr int GW = 4;                                   // waves per workgroup
+
+struct GatherArgs {
+    const bf16* map;          // [F][2 gh][2 gw][C0]
+    const bf16* w;            // kn: [4 C0][N] (n contiguous), else [N][4 C0] (k contiguous)
+    bf16* out;                // [F gh gw][N]
+    const float *sc, *sh;     // [F][C0] (PRO) : f(x) = gelu(x sc + sh)
+    int w_kn, F, gh, gw, tiles;
+};
+
+template <int NCB, int NNB> constexpr int gather_lds_bytes() { return 16 * NNB * (64 * NCB + 8) * 2; }
+
+template <int NCB, int NNB, bool PRO>
+__global__ void __launch_bounds__(64 * GW, 2) gather_gemm_kernel(GatherArgs a) {
+    constexpr int C0 = 16 * NCB, N = 16 * NNB, K = 4 * C0, LDK = K + 8, NS = C0 / 32;
+    static_assert(C0 % 32 == 0 && NNB % 2 == 0, "32-channel slabs, column blocks in pairs");
+    extern __shared__ __attribute__((aligned(16))) char smem_gg[];
+    bf16* Wt = reinterpret_cast<bf16*>(smem_gg);                     // [N][LDK]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, g = lane >> 4;
+    if (a.w_kn) {
+        for (int t = tid; t < K * (N / 8); t += 64 * GW) {          // 16-byte pieces of a k-row, scattered down a column of Wt
+            const int k = t / (N / 8), n0 = 8 * (t - k * (N / 8));
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(a.w + (long)k * N + n0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Wt[(n0 + j) * LDK + k] = v[j];
+        }
+    } else {
+        for (int t = tid; t < N * (K / 8); t += 64 * GW) {
+            const int n = t / (K / 8), k0 = 8 * (t - n * (K / 8));
+            *reinterpret_cast<bf16x8*>(Wt + n * LDK + k0) = *reinterpret_cast<const bf16x8*>(a.w + (long)n * K + k0);
+        }
+    }
+    __syncthreads();
+    // this wave's run of 32-row tiles (contiguous: mostly one frame, whose affine then stays in registers)
+    const int nw = gridDim.x * GW, wv = blockIdx.x * GW + wave;
+    const int t_beg = (int)((long)a.tiles * wv / nw), t_end = (int)((long)a.tiles * (wv + 1) / nw);
+    if (t_beg >= t_end) return;
+    const unsigned gw = (unsigned)a.gw, tpf = (unsigned)(a.gh * a.gw) / 32u;
+    float csc[PRO ? NS : 1][8], csh[PRO ? NS : 1][8];
+    int cf = -1;
+    // B-operand registers of one 2x2 position: [row block][slab], lane (coarse row i16, channels 32 s + 8 g ..)
+    bf16x8 cur[2][NS], nxt[2][NS];
+    auto issue = [&](int tt, int q, bf16x8 (&dst)[2][NS]) __attribute__((always_inline)) {
+        const unsigned f = (unsigned)tt / tpf, tl = (unsigned)tt - f * tpf;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const unsigned pl = 32u * tl + 16u * rb, y = pl / gw, x0 = pl - y * gw;     // a 16-row block lies inside one image row (gw % 16 == 0)
+            const long pix = ((long)f * (2 * a.gh) + 2 * y + (q >> 1)) * (2L * a.gw) + 2 * (x0 + i16) + (q & 1);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) dst[rb][s] = *reinterpret_cast<const bf16x8*>(a.map + pix * C0 + 32 * s + 8 * g);
+        }
+    };
+    issue(t_beg, 0, cur);
+    for (int tt = t_beg; tt < t_end; ++tt) {
+        if (PRO) {
+            const int f = (int)((unsigned)tt / tpf);
+            if (f != cf) {
+                cf = f;
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { csc[s][j] = a.sc[(long)f * C0 + 32 * s + 8 * g + j]; csh[s][j] = a.sh[(long)f * C0 + 32 * s + 8 * g + j]; }
+            }
+        }
+        f32x4 acc[NNB][2];
+#pragma unroll
+        for (int nb = 0; nb < NNB; ++nb) { acc[nb][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[nb][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q < 3) issue(tt, q + 1, nxt);
+            else if (tt + 1 < t_end) issue(tt + 1, 0, nxt);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                bf16x8 fb[2];
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    if (PRO) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) fb[rb][j] = (bf16)gelu_fast(fmaf((float)cur[rb][s][j], csc[s][j], csh[s][j]));
+                    } else fb[rb] = cur[rb][s];
+                }
+#pragma unroll
+                for (int nb = 0; nb < NNB; ++nb) {
+                    const bf16x8 aw = *reinterpret_cast<const bf16x8*>(Wt + (16 * nb + i16) * LDK + C0 * q + 32 * s + 8 * g);
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb) acc[nb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw, fb[rb], acc[nb][rb], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);          // or the scheduler lifts every slab's 6 weight reads to the top of the tile: 288 registers
+            }
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) cur[rb][s] = nxt[rb][s];
+        }
+        // acc[nb][rb]: coarse row 16 rb + i16, columns 16 nb + 4 g .. +3.  Exchanging the odd lane rows of block 2 pp with the even lane
+        // rows of block 2 pp + 1 leaves 8 consecutive columns at 32 pp + 16 (g & 1) + 8 (g >> 1)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            bf16* dst = a.out + ((long)tt * 32 + 16 * rb + i16) * N + (g & 1) * 16 + (g >> 1) * 8;
+#pragma unroll
+            for (int pp = 0; pp < NNB / 2; ++pp) {
+                bf16x8 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const u32x2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * pp][rb][r]), __float_as_uint(acc[2 * pp + 1][rb][r]), false, false);
+                    o[r] = (bf16)__uint_as_float(sw[0]); o[4 + r] = (bf16)__uint_as_float(sw[1]);
+                }
+                *reinterpret_cast<bf16x8*>(dst + 32 * pp) = o;
+            }
+        }
+    }
+}
+
+// The transposed direction (HMLPDebed's ConvTranspose2d(k=2, s=2) stages, layers/patching.py:80-104): map[pixel(p, q)][c] = sum_k f(a[p][k]) *
+// W[(q, c)][k], K = 96, 4 x 96 output columns scattered to the 2x2 positions.  Same organisation: the [384][96] weight in LDS, a wave
+// fetches and transforms its 32 coarse rows once and sweeps the four positions; 16-byte stores of 8 consecutive channels.  Optionally
+// leaves the InstanceNorm statistics of what it stored as {mean, centred second moment} per tile (128 fine pixels) and channel, in the
+// slice layout bf_in_stats_merge_slices finishes -- the 226 MB map is not read again for them.
+struct ScatterArgs {
+    const bf16* a;            // [F gh gw][K]
+    const bf16* w;            // [4 C0][K] (k contiguous)
+    bf16* map;                // [F][2 gh][2 gw][C0]
+    const float *sc, *sh;     // [F][K] (PRO)
+    float* part;              // optional: [F][tiles per frame][C0][2]
+    int F, gh, gw, tiles;
+};
+template <int NKB, int NCB> constexpr int scatter_lds_bytes() { return 4 * 16 * NCB * (32 * NKB + 8) * 2; }
+
+__device__ __forceinline__ float row16_total(float v) {      // sum over the 16 lanes of a row, in every lane (DPP: xor 1, xor 2, half mirror, mirror)
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
+template <int NKB, int NCB, bool PRO>
+__global__ void __launch_bounds__(64 * GW, 2) scatter_gemm_kernel(ScatterArgs a) {
+    constexpr int K = 32 * NKB, C0 = 16 * NCB, LDK = K + 8;
+    static_assert(NCB % 2 == 0, "column blocks in pairs");
+    extern __shared__ __attribute__((aligned(16))) char smem_sg[];
+    bf16* Wt = reinterpret_cast<bf16*>(smem_sg);                     // [4 C0][LDK]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, g = lane >> 4;
+    for (int t = tid; t < 4 * C0 * (K / 8); t += 64 * GW) {
+        const int n = t / (K / 8), k0 = 8 * (t - n * (K / 8));
+        *reinterpret_cast<bf16x8*>(Wt + n * LDK + k0) = *reinterpret_cast<const bf16x8*>(a.w + (long)n * K + k0);
+    }
+    __syncthreads();
+    const int nw = gridDim.x * GW, wv = blockIdx.x * GW + wave;
+    const int t_beg = (int)((long)a.tiles * wv / nw), t_end = (int)((long)a.tiles * (wv + 1) / nw);
+    if (t_beg >= t_end) return;
+    const unsigned gw = (unsigned)a.gw, tpf = (unsigned)(a.gh * a.gw) / 32u;
+    const int c8 = (g & 1) * 16 + (g >> 1) * 8;                      // + 32 pp: the 8 consecutive channels this lane stores
+    bf16x8 cur[2][NKB], nxt[2][NKB];
+    auto issue = [&](int tt, bf16x8 (&dst)[2][NKB]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int s = 0; s < NKB; ++s) dst[rb][s] = *reinterpret_cast<const bf16x8*>(a.a + ((long)tt * 32 + 16 * rb + i16) * K + 32 * s + 8 * g);
+    };
+    issue(t_beg, cur);
+    for (int tt = t_beg; tt < t_end; ++tt) {
+        const unsigned f = (unsigned)tt / tpf, tl = (unsigned)tt - f * tpf;
+        if (tt + 1 < t_end) issue(tt + 1, nxt);
+        bf16x8 fb[2][NKB];
+#pragma unroll
+        for (int s = 0; s < NKB; ++s) {
+            if (PRO) {
+                float cs[8], ch[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { cs[j] = a.sc[(long)f * K + 32 * s + 8 * g + j]; ch[j] = a.sh[(long)f * K + 32 * s + 8 * g + j]; }
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) fb[rb][s][j] = (bf16)gelu_fast(fmaf((float)cur[rb][s][j], cs[j], ch[j]));
+            } else { fb[0][s] = cur[0][s]; fb[1][s] = cur[1][s]; }
+        }
+        long pix0[2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const unsigned pl = 32u * tl + 16u * rb, y = pl / gw, x0 = pl - y * gw;
+            pix0[rb] = ((long)f * (2 * a.gh) + 2 * y) * (2L * a.gw) + 2 * (x0 + i16);
+        }
+        float ssum[NCB / 2][8], ssq[NCB / 2][8];
+#pragma unroll
+        for (int pp = 0; pp < NCB / 2; ++pp)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ssum[pp][j] = ssq[pp][j] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 acc[NCB][2];
+#pragma unroll
+            for (int nb = 0; nb < NCB; ++nb) { acc[nb][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[nb][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int s = 0; s < NKB; ++s)
+#pragma unroll
+                for (int nb = 0; nb < NCB; ++nb) {
+                    const bf16x8 aw = *reinterpret_cast<const bf16x8*>(Wt + (C0 * q + 16 * nb + i16) * LDK + 32 * s + 8 * g);
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb) acc[nb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw, fb[rb][s], acc[nb][rb], 0, 0, 0);
+                }
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                bf16* dst = a.map + (pix0[rb] + (long)(q >> 1) * (2L * a.gw) + (q & 1)) * C0 + c8;
+#pragma unroll
+                for (int pp = 0; pp < NCB / 2; ++pp) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const u32x2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * pp][rb][r]), __float_as_uint(acc[2 * pp + 1][rb][r]), false, false);
+                        o[r] = (bf16)__uint_as_float(sw[0]); o[4 + r] = (bf16)__uint_as_float(sw[1]);
+                    }
+                    *reinterpret_cast<bf16x8*>(dst + 32 * pp) = o;
+                    if (a.part) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { const float v = (float)o[j]; ssum[pp][j] += v; ssq[pp][j] = fmaf(v, v, ssq[pp][j]); }      // of the values as stored
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (a.part) {      // this tile = one slice of 128 fine pixels
+            float2* o2 = reinterpret_cast<float2*>(a.part) + ((long)f * tpf + tl) * C0 + c8;
+#pragma unroll
+            for (int pp = 0; pp < NCB / 2; ++pp)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float t1 = row16_total(ssum[pp][j]), t2 = row16_total(ssq[pp][j]);
+                    const float mu = t1 * (1.0f / 128.0f);
+                    if (i16 == 0) o2[32 * pp + j] = make_float2(mu, fmaxf(t2 - t1 * mu, 0.f));
+                }
+        }
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int s = 0; s < NKB; ++s) cur[rb][s] = nxt[rb][s];
+    }
+}
+
+}  // namespace
+
+// 0 = done, 1 = shape not covered (nothing launched)
+extern "C" int bf_gather_gemm(int dtype, const void* map, const void* w, int w_kn, const float* sc, const float* sh, void* out, int F, int gh,
+                              int gw, int C0, int N, bf_stream_t stream) {
+    if (dtype != BF_DTYPE_BF16 || C0 != 96 || N != 96) return 1;
+    if (F <= 0 || gh <= 0 || gw <= 0 || gw % 16 || ((long)gh * gw) % 32) return 1;
+    static const bool off = bf_knob("BF_GATHER_GEMM", 1) == 0;
+    if (off) return 1;
+    BF_REQUIRE(map && w && out && (!sc == !sh), "bf_gather_gemm: bad arguments");
+    BF_REQUIRE((((uintptr_t)map | (uintptr_t)w | (uintptr_t)out) & 15) == 0, "bf_gather_gemm: operands must be 16-byte aligned");
+    const long tiles = (long)F * gh * gw / 32;
+    BF_REQUIRE(tiles < (1L << 30), "bf_gather_gemm: too many rows");
+    hipStream_t st = (hipStream_t)stream;
+    int cus = 256, dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int grid = (int)std::min<long>((tiles + GW - 1) / GW, 2L * cus);
+    GatherArgs a{(const bf16*)map, (const bf16*)w, (bf16*)out, sc, sh, w_kn, F, gh, gw, (int)tiles};
+    constexpr int lds = gather_lds_bytes<6, 6>();
+    const double rows = (double)F * gh * gw;
+    BfProfScope prof(st, sc ? "gather_gemm<gelu>" : "gather_gemm<plain>", 2.0 * rows * 4 * C0 * N, rows * (4.0 * C0 + N) * 2.0);
+#define BF_GG_GO(PRO)                                                                                                                      \
+    do {                                                                                                                                  \
+        static bool attr_done = false;                                                                                                    \
+        if (!attr_done) {                                                                                                                 \
+            hipError_t e_ = hipFuncSetAttribute((const void*)gather_gemm_kernel<6, 6, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            if (e_ != hipSuccess) return bf_fail(e_, __FILE__, __LINE__);                                                                 \
+            attr_done = true;                                                                                                             \
+        }                                                                                                                                 \
+        hipLaunchKernelGGL((gather_gemm_kernel<6, 6, PRO>), dim3(grid), dim3(64 * GW), lds, st, a);                                       \
+    } while (0)
+    if (sc) BF_GG_GO(true); else BF_GG_GO(false);
+#undef BF_GG_GO
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
+// 0 = done, 1 = shape not covered (nothing launched).  stat_part (optional): the slice partials, 128-row slices, at ws + 2*frames*C0 of the
+// workspace bf_in_stats_merge_slices(..., rows = 128, ws) takes
+extern "C" int bf_scatter_gemm(int dtype, const void* a, const void* w, const float* sc, const float* sh, void* map, float* stat_part, int F,
+                               int gh, int gw, int K, int C0, bf_stream_t stream) {
+    if (dtype != BF_DTYPE_BF16 || C0 != 96 || K != 96) return 1;
+    if (F <= 0 || gh <= 0 || gw <= 0 || gw % 16 || ((long)gh * gw) % 32) return 1;
+    static const bool off = bf_knob("BF_SCATTER_GEMM", 1) == 0;
+    if (off) return 1;
+    BF_REQUIRE(a && w && map && (!sc == !sh), "bf_scatter_gemm: bad arguments");
+    BF_REQUIRE((((uintptr_t)a | (uintptr_t)w | (uintptr_t)map) & 15) == 0, "bf_scatter_gemm: operands must be 16-byte aligned");
+    const long tiles = (long)F * gh * gw / 32;
+    BF_REQUIRE(tiles < (1L << 30), "bf_scatter_gemm: too many rows");
+    hipStream_t st = (hipStream_t)stream;
+    int cus = 256, dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int grid = (int)std::min<long>((tiles + GW - 1) / GW, 2L * cus);
+    ScatterArgs sa{(const bf16*)a, (const bf16*)w, (bf16*)map, sc, sh, stat_part, F, gh, gw, (int)tiles};
+    constexpr int lds = scatter_lds_bytes<3, 6>();
+    const double rows = (double)F * gh * gw;
+    BfProfScope prof(st, sc ? "scatter_gemm<gelu>" : "scatter_gemm<plain>", 2.0 * rows * 4 * C0 * K, rows * (4.0 * C0 + K) * 2.0);
+#define BF_SG_GO(PRO)                                                                                                                      \
+    do {                                                                                                                                  \
+        static bool attr_done = false;                                                                                                    \
+        if (!attr_done) {                                                                                                                 \
+            hipError_t e_ = hipFuncSetAttribute((const void*)scatter_gemm_kernel<3, 6, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            if (e_ != hipSuccess) return bf_fail(e_, __FILE__, __LINE__);                                                                 \
+            attr_done = true;                                                                                                             \
+        }                                                                                                                                 \
+        hipLaunchKernelGGL((scatter_gemm_kernel<3, 6, PRO>), dim3(grid), dim3(64 * GW), lds, st, sa);                                     \
+    } while (0)
+    if (sc) BF_SG_GO(true); else BF_SG_GO(false);
+#undef BF_SG_GO
+    BF_CHECK_LAUNCH();
+    return 0;
+}

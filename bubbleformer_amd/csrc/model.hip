@@ -1187,12 +1187,17 @@ extern "C" int bf_embed_fwd(const bf_dims* dims, const bf_embed_params* p, const
             }
         } else {
             const int cp = sv.C[i - 1];
-            bf_operand A = op_plain(sv.y[i - 1], cp, BF_LAY_KC);
-            op_gather(A, sv.gw[i], sv.gh[i], cp);
-            op_affine(A, BF_PRO_AFFINE_GELU, sv.sc[i - 1], sv.sh[i - 1], (long)sv.gh[i] * sv.gw[i], cp);
-            bf_operand Bo = op_plain(sv.wc[i], 4L * cp, BF_LAY_KC);
-            bf_epilogue e = epi_store(sv.y[i], sv.C[i]);
-            TRY(bf_gemm(d.dtype, (int)sv.P[i], sv.C[i], 4 * cp, &A, &Bo, &e, 1, st));
+            // the 96 -> 96 channel stages stream their map once through a weight-stationary kernel (gather_gemm.hip)
+            const int grc = bf_gather_gemm(d.dtype, sv.y[i - 1], sv.wc[i], 0, sv.sc[i - 1], sv.sh[i - 1], sv.y[i], (int)d.F, sv.gh[i], sv.gw[i], cp, sv.C[i], st);
+            if (grc < 0) return grc;
+            if (grc == 1) {
+                bf_operand A = op_plain(sv.y[i - 1], cp, BF_LAY_KC);
+                op_gather(A, sv.gw[i], sv.gh[i], cp);
+                op_affine(A, BF_PRO_AFFINE_GELU, sv.sc[i - 1], sv.sh[i - 1], (long)sv.gh[i] * sv.gw[i], cp);
+                bf_operand Bo = op_plain(sv.wc[i], 4L * cp, BF_LAY_KC);
+                bf_epilogue e = epi_store(sv.y[i], sv.C[i]);
+                TRY(bf_gemm(d.dtype, (int)sv.P[i], sv.C[i], 4 * cp, &A, &Bo, &e, 1, st));
+            }
         }
         const bool last = i == n - 1;
         const bool film = last && d.nfluid > 0;
@@ -1336,11 +1341,27 @@ extern "C" int bf_debed_fwd(const bf_dims* dims, const bf_debed_params* p, const
         bf_operand A = op_plain(i == 0 ? x : sv.y[i - 1], cin, BF_LAY_KC);
         if (i > 0) op_affine(A, BF_PRO_AFFINE_GELU, sv.sc[i - 1], sv.sh[i - 1], (long)sv.gh[i] * sv.gw[i], cin);
         if (!last) {
-            bf_operand Bo = op_plain(sv.wc[i], cin, BF_LAY_KC);
-            bf_epilogue e = epi_store(sv.y[i], co);
-            epi_scatter(e, sv.gw[i], sv.gh[i], co);
-            TRY(bf_gemm(d.dtype, (int)sv.Pin[i], 4 * co, cin, &A, &Bo, &e, 1, st));
-            TRY(bf_in_stats(d.dtype, sv.y[i], (int)d.F, 4 * sv.gh[i] * sv.gw[i], co, p->in_w[i], p->in_b[i], nullptr, 1, nullptr, sv.mean[i],
+            // the 96 -> 4 x 96 channel stages: one streaming kernel that also leaves the InstanceNorm slice partials of the map it writes
+            // (gather_gemm.hip); the statistics then need no second pass over the map
+            const int S4 = 4 * sv.gh[i] * sv.gw[i];
+            const bool part_ok = i > 0 && S4 % 128 == 0 &&
+                                 bf_in_ws_floats(d.dtype, (int)d.F, S4, co) >= (int64_t)2 * d.F * co * (1 + S4 / 128);
+            const int src = i > 0 ? bf_scatter_gemm(d.dtype, sv.y[i - 1], sv.wc[i], sv.sc[i - 1], sv.sh[i - 1], sv.y[i],
+                                                    part_ok ? sc.in_ws + (size_t)2 * d.F * co : nullptr, (int)d.F, sv.gh[i], sv.gw[i], cin, co, st) : 1;
+            if (src < 0) return src;
+            if (src == 0 && part_ok) {
+                const int mrc = bf_in_stats_merge_slices(d.dtype, (int)d.F, S4, co, 128, p->in_w[i], p->in_b[i], nullptr, 1, nullptr, sv.mean[i], sv.rstd[i],
+                                                         sv.sc[i], sv.sh[i], sc.in_ws, st);
+                if (mrc < 0) return mrc;
+                if (mrc == 0) continue;
+            }
+            if (src == 1) {
+                bf_operand Bo = op_plain(sv.wc[i], cin, BF_LAY_KC);
+                bf_epilogue e = epi_store(sv.y[i], co);
+                epi_scatter(e, sv.gw[i], sv.gh[i], co);
+                TRY(bf_gemm(d.dtype, (int)sv.Pin[i], 4 * co, cin, &A, &Bo, &e, 1, st));
+            }
+            TRY(bf_in_stats(d.dtype, sv.y[i], (int)d.F, S4, co, p->in_w[i], p->in_b[i], nullptr, 1, nullptr, sv.mean[i],
                             sv.rstd[i], sv.sc[i], sv.sh[i], sc.in_ws, st));
         } else {
             if (target) ZERO(sv.lossbuf, (size_t)d.F * d.cout * 2 * 8);
@@ -1435,11 +1456,15 @@ extern "C" int bf_debed_bwd(const bf_dims* dims, const bf_debed_params* p, const
             }
             TRY(bf_wgrad_unprep(2, sc.wg, g->conv_w[i], N4, cin, cin, 0, ss));
             {
-                bf_operand A = op_plain(dy, co, BF_LAY_KC);
-                op_gather(A, sv.gw[i], sv.gh[i], co);
-                bf_operand Bo = op_plain(sv.wc[i], cin, BF_LAY_XC);
-                bf_epilogue e = epi_store(dact, cin);
-                TRY(bf_gemm(d.dtype, (int)sv.Pin[i], cin, N4, &A, &Bo, &e, 1, st));
+                const int grc = bf_gather_gemm(d.dtype, dy, sv.wc[i], 1, nullptr, nullptr, dact, (int)d.F, sv.gh[i], sv.gw[i], co, cin, st);
+                if (grc < 0) return grc;
+                if (grc == 1) {
+                    bf_operand A = op_plain(dy, co, BF_LAY_KC);
+                    op_gather(A, sv.gw[i], sv.gh[i], co);
+                    bf_operand Bo = op_plain(sv.wc[i], cin, BF_LAY_XC);
+                    bf_epilogue e = epi_store(dact, cin);
+                    TRY(bf_gemm(d.dtype, (int)sv.Pin[i], cin, N4, &A, &Bo, &e, 1, st));
+                }
             }
         }
         if (i > 0) {

@@ -234,6 +234,19 @@ int bf_in_stats_merge_slices(int dtype, int frames, int S, int C, int rows, cons
  * weight.  dwprep [C0][Kp] is WRITTEN (bf_wgrad_unprep folds it into the gradient), d_in_w / d_in_b [C0] are accumulated (optional).
  * ws: bf_embed_tail_ws_floats floats.  Returns 1 (nothing launched) for shapes it does not take: fp32, C0 != 96, C1 not in {96, 192}, Kp != 16,
  * gw1 % 16, gh1*gw1 % 128, or a workspace that is too small. */
+/* The 2x2 / stride-2 stages at 96 channels as one streaming GEMM: out[p][n] = sum_{q, c} f(map[pixel(p, q)][c]) * W[(q, c)][n], p over the
+ * coarse grid [frames][gh][gw], pixel(p, q) = (2y + q/2, 2x + q%2) of the fine grid [frames][2gh][2gw][C0].  f = GELU(x * sc + sh)
+ * (sc / sh [frames][C0]: the HMLPEmbed convolutions after the first, layers/patching.py:30-56) or the identity (sc = sh = NULL: the data
+ * gradients of the HMLPDebed transposed convolutions).  w: [4*C0][N] (w_kn = 1) or [N][4*C0] (w_kn = 0).  Returns 1 (nothing launched)
+ * for shapes it does not take: fp32, C0 != 96, N != 96, gw % 16, gh*gw % 32. */
+int bf_gather_gemm(int dtype, const void* map, const void* w, int w_kn, const float* sc, const float* sh, void* out, int frames, int gh,
+                   int gw, int C0, int N, bf_stream_t stream);
+/* ... and the transposed direction (HMLPDebed's ConvTranspose2d(k=2, s=2) stages, layers/patching.py:80-104): map[pixel(p, q)][c] =
+ * sum_k f(a[p][k]) * w[q*C0 + c][k], a [frames*gh*gw][K], map [frames][2gh][2gw][C0].  stat_part (optional): {mean, centred second moment} of the
+ * map as stored per 128-pixel slice, [frames][gh*gw/32][C0][2]; finished by bf_in_stats_merge_slices(..., rows = 128, ws) with
+ * ws + 2*frames*C0 == stat_part.  Returns 1 (nothing launched) for: fp32, K != 96, C0 != 96, gw % 16, gh*gw % 32. */
+int bf_scatter_gemm(int dtype, const void* a, const void* w, const float* sc, const float* sh, void* map, float* stat_part, int frames, int gh,
+                    int gw, int K, int C0, bf_stream_t stream);
 int64_t bf_embed_tail_ws_floats(int frames, int gh1, int gw1, int C0, int Kp);
 int bf_embed_tail_bwd(int dtype, const void* dy1, const void* w1c, const void* y0, const void* patches, const void* w0c, const float* sc,
                       const float* sh, const float* mean, const float* rstd, const float* in_w, float* dwprep, float* d_in_w, float* d_in_b,

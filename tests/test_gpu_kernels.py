@@ -827,6 +827,83 @@ def test_embed_first_stage_one_pass_with_statistics(cin, h2, w2):
         assert _rel(a, r) < 1e-5
 
 
+@pytest.mark.parametrize("Fr,gh,gw", [(3, 2, 16), (2, 12, 32), (7, 48, 48)])
+@pytest.mark.parametrize("variant", ["gelu_nk", "plain_kn"])
+def test_gather_gemm_2x2_stage(Fr, gh, gw, variant):
+    """bf_gather_gemm (gather_gemm.hip): rows of 2x2 / stride-2 patches of a 96-channel map times a [384][96] weight, with GELU(x * sc + sh)
+    folded into the operand (the HMLPEmbed stages, weight stored [n][k]) or plain (the HMLPDebed data gradients, weight stored [k][n]),
+    against fp64 torch on the same bf16 operands.  One tile in all, runs that cross frames (7 frames x 72 tiles over 512 x 4 waves), 16-row
+    blocks in the middle of an image row."""
+    from bubbleformer_amd import _lib as L
+    from bubbleformer_amd.ops import _p, _stream
+    lib = L.lib()
+    C0, N = 96, 96
+    g = torch.Generator(device="cuda").manual_seed(43)
+    fine = torch.randn(Fr, 2 * gh, 2 * gw, C0, device="cuda", generator=g).bfloat16()
+    W = (torch.randn(4 * C0, N, device="cuda", generator=g) / 16).bfloat16()              # [k = (2 ky + kx) * C0 + c][n]
+    sc, sh = 0.5 + torch.rand(Fr, C0, device="cuda", generator=g), 0.3 * torch.randn(Fr, C0, device="cuda", generator=g)
+    out = torch.full((Fr * gh * gw, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    x = fine.double()
+    if variant == "gelu_nk":
+        x = torch.nn.functional.gelu(x * sc.double()[:, None, None] + sh.double()[:, None, None]).bfloat16().double()      # the operand as the MFMA sees it
+        wdev = W.t().contiguous()
+        rc = lib.bf_gather_gemm(1, _p(fine), _p(wdev), 0, _p(sc), _p(sh), _p(out), Fr, gh, gw, C0, N, _stream())
+    else:
+        rc = lib.bf_gather_gemm(1, _p(fine), _p(W), 1, None, None, _p(out), Fr, gh, gw, C0, N, _stream())
+    L.check(rc, "gather_gemm")
+    A = x.view(Fr, gh, 2, gw, 2, C0).permute(0, 1, 3, 2, 4, 5).reshape(Fr * gh * gw, 4 * C0)
+    ref = A @ W.double()
+    assert torch.isfinite(out.float()).all()
+    assert _rel(out, ref) < 4e-3
+    # no misplaced row / 8-column group (the gelu form: polynomial vs exact GELU flips the bf16 rounding of a few operands)
+    assert float(((out.double() - ref).abs() / (ref.abs() + 0.05 * ref.abs().mean())).max()) < (0.2 if variant == "gelu_nk" else 0.06)
+    assert lib.bf_gather_gemm(0, _p(fine), _p(W), 1, None, None, _p(out), Fr, gh, gw, C0, N, _stream()) == 1          # fp32
+    assert lib.bf_gather_gemm(1, _p(fine), _p(W), 1, None, None, _p(out), Fr, gh, gw + 8, C0, N, _stream()) == 1      # gw % 16
+
+
+@pytest.mark.parametrize("Fr,gh,gw", [(3, 2, 16), (2, 12, 32), (7, 48, 48)])
+@pytest.mark.parametrize("pro", [True, False])
+def test_scatter_gemm_2x2_stage_with_statistics(Fr, gh, gw, pro):
+    """bf_scatter_gemm (gather_gemm.hip): the transposed 2x2 / stride-2 stage at 96 channels -- rows of a coarse map (GELU(x * sc + sh) folded
+    in, or plain) times a [4 x 96][96] weight, scattered to the four positions of the fine map -- against fp64 torch on the same bf16
+    operands; and the slice partials it leaves, merged by bf_in_stats_merge_slices, against bf_in_stats on the stored map."""
+    from bubbleformer_amd import _lib as L
+    from bubbleformer_amd.ops import _p, _stream
+    lib = L.lib()
+    K, C0 = 96, 96
+    g = torch.Generator(device="cuda").manual_seed(47)
+    P, S4 = Fr * gh * gw, 4 * gh * gw
+    a = torch.randn(P, K, device="cuda", generator=g).bfloat16()
+    W = (torch.randn(4 * C0, K, device="cuda", generator=g) / 8).bfloat16()              # [n = (2 ky + kx) * C0 + c][k]
+    sc, sh = 0.5 + torch.rand(Fr, K, device="cuda", generator=g), 0.3 * torch.randn(Fr, K, device="cuda", generator=g)
+    fine = torch.full((Fr, 2 * gh, 2 * gw, C0), float("nan"), device="cuda", dtype=torch.bfloat16)
+    nsl = gh * gw // 32
+    ws = torch.zeros(2 * Fr * C0 * (1 + max(nsl, (S4 + 95) // 96)), device="cuda")
+    part = ws[2 * Fr * C0:]
+    x = a.double()
+    if pro:
+        x = torch.nn.functional.gelu(x.view(Fr, gh * gw, K) * sc.double()[:, None] + sh.double()[:, None]).view(P, K).bfloat16().double()
+    rc = lib.bf_scatter_gemm(1, _p(a), _p(W), _p(sc) if pro else None, _p(sh) if pro else None, _p(fine), _p(part), Fr, gh, gw, K, C0, _stream())
+    L.check(rc, "scatter_gemm")
+    ref = (x @ W.double().t()).view(Fr, gh, gw, 2, 2, C0).permute(0, 1, 3, 2, 4, 5).reshape(Fr, 2 * gh, 2 * gw, C0)
+    assert torch.isfinite(fine.float()).all()
+    assert _rel(fine, ref) < 4e-3
+    assert float(((fine.double() - ref).abs() / (ref.abs() + 0.05 * ref.abs().mean())).max()) < (0.2 if pro else 0.06)
+    # statistics of the map AS STORED
+    w_, b_ = 1 + 0.1 * torch.randn(C0, device="cuda", generator=g), 0.1 * torch.randn(C0, device="cuda", generator=g)
+    yf = fine.float().view(Fr, S4, C0)
+    if lib.bf_in_ws_floats(1, Fr, S4, C0) >= 2 * Fr * C0 * (1 + nsl):          # long frames: the sliced workspace holds the 128-pixel slices
+        got = [torch.empty(Fr, C0, device="cuda") for _ in range(4)]
+        L.check(lib.bf_in_stats_merge_slices(1, Fr, S4, C0, 128, _p(w_), _p(b_), None, 1, None, *[_p(t) for t in got], _p(ws), _stream()), "merge")
+        assert _rel(got[0], yf.mean(1)) < 1e-5 and _rel(got[1], (yf.var(1, unbiased=False) + 1e-5).rsqrt()) < 1e-5
+    pm = part[:Fr * nsl * C0 * 2].view(Fr, nsl, C0, 2)
+    # (a slice is 32 coarse rows x 4 positions: equal counts, so the frame mean is the mean of the slice means)
+    tot_mean = pm[..., 0].mean(1)
+    assert _rel(tot_mean, yf.mean(1)) < 1e-5
+    assert lib.bf_scatter_gemm(0, _p(a), _p(W), None, None, _p(fine), None, Fr, gh, gw, K, C0, _stream()) == 1          # fp32
+    assert lib.bf_scatter_gemm(1, _p(a), _p(W), None, None, _p(fine), None, Fr, gh, gw + 8, K, C0, _stream()) == 1      # gw % 16
+
+
 @pytest.mark.parametrize("Fr,gh1,gw1,C1", [(3, 8, 16, 96), (2, 12, 32, 192), (5, 48, 48, 96)])
 def test_embed_backward_tail_one_pass(Fr, gh1, gw1, C1):
     """bf_embed_tail_bwd (embed_tail.hip): the stage-1 data gradient, GELU', the stage-0 InstanceNorm backward and the stage-0 weight
