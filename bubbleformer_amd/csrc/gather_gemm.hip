@@ -16,7 +16,18 @@
 namespace {
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
 constexpr int GW = 4;                                   // waves per workgroup
+// transposing read of a 4-row x 16-col block of a bf16 LDS tile: lane i16 of the 16-lane group gets column c0 + i16 of rows r0..r0+3
+__device__ __forceinline__ s16x4 tr4g(const bf16* tile, int ld, int r0, int c0, int lane) {
+    const int i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tile + (r0 + q) * ld + c0 + 4 * p));
+}
+__device__ __forceinline__ bf16x8 cat8(s16x4 lo, s16x4 hi) {
+    s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
 
 struct GatherArgs {
     const bf16* map;          // [F][2 gh][2 gw][C0]
@@ -257,6 +268,115 @@ __global__ void __launch_bounds__(64 * GW, 2) scatter_gemm_kernel(ScatterArgs a)
     }
 }
 
+// The weight gradients of the same stages: dW[(q, c)][k] = sum_p ff(fine[pixel(p, q)][c]) * fc(coarse[p][k]) -- the fine map gathered,
+// the coarse rows plain, either side optionally through GELU(x * sc + sh) (the embed stages transform the fine side, the debed stages the
+// coarse side).  A reduction over hundreds of thousands of rows into a 384 x 96 result: 8 waves split the result (wave = 2x2 position
+// x half of the fine channels: 3 x 6 accumulator tiles), so every fine element is fetched and transformed by exactly one wave; the 32
+// coarse rows of a step are staged once per workgroup.  Both operands need the row index as the MFMA k-slot, i.e. transposed tiles:
+// they pass through LDS (wave-private for the fine side) and come back through ds_read_b64_tr_b16.  One barrier per step (the coarse
+// tile is double-buffered), global loads one step ahead.  Partials: one [384][96] fp32 slab per workgroup, summed in a fixed order.
+constexpr int WW = 8;                                   // waves per workgroup
+struct WgradArgs {
+    const bf16 *fine, *coarse;
+    const float *fsc, *fsh, *csc, *csh;                 // [F][96] each, or null
+    float* slab;                                        // [workgroups][384][96]
+    int F, gh, gw, rpf, steps;                          // runs per frame, 32-row steps per run
+};
+template <bool FPRO, bool CPRO>
+__global__ void __launch_bounds__(64 * WW, 4) gather_wgrad_kernel(WgradArgs a) {
+    constexpr int C = 96, HC = 48, LDF = HC + 8, LDC = C + 8;
+    __shared__ __attribute__((aligned(16))) bf16 ctile[2][32 * LDC];
+    __shared__ __attribute__((aligned(16))) bf16 ftile_all[WW][32 * LDF];
+    __shared__ float2 kf[C], kc[C];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, g = lane >> 4;
+    const int q = wave >> 1, half = wave & 1;
+    bf16* ftile = ftile_all[wave];
+    const int f = blockIdx.x / a.rpf, run = blockIdx.x - f * a.rpf;
+    if (FPRO) for (int c = tid; c < C; c += 64 * WW) kf[c] = make_float2(a.fsc[(long)f * C + c], a.fsh[(long)f * C + c]);
+    if (CPRO) for (int c = tid; c < C; c += 64 * WW) kc[c] = make_float2(a.csc[(long)f * C + c], a.csh[(long)f * C + c]);
+    __syncthreads();
+    const unsigned gw = (unsigned)a.gw;
+    // fine pieces of this wave: row lane / 2, channels 48 half + 8 (2 j + lane % 2), j = 0..2; coarse piece of this thread (tid < 384)
+    const int frow = lane >> 1, fc0 = 8 * (lane & 1);
+    const int crow = tid / 12, cch = 8 * (tid - 12 * crow);
+    const bool cth = tid < 32 * 12;
+    bf16x8 fr[3], cr;
+    auto issue = [&](int st) __attribute__((always_inline)) {
+        const unsigned tl = (unsigned)(run * a.steps + st);                      // 32-row tile inside the frame
+        const unsigned pl = 32u * tl + (unsigned)(frow & 16), y = pl / gw, x0 = pl - y * gw;      // a 16-row block lies inside one image row
+        const bf16* src = a.fine + (((long)f * (2 * a.gh) + 2 * y + (q >> 1)) * (2L * a.gw) + 2 * (x0 + (frow & 15)) + (q & 1)) * C + HC * half + fc0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) fr[j] = *reinterpret_cast<const bf16x8*>(src + 16 * j);
+        if (cth) cr = *reinterpret_cast<const bf16x8*>(a.coarse + ((long)f * a.gh * a.gw + 32L * tl + crow) * C + cch);
+    };
+    f32x4 acc[3][6];
+#pragma unroll
+    for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+        for (int kb = 0; kb < 6; ++kb) acc[cb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    issue(0);
+    for (int st = 0; st < a.steps; ++st) {
+        bf16* ct = ctile[st & 1];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            bf16x8 v = fr[j];
+            if (FPRO) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float2 k2 = kf[HC * half + fc0 + 16 * j + e]; v[e] = (bf16)gelu_fast(fmaf((float)v[e], k2.x, k2.y)); }
+            }
+            *reinterpret_cast<bf16x8*>(ftile + frow * LDF + fc0 + 16 * j) = v;
+        }
+        if (cth) {
+            bf16x8 v = cr;
+            if (CPRO) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float2 k2 = kc[cch + e]; v[e] = (bf16)gelu_fast(fmaf((float)v[e], k2.x, k2.y)); }
+            }
+            *reinterpret_cast<bf16x8*>(ct + crow * LDC + cch) = v;
+        }
+        __syncthreads();
+        if (st + 1 < a.steps) issue(st + 1);
+        // k-slot (g, jj) := row 4g + jj (jj < 4) / row 16 + 4g + jj - 4: the same order on both operands
+        bf16x8 fa[3];
+#pragma unroll
+        for (int cb = 0; cb < 3; ++cb) fa[cb] = cat8(tr4g(ftile, LDF, 4 * g, 16 * cb, lane), tr4g(ftile, LDF, 16 + 4 * g, 16 * cb, lane));
+#pragma unroll
+        for (int kb = 0; kb < 6; ++kb) {
+            const bf16x8 fbk = cat8(tr4g(ct, LDC, 4 * g, 16 * kb, lane), tr4g(ct, LDC, 16 + 4 * g, 16 * kb, lane));
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb) acc[cb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cb], fbk, acc[cb][kb], 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // this wave's tile reads before its next tile writes
+        __builtin_amdgcn_wave_barrier();
+    }
+    // acc[cb][kb]: lane (k = 16 kb + i16) holds fine channels 16 cb + 4 g + r of this wave's half
+    float* dst = a.slab + (long)blockIdx.x * (4 * C * C) + (long)(q * C + HC * half) * C;
+#pragma unroll
+    for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+        for (int kb = 0; kb < 6; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(16 * cb + 4 * g + r) * C + 16 * kb + i16] = acc[cb][kb][r];
+}
+// out = sum over slabs, in slab order; transposed: out[k][(q, c)] (ldo = 384), else out[(q, c)][k] (ldo = 96)
+__global__ void __launch_bounds__(256) gather_wgrad_reduce_kernel(const float* __restrict__ slab, int rows, float* __restrict__ out, int transposed) {
+    const int e = blockIdx.x * 256 + threadIdx.x, n = 4 * 96 * 96;
+    if (e >= n) return;
+    float v = 0.f;
+    int r = 0;
+    for (; r + 16 <= rows; r += 16) {
+        float t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = slab[(long)(r + u) * n + e];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v += t[u];
+    }
+    for (; r < rows; ++r) v += slab[(long)r * n + e];
+    const int qc = e / 96, k = e - 96 * qc;
+    out[transposed ? (long)k * 384 + qc : (long)e] = v;
+}
+
 }  // namespace
 
 // 0 = done, 1 = shape not covered (nothing launched)
@@ -328,6 +448,46 @@ extern "C" int bf_scatter_gemm(int dtype, const void* a, const void* w, const fl
     } while (0)
     if (sc) BF_SG_GO(true); else BF_SG_GO(false);
 #undef BF_SG_GO
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
+// runs per frame: a divisor of the 32-row tiles per frame, about two workgroups per CU in all
+static int wgrad_runs(int F, int tpf) {
+    int rpf = 1;
+    for (int r = 1; r <= tpf; ++r)
+        if (tpf % r == 0 && (long)F * r <= 512) rpf = r;
+    return rpf;
+}
+extern "C" int64_t bf_gather_wgrad_ws_floats(int F, int gh, int gw) {
+    if (F <= 0 || gh <= 0 || gw <= 0 || gw % 16 || ((long)gh * gw) % 32) return 0;
+    return (int64_t)F * wgrad_runs(F, (int)((long)gh * gw / 32)) * (4 * 96 * 96);
+}
+// dW[(q, c)][k] (transposed = 0, [384][96]) or dW[k][(q, c)] (transposed = 1, [96][384]) is WRITTEN.  0 = done, 1 = shape not covered.
+extern "C" int bf_gather_wgrad(int dtype, const void* fine, const void* coarse, const float* fsc, const float* fsh, const float* csc, const float* csh,
+                               float* out, int transposed, int F, int gh, int gw, int C0, int Kc, float* ws, int64_t ws_floats, bf_stream_t stream) {
+    if (dtype != BF_DTYPE_BF16 || C0 != 96 || Kc != 96) return 1;
+    if (F <= 0 || gh <= 0 || gw <= 0 || gw % 16 || ((long)gh * gw) % 32) return 1;
+    if ((fsc && csc) || (!fsc != !fsh) || (!csc != !csh)) return 1;
+    static const bool off = bf_knob("BF_GATHER_WGRAD", 1) == 0;
+    if (off) return 1;
+    BF_REQUIRE(fine && coarse && out && ws, "bf_gather_wgrad: null pointer");
+    BF_REQUIRE((((uintptr_t)fine | (uintptr_t)coarse) & 15) == 0, "bf_gather_wgrad: operands must be 16-byte aligned");
+    const int tpf = (int)((long)gh * gw / 32);
+    const int rpf = wgrad_runs(F, tpf);
+    const long nwg = (long)F * rpf;
+    if (ws_floats < nwg * (4 * 96 * 96)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    WgradArgs a{(const bf16*)fine, (const bf16*)coarse, fsc, fsh, csc, csh, ws, F, gh, gw, rpf, tpf / rpf};
+    {
+        const double rows = (double)F * gh * gw;
+        BfProfScope prof(st, fsc ? "gather_wgrad<fine gelu>" : csc ? "gather_wgrad<coarse gelu>" : "gather_wgrad<plain>", 2.0 * rows * 384 * 96, rows * (384 + 96) * 2.0);
+        if (fsc) hipLaunchKernelGGL((gather_wgrad_kernel<true, false>), dim3((unsigned)nwg), dim3(64 * WW), 0, st, a);
+        else if (csc) hipLaunchKernelGGL((gather_wgrad_kernel<false, true>), dim3((unsigned)nwg), dim3(64 * WW), 0, st, a);
+        else hipLaunchKernelGGL((gather_wgrad_kernel<false, false>), dim3((unsigned)nwg), dim3(64 * WW), 0, st, a);
+        BF_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(gather_wgrad_reduce_kernel, dim3(bf_cdiv(4 * 96 * 96, 256)), dim3(256), 0, st, (const float*)ws, (int)nwg, out, transposed);
     BF_CHECK_LAUNCH();
     return 0;
 }

@@ -449,7 +449,7 @@ struct Scratch {
     float *G, *csum, *zeros, *ones, *wg, *attn_ws, *attn_ws2, *in_ws, *in_ws2, *in_ws3;   // wg: prepared-layout weight gradient scratch
     float* tokred_ws; int64_t tokred_floats;      // slabs of the token-reduction (weight-gradient) GEMM
     static constexpr long ATTN_WS_FLOATS = 1024L * (4 * 128 + 32 * 16 + 16);
-    void *t1, *t3, *t4, *t1b;
+    void *t1, *t3, *t4, *t1b; int64_t t1b_floats;
     void *s1, *e5, *e6, *e7;     // [N][E] each: s1 feeds side-stream GEMMs only; e5..e7 keep side-stream inputs from being recycled within a stage
     size_t bytes;
     Scratch(const D& d, void* base) {
@@ -488,6 +488,7 @@ struct Scratch {
         t3 = a.take(std::max(tok * 3, big / 2) * d.es);
         t1 = a.take(std::max(tok, big / 2) * d.es);
         t1b = a.take(std::max(tok, big / 2) * d.es);
+        t1b_floats = (int64_t)(std::max(tok, big / 2) * d.es / 4);
         s1 = a.take(tok * d.es); e5 = a.take(tok * d.es); e6 = a.take(tok * d.es); e7 = a.take(tok * d.es);
         bytes = a.off;
     }
@@ -1248,8 +1249,13 @@ extern "C" int bf_embed_bwd(const bf_dims* dims, const bf_embed_params* p, const
         const long rpf = (long)sv.gh[i] * sv.gw[i];
         TRY(fk.join());
         TRY(fk.begin(&ss));
-        ZERO_ON(ss, sc.wg, (size_t)sv.C[i] * K4 * 4);
-        {   // dWprep[co][k] = sum_p dy[p][co] * act(patch)[p][k]
+        // dWprep[co][k] = sum_p dy[p][co] * act(patch)[p][k]: the 96-channel stages as one stream over the map with slabs summed in a fixed
+        // order (gather_gemm.hip; its slabs live in t1b, which nothing else of this call touches), else split-K with fp32 atomics
+        const int wrc = bf_gather_wgrad(d.dtype, sv.y[i - 1], dy, sv.sc[i - 1], sv.sh[i - 1], nullptr, nullptr, sc.wg, 1, (int)d.F, sv.gh[i], sv.gw[i], cp,
+                                        sv.C[i], (float*)sc.t1b, sc.t1b_floats, ss);
+        if (wrc < 0) return wrc;
+        if (wrc == 1) {
+            ZERO_ON(ss, sc.wg, (size_t)sv.C[i] * K4 * 4);
             bf_operand A = op_plain(dy, sv.C[i], BF_LAY_XC);
             bf_operand Bo = op_plain(sv.y[i - 1], cp, BF_LAY_XC);
             op_gather(Bo, sv.gw[i], sv.gh[i], cp);
@@ -1445,8 +1451,12 @@ extern "C" int bf_debed_bwd(const bf_dims* dims, const bf_debed_params* p, const
             const int N4 = 4 * co;
             TRY(fk.join());
             TRY(fk.begin(&ss));
-            ZERO_ON(ss, sc.wg, (size_t)N4 * cin * 4);
-            {   // wg[(q,co)][ci] = sum_p dy_gathered[p][(q,co)] * act[p][ci]
+            // wg[(q,co)][ci] = sum_p dy_gathered[p][(q,co)] * act[p][ci]: as in bf_embed_bwd, the transformed side here being the coarse rows
+            const int wrc = i > 0 ? bf_gather_wgrad(d.dtype, dy, ain, nullptr, nullptr, sv.sc[i - 1], sv.sh[i - 1], sc.wg, 0, (int)d.F, sv.gh[i], sv.gw[i], co,
+                                                    cin, (float*)sc.t1b, sc.t1b_floats, ss) : 1;
+            if (wrc < 0) return wrc;
+            if (wrc == 1) {
+                ZERO_ON(ss, sc.wg, (size_t)N4 * cin * 4);
                 bf_operand A = op_plain(dy, co, BF_LAY_XC);
                 op_gather(A, sv.gw[i], sv.gh[i], co);
                 bf_operand Bo = op_plain(ain, cin, BF_LAY_XC);

@@ -247,6 +247,14 @@ int bf_gather_gemm(int dtype, const void* map, const void* w, int w_kn, const fl
  * ws + 2*frames*C0 == stat_part.  Returns 1 (nothing launched) for: fp32, K != 96, C0 != 96, gw % 16, gh*gw % 32. */
 int bf_scatter_gemm(int dtype, const void* a, const void* w, const float* sc, const float* sh, void* map, float* stat_part, int frames, int gh,
                     int gw, int K, int C0, bf_stream_t stream);
+/* ... and their weight gradients: dW[(q, c)][k] = sum_p ff(fine[pixel(p, q)][c]) * fc(coarse[p][k]), fine [frames][2gh][2gw][C0], coarse
+ * [frames*gh*gw][Kc]; at most one side through GELU(x * sc + sh) ([frames][96] each; the embed stages transform the fine side, the debed
+ * stages the coarse side).  out is WRITTEN: [4*C0][Kc] (transposed = 0) or [Kc][4*C0] (transposed = 1); per-workgroup slabs summed in a
+ * fixed order (bit-reproducible).  ws: bf_gather_wgrad_ws_floats floats.  Returns 1 (nothing launched) for: fp32, C0 != 96, Kc != 96,
+ * gw % 16, gh*gw % 32, both sides transformed, a workspace too small. */
+int64_t bf_gather_wgrad_ws_floats(int frames, int gh, int gw);
+int bf_gather_wgrad(int dtype, const void* fine, const void* coarse, const float* fsc, const float* fsh, const float* csc, const float* csh,
+                    float* out, int transposed, int frames, int gh, int gw, int C0, int Kc, float* ws, int64_t ws_floats, bf_stream_t stream);
 int64_t bf_embed_tail_ws_floats(int frames, int gh1, int gw1, int C0, int Kp);
 int bf_embed_tail_bwd(int dtype, const void* dy1, const void* w1c, const void* y0, const void* patches, const void* w0c, const float* sc,
                       const float* sh, const float* mean, const float* rstd, const float* in_w, float* dwprep, float* d_in_w, float* d_in_b,

@@ -904,6 +904,47 @@ def test_scatter_gemm_2x2_stage_with_statistics(Fr, gh, gw, pro):
     assert lib.bf_scatter_gemm(1, _p(a), _p(W), None, None, _p(fine), None, Fr, gh, gw + 8, K, C0, _stream()) == 1      # gw % 16
 
 
+@pytest.mark.parametrize("Fr,gh,gw", [(3, 2, 16), (2, 12, 32), (7, 48, 48)])
+@pytest.mark.parametrize("variant", ["fine_gelu_T", "coarse_gelu", "plain"])
+def test_gather_wgrad_2x2_stage(Fr, gh, gw, variant):
+    """bf_gather_wgrad (gather_gemm.hip): dW[(q, c)][k] = sum over coarse rows of the gathered fine row times the coarse row, one side
+    optionally through GELU(x * sc + sh), against fp64 torch on the same bf16 operands; both output orientations; bit-reproducible."""
+    from bubbleformer_amd import _lib as L
+    from bubbleformer_amd.ops import _p, _stream
+    lib = L.lib()
+    C0 = 96
+    g = torch.Generator(device="cuda").manual_seed(53)
+    P = Fr * gh * gw
+    fine = torch.randn(Fr, 2 * gh, 2 * gw, C0, device="cuda", generator=g).bfloat16()
+    coarse = torch.randn(P, C0, device="cuda", generator=g).bfloat16()
+    sc, sh = 0.5 + torch.rand(Fr, C0, device="cuda", generator=g), 0.3 * torch.randn(Fr, C0, device="cuda", generator=g)
+    xf, xc = fine.double(), coarse.double()
+    fs = cs = (None, None)
+    if variant == "fine_gelu_T":
+        xf = torch.nn.functional.gelu(xf * sc.double()[:, None, None] + sh.double()[:, None, None]).bfloat16().double()
+        fs = (_p(sc), _p(sh))
+    elif variant == "coarse_gelu":
+        xc = torch.nn.functional.gelu(xc.view(Fr, gh * gw, C0) * sc.double()[:, None] + sh.double()[:, None]).view(P, C0).bfloat16().double()
+        cs = (_p(sc), _p(sh))
+    tr = 1 if variant == "fine_gelu_T" else 0
+    nws = lib.bf_gather_wgrad_ws_floats(Fr, gh, gw)
+    assert nws > 0
+    ws = torch.full((nws,), float("nan"), device="cuda")
+    out = torch.full((C0, 4 * C0) if tr else (4 * C0, C0), float("nan"), device="cuda")
+    L.check(lib.bf_gather_wgrad(1, _p(fine), _p(coarse), *fs, *cs, _p(out), tr, Fr, gh, gw, C0, C0, _p(ws), nws, _stream()), "gather_wgrad")
+    A = xf.view(Fr, gh, 2, gw, 2, C0).permute(0, 1, 3, 2, 4, 5).reshape(P, 4 * C0)
+    ref = A.t() @ xc
+    got = out.t() if tr else out
+    assert torch.isfinite(out).all()
+    assert _rel(got, ref) < 3e-3
+    first = out.clone()
+    L.check(lib.bf_gather_wgrad(1, _p(fine), _p(coarse), *fs, *cs, _p(out), tr, Fr, gh, gw, C0, C0, _p(ws), nws, _stream()), "gather_wgrad")
+    assert torch.equal(first, out)
+    assert lib.bf_gather_wgrad(0, _p(fine), _p(coarse), *fs, *cs, _p(out), tr, Fr, gh, gw, C0, C0, _p(ws), nws, _stream()) == 1            # fp32
+    assert lib.bf_gather_wgrad(1, _p(fine), _p(coarse), *fs, *cs, _p(out), tr, Fr, gh, gw, C0, C0, _p(ws), nws - 1, _stream()) == 1        # workspace
+    assert lib.bf_gather_wgrad(1, _p(fine), _p(coarse), _p(sc), _p(sh), _p(sc), _p(sh), _p(out), tr, Fr, gh, gw, C0, C0, _p(ws), nws, _stream()) == 1
+
+
 @pytest.mark.parametrize("Fr,gh1,gw1,C1", [(3, 8, 16, 96), (2, 12, 32, 192), (5, 48, 48, 96)])
 def test_embed_backward_tail_one_pass(Fr, gh1, gw1, C1):
     """bf_embed_tail_bwd (embed_tail.hip): the stage-1 data gradient, GELU', the stage-0 InstanceNorm backward and the stage-0 weight
