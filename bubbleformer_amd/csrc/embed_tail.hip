@@ -213,14 +213,15 @@ __global__ void __launch_bounds__(256) embed_tail_frame_kernel(const float* __re
     __shared__ float sm[NPART];
     const int f = blockIdx.x;
     const float* src = part + (long)f * nper * NPART;
-    for (int e = threadIdx.x; e < NPART; e += 256) {
+    for (int e = threadIdx.x; e < NPART; e += 256) {      // up to 16 partial rows in flight (a load-then-add loop pays a round trip per row)
         float v = 0.f;
-        int b = 0;
-        for (; b + 4 <= nper; b += 4) {
-            const float t0 = src[(long)b * NPART + e], t1 = src[(long)(b + 1) * NPART + e], t2 = src[(long)(b + 2) * NPART + e], t3 = src[(long)(b + 3) * NPART + e];
-            v += (t0 + t1) + (t2 + t3);
+        for (int b0 = 0; b0 < nper; b0 += 16) {
+            float t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u] = b0 + u < nper ? src[(long)(b0 + u) * NPART + e] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v += t[u];
         }
-        for (; b < nper; ++b) v += src[(long)b * NPART + e];
         sm[e] = v;
     }
     __syncthreads();

@@ -361,18 +361,26 @@ __global__ void __launch_bounds__(64 * WW, 4) gather_wgrad_kernel(WgradArgs a) {
 }
 // out = sum over slabs, in slab order; transposed: out[k][(q, c)] (ldo = 384), else out[(q, c)][k] (ldo = 96)
 __global__ void __launch_bounds__(256) gather_wgrad_reduce_kernel(const float* __restrict__ slab, int rows, float* __restrict__ out, int transposed) {
-    const int e = blockIdx.x * 256 + threadIdx.x, n = 4 * 96 * 96;
-    if (e >= n) return;
+    // 64 elements x 4 row lanes per block: each lane sums every fourth slab (16 loads in flight), the four lanes are added in a fixed order
+    __shared__ float red[4][64];
+    const int l = threadIdx.x & 63, q = threadIdx.x >> 6, n = 4 * 96 * 96;
+    const int e = blockIdx.x * 64 + l;
     float v = 0.f;
-    int r = 0;
-    for (; r + 16 <= rows; r += 16) {
-        float t[16];
+    if (e < n) {
+        int r = q;
+        for (; r + 60 < rows; r += 64) {
+            float t[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) t[u] = slab[(long)(r + u) * n + e];
+            for (int u = 0; u < 16; ++u) t[u] = slab[(long)(r + 4 * u) * n + e];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v += t[u];
+            for (int u = 0; u < 16; ++u) v += t[u];
+        }
+        for (; r < rows; r += 4) v += slab[(long)r * n + e];
     }
-    for (; r < rows; ++r) v += slab[(long)r * n + e];
+    red[q][l] = v;
+    __syncthreads();
+    if (q != 0 || e >= n) return;
+    v = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
     const int qc = e / 96, k = e - 96 * qc;
     out[transposed ? (long)k * 384 + qc : (long)e] = v;
 }
@@ -487,7 +495,7 @@ extern "C" int bf_gather_wgrad(int dtype, const void* fine, const void* coarse, 
         else hipLaunchKernelGGL((gather_wgrad_kernel<false, false>), dim3((unsigned)nwg), dim3(64 * WW), 0, st, a);
         BF_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(gather_wgrad_reduce_kernel, dim3(bf_cdiv(4 * 96 * 96, 256)), dim3(256), 0, st, (const float*)ws, (int)nwg, out, transposed);
+    hipLaunchKernelGGL(gather_wgrad_reduce_kernel, dim3(bf_cdiv(4 * 96 * 96, 64)), dim3(256), 0, st, (const float*)ws, (int)nwg, out, transposed);
     BF_CHECK_LAUNCH();
     return 0;
 }

@@ -347,15 +347,16 @@ __global__ void __launch_bounds__(NT) debed_last_inbwd_kernel(const float* __res
             o.r[2] = *reinterpret_cast<const float2*>(y + oo); o.r[3] = *reinterpret_cast<const float2*>(y + oo + W);
         }
     };
-    Row cur, nxt;
+    Row cur, nxt, nx2;                  // two 16-pixel groups ahead: a wave has few registers left for anything but bytes in flight
     fetch(g0, cur);
+    if (g0 + 1 < g1) fetch(g0 + 1, nxt);
     float s1[PASS == 1 ? 4 * T : 1], s2[PASS == 1 ? 4 * T : 1];
     if (PASS == 1) {
 #pragma unroll
         for (int k = 0; k < 4 * T; ++k) s1[k] = s2[k] = 0.f;
     }
     for (int g = g0; g < g1; ++g) {
-        if (g + 1 < g1) fetch(g + 1, nxt);
+        if (g + 2 < g1) fetch(g + 2, nx2);
         const long p = (long)f * h * w + g * 16 + li;
         bf16x4v b;
         if (PASS == 1) {
@@ -367,18 +368,22 @@ __global__ void __launch_bounds__(NT) debed_last_inbwd_kernel(const float* __res
         } else b = cur.d;
         const s16x4 bs = __builtin_bit_cast(s16x4, b);
         bf16x8 o8[T / 2];
+        // the per-channel constants are loop invariant: left alone the compiler keeps all 4 * 4T (+ 3 * 4T) of them in registers, which
+        // halves the waves a SIMD can hold; an offset it cannot see through makes them 16-byte LDS reads per group instead
+        int kofs = 8 * lg;
+        asm volatile("" : "+v"(kofs));
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wf[t], bs, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = 4 * t + j;
-                const float4 c1 = k1[32 * (k >> 3) + 8 * lg + (k & 7)];
+                const float4 c1 = k1[32 * (k >> 3) + kofs + (k & 7)];
                 const float yv = (float)cur.yv[k >> 3][k & 7];
                 const float dd = acc[j] * dgelu_fast(fmaf(yv, c1.x, c1.y)), xh = fmaf(yv, c1.z, c1.w);
                 if (PASS == 1) { s1[k] += dd; s2[k] = fmaf(dd, xh, s2[k]); }
                 else {
-                    const float4 c2 = k2[32 * (k >> 3) + 8 * lg + (k & 7)];
+                    const float4 c2 = k2[32 * (k >> 3) + kofs + (k & 7)];
                     o8[k >> 3][k & 7] = (bf16)(c2.x * (dd - c2.y - xh * c2.z));
                 }
             }
@@ -388,6 +393,7 @@ __global__ void __launch_bounds__(NT) debed_last_inbwd_kernel(const float* __res
             for (int q = 0; q < T / 2; ++q) *reinterpret_cast<bf16x8*>(dx + p * Ci + 8 * lg + 32 * q) = o8[q];
         }
         cur = nxt;
+        nxt = nx2;
     }
     if (PASS == 1) {      // {sum dd, sum dd xh} of this wave's slice: part[(f * nsl + sl) * Ci + c]
         const int nsl = (GF + DL_GPW - 1) / DL_GPW, sl = g0 / DL_GPW;
