@@ -104,7 +104,7 @@ SIGNATURES = {
     "bf_debed_last_bwd_norm": (C.c_int, [C.c_int, fp, fp, fp, fp, fp, vp, vp, vp, fp, fp, fp, fp, vp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, fp, C.c_int64, vp]),
     "bf_gather_gemm": (C.c_int, [C.c_int, vp, vp, C.c_int, fp, fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
-    "bf_scatter_gemm": (C.c_int, [C.c_int, vp, vp, fp, fp, vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "bf_scatter_gemm": (C.c_int, [C.c_int, vp, vp, C.c_int, fp, fp, vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "bf_gather_wgrad_ws_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "bf_gather_wgrad": (C.c_int, [C.c_int, vp, vp, fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, C.c_int64, vp]),
     "bf_embed_tail_ws_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -74,8 +74,8 @@ __global__ void __launch_bounds__(64 * GW, 2) gather_gemm_kernel(GatherArgs a) {
         const unsigned f = (unsigned)tt / tpf, tl = (unsigned)tt - f * tpf;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
-            const unsigned pl = 32u * tl + 16u * rb, y = pl / gw, x0 = pl - y * gw;     // a 16-row block lies inside one image row (gw % 16 == 0)
-            const long pix = ((long)f * (2 * a.gh) + 2 * y + (q >> 1)) * (2L * a.gw) + 2 * (x0 + i16) + (q & 1);
+            const unsigned pl = 32u * tl + 16u * rb + (unsigned)i16, y = pl / gw, x = pl - y * gw;     // per lane: a 16-row block may wrap an image row
+            const long pix = ((long)f * (2 * a.gh) + 2 * y + (q >> 1)) * (2L * a.gw) + 2 * x + (q & 1);
 #pragma unroll
             for (int s = 0; s < NS; ++s) dst[rb][s] = *reinterpret_cast<const bf16x8*>(a.map + pix * C0 + 32 * s + 8 * g);
         }
@@ -148,11 +148,11 @@ __global__ void __launch_bounds__(64 * GW, 2) gather_gemm_kernel(GatherArgs a) {
 // slice layout bf_in_stats_merge_slices finishes -- the 226 MB map is not read again for them.
 struct ScatterArgs {
     const bf16* a;            // [F gh gw][K]
-    const bf16* w;            // [4 C0][K] (k contiguous)
+    const bf16* w;            // [4 C0][K] (k contiguous), or kn: [K][4 C0]
     bf16* map;                // [F][2 gh][2 gw][C0]
     const float *sc, *sh;     // [F][K] (PRO)
     float* part;              // optional: [F][tiles per frame][C0][2]
-    int F, gh, gw, tiles;
+    int w_kn, F, gh, gw, tiles;
 };
 template <int NKB, int NCB> constexpr int scatter_lds_bytes() { return 4 * 16 * NCB * (32 * NKB + 8) * 2; }
 
@@ -172,9 +172,18 @@ __global__ void __launch_bounds__(64 * GW, 2) scatter_gemm_kernel(ScatterArgs a)
     bf16* Wt = reinterpret_cast<bf16*>(smem_sg);                     // [4 C0][LDK]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, g = lane >> 4;
-    for (int t = tid; t < 4 * C0 * (K / 8); t += 64 * GW) {
-        const int n = t / (K / 8), k0 = 8 * (t - n * (K / 8));
-        *reinterpret_cast<bf16x8*>(Wt + n * LDK + k0) = *reinterpret_cast<const bf16x8*>(a.w + (long)n * K + k0);
+    if (a.w_kn) {
+        for (int t = tid; t < K * (4 * C0 / 8); t += 64 * GW) {      // 16-byte pieces of a k-row, scattered down a column of Wt
+            const int k = t / (4 * C0 / 8), n0 = 8 * (t - k * (4 * C0 / 8));
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(a.w + (long)k * (4 * C0) + n0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Wt[(n0 + j) * LDK + k] = v[j];
+        }
+    } else {
+        for (int t = tid; t < 4 * C0 * (K / 8); t += 64 * GW) {
+            const int n = t / (K / 8), k0 = 8 * (t - n * (K / 8));
+            *reinterpret_cast<bf16x8*>(Wt + n * LDK + k0) = *reinterpret_cast<const bf16x8*>(a.w + (long)n * K + k0);
+        }
     }
     __syncthreads();
     const int nw = gridDim.x * GW, wv = blockIdx.x * GW + wave;
@@ -209,8 +218,8 @@ __global__ void __launch_bounds__(64 * GW, 2) scatter_gemm_kernel(ScatterArgs a)
         long pix0[2];
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
-            const unsigned pl = 32u * tl + 16u * rb, y = pl / gw, x0 = pl - y * gw;
-            pix0[rb] = ((long)f * (2 * a.gh) + 2 * y) * (2L * a.gw) + 2 * (x0 + i16);
+            const unsigned pl = 32u * tl + 16u * rb + (unsigned)i16, y = pl / gw, x = pl - y * gw;      // per lane: a 16-row block may wrap an image row
+            pix0[rb] = ((long)f * (2 * a.gh) + 2 * y) * (2L * a.gw) + 2 * x;
         }
         float ssum[NCB / 2][8], ssq[NCB / 2][8];
 #pragma unroll
@@ -304,8 +313,8 @@ __global__ void __launch_bounds__(64 * WW, 4) gather_wgrad_kernel(WgradArgs a) {
     bf16x8 fr[3], cr;
     auto issue = [&](int st) __attribute__((always_inline)) {
         const unsigned tl = (unsigned)(run * a.steps + st);                      // 32-row tile inside the frame
-        const unsigned pl = 32u * tl + (unsigned)(frow & 16), y = pl / gw, x0 = pl - y * gw;      // a 16-row block lies inside one image row
-        const bf16* src = a.fine + (((long)f * (2 * a.gh) + 2 * y + (q >> 1)) * (2L * a.gw) + 2 * (x0 + (frow & 15)) + (q & 1)) * C + HC * half + fc0;
+        const unsigned pl = 32u * tl + (unsigned)frow, y = pl / gw, x = pl - y * gw;
+        const bf16* src = a.fine + (((long)f * (2 * a.gh) + 2 * y + (q >> 1)) * (2L * a.gw) + 2 * x + (q & 1)) * C + HC * half + fc0;
 #pragma unroll
         for (int j = 0; j < 3; ++j) fr[j] = *reinterpret_cast<const bf16x8*>(src + 16 * j);
         if (cth) cr = *reinterpret_cast<const bf16x8*>(a.coarse + ((long)f * a.gh * a.gw + 32L * tl + crow) * C + cch);
@@ -391,7 +400,7 @@ __global__ void __launch_bounds__(256) gather_wgrad_reduce_kernel(const float* _
 extern "C" int bf_gather_gemm(int dtype, const void* map, const void* w, int w_kn, const float* sc, const float* sh, void* out, int F, int gh,
                               int gw, int C0, int N, bf_stream_t stream) {
     if (dtype != BF_DTYPE_BF16 || C0 != 96 || N != 96) return 1;
-    if (F <= 0 || gh <= 0 || gw <= 0 || gw % 16 || ((long)gh * gw) % 32) return 1;
+    if (F <= 0 || gh <= 0 || gw <= 0 || ((long)gh * gw) % 32) return 1;
     static const bool off = bf_knob("BF_GATHER_GEMM", 1) == 0;
     if (off) return 1;
     BF_REQUIRE(map && w && out && (!sc == !sh), "bf_gather_gemm: bad arguments");
@@ -425,10 +434,10 @@ extern "C" int bf_gather_gemm(int dtype, const void* map, const void* w, int w_k
 
 // 0 = done, 1 = shape not covered (nothing launched).  stat_part (optional): the slice partials, 128-row slices, at ws + 2*frames*C0 of the
 // workspace bf_in_stats_merge_slices(..., rows = 128, ws) takes
-extern "C" int bf_scatter_gemm(int dtype, const void* a, const void* w, const float* sc, const float* sh, void* map, float* stat_part, int F,
+extern "C" int bf_scatter_gemm(int dtype, const void* a, const void* w, int w_kn, const float* sc, const float* sh, void* map, float* stat_part, int F,
                                int gh, int gw, int K, int C0, bf_stream_t stream) {
     if (dtype != BF_DTYPE_BF16 || C0 != 96 || K != 96) return 1;
-    if (F <= 0 || gh <= 0 || gw <= 0 || gw % 16 || ((long)gh * gw) % 32) return 1;
+    if (F <= 0 || gh <= 0 || gw <= 0 || ((long)gh * gw) % 32) return 1;
     static const bool off = bf_knob("BF_SCATTER_GEMM", 1) == 0;
     if (off) return 1;
     BF_REQUIRE(a && w && map && (!sc == !sh), "bf_scatter_gemm: bad arguments");
@@ -440,7 +449,7 @@ extern "C" int bf_scatter_gemm(int dtype, const void* a, const void* w, const fl
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int grid = (int)std::min<long>((tiles + GW - 1) / GW, 2L * cus);
-    ScatterArgs sa{(const bf16*)a, (const bf16*)w, (bf16*)map, sc, sh, stat_part, F, gh, gw, (int)tiles};
+    ScatterArgs sa{(const bf16*)a, (const bf16*)w, (bf16*)map, sc, sh, stat_part, w_kn, F, gh, gw, (int)tiles};
     constexpr int lds = scatter_lds_bytes<3, 6>();
     const double rows = (double)F * gh * gw;
     BfProfScope prof(st, sc ? "scatter_gemm<gelu>" : "scatter_gemm<plain>", 2.0 * rows * 4 * C0 * K, rows * (4.0 * C0 + K) * 2.0);
@@ -468,14 +477,14 @@ static int wgrad_runs(int F, int tpf) {
     return rpf;
 }
 extern "C" int64_t bf_gather_wgrad_ws_floats(int F, int gh, int gw) {
-    if (F <= 0 || gh <= 0 || gw <= 0 || gw % 16 || ((long)gh * gw) % 32) return 0;
+    if (F <= 0 || gh <= 0 || gw <= 0 || ((long)gh * gw) % 32) return 0;
     return (int64_t)F * wgrad_runs(F, (int)((long)gh * gw / 32)) * (4 * 96 * 96);
 }
 // dW[(q, c)][k] (transposed = 0, [384][96]) or dW[k][(q, c)] (transposed = 1, [96][384]) is WRITTEN.  0 = done, 1 = shape not covered.
 extern "C" int bf_gather_wgrad(int dtype, const void* fine, const void* coarse, const float* fsc, const float* fsh, const float* csc, const float* csh,
                                float* out, int transposed, int F, int gh, int gw, int C0, int Kc, float* ws, int64_t ws_floats, bf_stream_t stream) {
     if (dtype != BF_DTYPE_BF16 || C0 != 96 || Kc != 96) return 1;
-    if (F <= 0 || gh <= 0 || gw <= 0 || gw % 16 || ((long)gh * gw) % 32) return 1;
+    if (F <= 0 || gh <= 0 || gw <= 0 || ((long)gh * gw) % 32) return 1;
     if ((fsc && csc) || (!fsc != !fsh) || (!csc != !csh)) return 1;
     static const bool off = bf_knob("BF_GATHER_WGRAD", 1) == 0;
     if (off) return 1;

@@ -1284,11 +1284,15 @@ extern "C" int bf_embed_bwd(const bf_dims* dims, const bf_embed_params* p, const
         }
         void* dact = buf(i - 1);
         {   // d(act patch)[p][k] = sum_co dy[p][co] * Wprep[co][k], scattered back to the input grid
-            bf_operand A = op_plain(dy, sv.C[i], BF_LAY_KC);
-            bf_operand Bo = op_plain(sv.wc[i], K4, BF_LAY_XC);
-            bf_epilogue e = epi_store(dact, cp);
-            epi_scatter(e, sv.gw[i], sv.gh[i], cp);
-            TRY(bf_gemm(d.dtype, (int)sv.P[i], K4, sv.C[i], &A, &Bo, &e, 1, st));
+            const int src = bf_scatter_gemm(d.dtype, dy, sv.wc[i], 1, nullptr, nullptr, dact, nullptr, (int)d.F, sv.gh[i], sv.gw[i], sv.C[i], cp, st);
+            if (src < 0) return src;
+            if (src == 1) {
+                bf_operand A = op_plain(dy, sv.C[i], BF_LAY_KC);
+                bf_operand Bo = op_plain(sv.wc[i], K4, BF_LAY_XC);
+                bf_epilogue e = epi_store(dact, cp);
+                epi_scatter(e, sv.gw[i], sv.gh[i], cp);
+                TRY(bf_gemm(d.dtype, (int)sv.P[i], K4, sv.C[i], &A, &Bo, &e, 1, st));
+            }
         }
         TRY(bf_in_bwd(d.dtype, dact, sv.y[i - 1], nullptr, dact, (int)d.F, sv.gh[i - 1] * sv.gw[i - 1], cp, sv.mean[i - 1], sv.rstd[i - 1],
                       p->in_w[i - 1], p->in_b[i - 1], nullptr, 1, 1, g->in_w[i - 1], g->in_b[i - 1], nullptr, nullptr, sc.in_ws, st));
@@ -1352,7 +1356,7 @@ extern "C" int bf_debed_fwd(const bf_dims* dims, const bf_debed_params* p, const
             const int S4 = 4 * sv.gh[i] * sv.gw[i];
             const bool part_ok = i > 0 && S4 % 128 == 0 &&
                                  bf_in_ws_floats(d.dtype, (int)d.F, S4, co) >= (int64_t)2 * d.F * co * (1 + S4 / 128);
-            const int src = i > 0 ? bf_scatter_gemm(d.dtype, sv.y[i - 1], sv.wc[i], sv.sc[i - 1], sv.sh[i - 1], sv.y[i],
+            const int src = i > 0 ? bf_scatter_gemm(d.dtype, sv.y[i - 1], sv.wc[i], 0, sv.sc[i - 1], sv.sh[i - 1], sv.y[i],
                                                     part_ok ? sc.in_ws + (size_t)2 * d.F * co : nullptr, (int)d.F, sv.gh[i], sv.gw[i], cin, co, st) : 1;
             if (src < 0) return src;
             if (src == 0 && part_ok) {

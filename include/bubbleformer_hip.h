@@ -238,20 +238,20 @@ int bf_in_stats_merge_slices(int dtype, int frames, int S, int C, int rows, cons
  * coarse grid [frames][gh][gw], pixel(p, q) = (2y + q/2, 2x + q%2) of the fine grid [frames][2gh][2gw][C0].  f = GELU(x * sc + sh)
  * (sc / sh [frames][C0]: the HMLPEmbed convolutions after the first, layers/patching.py:30-56) or the identity (sc = sh = NULL: the data
  * gradients of the HMLPDebed transposed convolutions).  w: [4*C0][N] (w_kn = 1) or [N][4*C0] (w_kn = 0).  Returns 1 (nothing launched)
- * for shapes it does not take: fp32, C0 != 96, N != 96, gw % 16, gh*gw % 32. */
+ * for shapes it does not take: fp32, C0 != 96, N != 96, gh*gw % 32. */
 int bf_gather_gemm(int dtype, const void* map, const void* w, int w_kn, const float* sc, const float* sh, void* out, int frames, int gh,
                    int gw, int C0, int N, bf_stream_t stream);
 /* ... and the transposed direction (HMLPDebed's ConvTranspose2d(k=2, s=2) stages, layers/patching.py:80-104): map[pixel(p, q)][c] =
- * sum_k f(a[p][k]) * w[q*C0 + c][k], a [frames*gh*gw][K], map [frames][2gh][2gw][C0].  stat_part (optional): {mean, centred second moment} of the
+ * sum_k f(a[p][k]) * w[q*C0 + c][k] (w_kn = 0; or w [K][4*C0] with w_kn = 1), a [frames*gh*gw][K], map [frames][2gh][2gw][C0].  stat_part (optional): {mean, centred second moment} of the
  * map as stored per 128-pixel slice, [frames][gh*gw/32][C0][2]; finished by bf_in_stats_merge_slices(..., rows = 128, ws) with
- * ws + 2*frames*C0 == stat_part.  Returns 1 (nothing launched) for: fp32, K != 96, C0 != 96, gw % 16, gh*gw % 32. */
-int bf_scatter_gemm(int dtype, const void* a, const void* w, const float* sc, const float* sh, void* map, float* stat_part, int frames, int gh,
-                    int gw, int K, int C0, bf_stream_t stream);
+ * ws + 2*frames*C0 == stat_part.  Returns 1 (nothing launched) for: fp32, K != 96, C0 != 96, gh*gw % 32. */
+int bf_scatter_gemm(int dtype, const void* a, const void* w, int w_kn, const float* sc, const float* sh, void* map, float* stat_part, int frames,
+                    int gh, int gw, int K, int C0, bf_stream_t stream);
 /* ... and their weight gradients: dW[(q, c)][k] = sum_p ff(fine[pixel(p, q)][c]) * fc(coarse[p][k]), fine [frames][2gh][2gw][C0], coarse
  * [frames*gh*gw][Kc]; at most one side through GELU(x * sc + sh) ([frames][96] each; the embed stages transform the fine side, the debed
  * stages the coarse side).  out is WRITTEN: [4*C0][Kc] (transposed = 0) or [Kc][4*C0] (transposed = 1); per-workgroup slabs summed in a
  * fixed order (bit-reproducible).  ws: bf_gather_wgrad_ws_floats floats.  Returns 1 (nothing launched) for: fp32, C0 != 96, Kc != 96,
- * gw % 16, gh*gw % 32, both sides transformed, a workspace too small. */
+ * gh*gw % 32, both sides transformed, a workspace too small. */
 int64_t bf_gather_wgrad_ws_floats(int frames, int gh, int gw);
 int bf_gather_wgrad(int dtype, const void* fine, const void* coarse, const float* fsc, const float* fsh, const float* csc, const float* csh,
                     float* out, int transposed, int frames, int gh, int gw, int C0, int Kc, float* ws, int64_t ws_floats, bf_stream_t stream);

@@ -827,7 +827,7 @@ def test_embed_first_stage_one_pass_with_statistics(cin, h2, w2):
         assert _rel(a, r) < 1e-5
 
 
-@pytest.mark.parametrize("Fr,gh,gw", [(3, 2, 16), (2, 12, 32), (7, 48, 48)])
+@pytest.mark.parametrize("Fr,gh,gw", [(3, 2, 16), (2, 12, 32), (7, 48, 48), (3, 24, 24), (2, 4, 40)])
 @pytest.mark.parametrize("variant", ["gelu_nk", "plain_kn"])
 def test_gather_gemm_2x2_stage(Fr, gh, gw, variant):
     """bf_gather_gemm (gather_gemm.hip): rows of 2x2 / stride-2 patches of a 96-channel map times a [384][96] weight, with GELU(x * sc + sh)
@@ -858,10 +858,10 @@ def test_gather_gemm_2x2_stage(Fr, gh, gw, variant):
     # no misplaced row / 8-column group (the gelu form: polynomial vs exact GELU flips the bf16 rounding of a few operands)
     assert float(((out.double() - ref).abs() / (ref.abs() + 0.05 * ref.abs().mean())).max()) < (0.2 if variant == "gelu_nk" else 0.06)
     assert lib.bf_gather_gemm(0, _p(fine), _p(W), 1, None, None, _p(out), Fr, gh, gw, C0, N, _stream()) == 1          # fp32
-    assert lib.bf_gather_gemm(1, _p(fine), _p(W), 1, None, None, _p(out), Fr, gh, gw + 8, C0, N, _stream()) == 1      # gw % 16
+    assert lib.bf_gather_gemm(1, _p(fine), _p(W), 1, None, None, _p(out), Fr, 3, 5, C0, N, _stream()) == 1      # rows % 32
 
 
-@pytest.mark.parametrize("Fr,gh,gw", [(3, 2, 16), (2, 12, 32), (7, 48, 48)])
+@pytest.mark.parametrize("Fr,gh,gw", [(3, 2, 16), (2, 12, 32), (7, 48, 48), (3, 24, 24), (2, 4, 40)])
 @pytest.mark.parametrize("pro", [True, False])
 def test_scatter_gemm_2x2_stage_with_statistics(Fr, gh, gw, pro):
     """bf_scatter_gemm (gather_gemm.hip): the transposed 2x2 / stride-2 stage at 96 channels -- rows of a coarse map (GELU(x * sc + sh) folded
@@ -883,7 +883,9 @@ def test_scatter_gemm_2x2_stage_with_statistics(Fr, gh, gw, pro):
     x = a.double()
     if pro:
         x = torch.nn.functional.gelu(x.view(Fr, gh * gw, K) * sc.double()[:, None] + sh.double()[:, None]).view(P, K).bfloat16().double()
-    rc = lib.bf_scatter_gemm(1, _p(a), _p(W), _p(sc) if pro else None, _p(sh) if pro else None, _p(fine), _p(part), Fr, gh, gw, K, C0, _stream())
+    # the folded form takes the weight as stored by the debed stages ([n][k]), the plain form as stored by the embed stages ([k][n])
+    wdev = W if pro else W.t().contiguous()
+    rc = lib.bf_scatter_gemm(1, _p(a), _p(wdev), 0 if pro else 1, _p(sc) if pro else None, _p(sh) if pro else None, _p(fine), _p(part), Fr, gh, gw, K, C0, _stream())
     L.check(rc, "scatter_gemm")
     ref = (x @ W.double().t()).view(Fr, gh, gw, 2, 2, C0).permute(0, 1, 3, 2, 4, 5).reshape(Fr, 2 * gh, 2 * gw, C0)
     assert torch.isfinite(fine.float()).all()
@@ -900,11 +902,11 @@ def test_scatter_gemm_2x2_stage_with_statistics(Fr, gh, gw, pro):
     # (a slice is 32 coarse rows x 4 positions: equal counts, so the frame mean is the mean of the slice means)
     tot_mean = pm[..., 0].mean(1)
     assert _rel(tot_mean, yf.mean(1)) < 1e-5
-    assert lib.bf_scatter_gemm(0, _p(a), _p(W), None, None, _p(fine), None, Fr, gh, gw, K, C0, _stream()) == 1          # fp32
-    assert lib.bf_scatter_gemm(1, _p(a), _p(W), None, None, _p(fine), None, Fr, gh, gw + 8, K, C0, _stream()) == 1      # gw % 16
+    assert lib.bf_scatter_gemm(0, _p(a), _p(W), 0, None, None, _p(fine), None, Fr, gh, gw, K, C0, _stream()) == 1          # fp32
+    assert lib.bf_scatter_gemm(1, _p(a), _p(W), 0, None, None, _p(fine), None, Fr, 3, 5, K, C0, _stream()) == 1      # rows % 32
 
 
-@pytest.mark.parametrize("Fr,gh,gw", [(3, 2, 16), (2, 12, 32), (7, 48, 48)])
+@pytest.mark.parametrize("Fr,gh,gw", [(3, 2, 16), (2, 12, 32), (7, 48, 48), (3, 24, 24), (2, 4, 40)])
 @pytest.mark.parametrize("variant", ["fine_gelu_T", "coarse_gelu", "plain"])
 def test_gather_wgrad_2x2_stage(Fr, gh, gw, variant):
     """bf_gather_wgrad (gather_gemm.hip): dW[(q, c)][k] = sum over coarse rows of the gathered fine row times the coarse row, one side
