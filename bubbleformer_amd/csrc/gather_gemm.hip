@@ -411,7 +411,9 @@ extern "C" int bf_gather_gemm(int dtype, const void* map, const void* w, int w_k
     int cus = 256, dev = 0;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int grid = (int)std::min<long>((tiles + GW - 1) / GW, 2L * cus);
+    // as few workgroups as give every wave the same number of tiles as a full grid would (each loads the whole weight first)
+    const long rounds = (tiles + 2L * cus * GW - 1) / (2L * cus * GW), nwaves = (tiles + rounds - 1) / rounds;
+    const int grid = (int)((nwaves + GW - 1) / GW);
     GatherArgs a{(const bf16*)map, (const bf16*)w, (bf16*)out, sc, sh, w_kn, F, gh, gw, (int)tiles};
     constexpr int lds = gather_lds_bytes<6, 6>();
     const double rows = (double)F * gh * gw;
@@ -448,7 +450,9 @@ extern "C" int bf_scatter_gemm(int dtype, const void* a, const void* w, int w_kn
     int cus = 256, dev = 0;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int grid = (int)std::min<long>((tiles + GW - 1) / GW, 2L * cus);
+    // as few workgroups as give every wave the same number of tiles as a full grid would (each loads the whole weight first)
+    const long rounds = (tiles + 2L * cus * GW - 1) / (2L * cus * GW), nwaves = (tiles + rounds - 1) / rounds;
+    const int grid = (int)((nwaves + GW - 1) / GW);
     ScatterArgs sa{(const bf16*)a, (const bf16*)w, (bf16*)map, sc, sh, stat_part, w_kn, F, gh, gw, (int)tiles};
     constexpr int lds = scatter_lds_bytes<3, 6>();
     const double rows = (double)F * gh * gw;
