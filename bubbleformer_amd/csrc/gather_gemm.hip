@@ -394,6 +394,15 @@ __global__ void __launch_bounds__(256) gather_wgrad_reduce_kernel(const float* _
     out[transposed ? (long)k * 384 + qc : (long)e] = v;
 }
 
+int gg_cus() {
+    static const int n = []() {
+        int dev = 0, c = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c < 8) return 256;
+        return c;
+    }();
+    return n;
+}
+
 }  // namespace
 
 // 0 = done, 1 = shape not covered (nothing launched)
@@ -408,9 +417,7 @@ extern "C" int bf_gather_gemm(int dtype, const void* map, const void* w, int w_k
     const long tiles = (long)F * gh * gw / 32;
     BF_REQUIRE(tiles < (1L << 30), "bf_gather_gemm: too many rows");
     hipStream_t st = (hipStream_t)stream;
-    int cus = 256, dev = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = gg_cus();
     // as few workgroups as give every wave the same number of tiles as a full grid would (each loads the whole weight first)
     const long rounds = (tiles + 2L * cus * GW - 1) / (2L * cus * GW), nwaves = (tiles + rounds - 1) / rounds;
     const int grid = (int)((nwaves + GW - 1) / GW);
@@ -447,9 +454,7 @@ extern "C" int bf_scatter_gemm(int dtype, const void* a, const void* w, int w_kn
     const long tiles = (long)F * gh * gw / 32;
     BF_REQUIRE(tiles < (1L << 30), "bf_scatter_gemm: too many rows");
     hipStream_t st = (hipStream_t)stream;
-    int cus = 256, dev = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = gg_cus();
     // as few workgroups as give every wave the same number of tiles as a full grid would (each loads the whole weight first)
     const long rounds = (tiles + 2L * cus * GW - 1) / (2L * cus * GW), nwaves = (tiles + rounds - 1) / rounds;
     const int grid = (int)((nwaves + GW - 1) / GW);

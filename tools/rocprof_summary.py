@@ -66,6 +66,26 @@ def normalise(name: str) -> str:
         return "frame_linear<ring,bn%d,in>" % (32 * int(m.group(1)))      # the model uses the streamed form for fc2 + InstanceNorm only
     if "tokred_reduce_kernel" in name:
         return "tokred_reduce_kernel"
+    # round-3 embed / debed kernels (gather_gemm.hip, embed_tail.hip, patch.hip)
+    m = re.search(r"gather_gemm_kernel<\d, \d, (true|false)>", name)
+    if m:
+        return "gather_gemm<%s>" % ("gelu" if m.group(1) == "true" else "plain")
+    m = re.search(r"scatter_gemm_kernel<\d, \d, (true|false)>", name)
+    if m:
+        return "scatter_gemm<%s>" % ("gelu" if m.group(1) == "true" else "plain")
+    m = re.search(r"gather_wgrad_kernel<(true|false), (true|false)>", name)
+    if m:
+        return "gather_wgrad<%s>" % ("fine gelu" if m.group(1) == "true" else "coarse gelu" if m.group(2) == "true" else "plain")
+    m = re.search(r"debed_last_inbwd_kernel<\d, (\d)>", name)
+    if m:
+        return "debed_last_bwd<%s>" % ("stats" if m.group(1) == "1" else "apply")
+    m = re.search(r"tokred_narrow_kernel<\d, (true|false)>", name)
+    if m:
+        return "tokred_narrow<%s>" % ("gelu" if m.group(1) == "true" else "plain")
+    for key in ("gather_wgrad_reduce_kernel", "embed_tail_bwd_kernel", "embed_tail_frame_kernel", "embed_tail_sum_kernel", "tokred_narrow_reduce_kernel", "dl_slice_sum_kernel",
+                "dl_param_reduce_kernel"):
+        if key in name:
+            return key
     if "gemm_inbwd_frames_kernel" in name:
         return "gemm_inbwd_frames<bf16>"
     for key in ("frame_scale_kernel", "stage_param_reduce_kernel", "stage_prep_kernel", "clip_gather_kernel", "eikonal_kernel", "heatflux_kernel",

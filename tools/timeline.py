@@ -31,6 +31,10 @@ def short(n):
         return "gemm_pair<inbwd>" if m.group(1) == "0" else "gemm_pair<add>"
     if "tokred_pp_reduce" in n:
         return "tokred_reduce"
+    for key in ("gather_wgrad_reduce", "gather_wgrad", "gather_gemm", "scatter_gemm", "embed_tail_bwd", "embed_tail_frame", "embed_tail_sum", "debed_last_inbwd", "tokred_narrow_reduce",
+                "tokred_narrow", "dl_slice_sum", "dl_param_reduce"):
+        if key in n:
+            return key
     for key in ("tokred_pp_kernel", "tokred_reduce", "tokred_kernel", "gemm_inbwd_frames", "attn_fwd_axial_mfma", "attn_bwd_mfma", "attn_fwd_mfma", "in_bwd_slice", "in_stats_slice", "in_stats_merge", "in_slice_sum", "in_bwd_kernel",
                 "in_stats_kernel", "in_param_reduce", "stage_param_reduce", "stage_prep_multi", "stage_prep", "frame_scale", "frame_table", "adamw", "outproj_finalize",
                 "wgrad_unprep", "wprep", "debed_last_bwd", "debed_last", "pm2nchw", "nchw2pm", "im2col", "film_net_bwd", "film_net_fwd", "fillBufferAligned", "copyBuffer", "lploss"):
