@@ -517,11 +517,12 @@ extern "C" int bf_gemm_tokred(int dtype, int Nout, int Kin, int64_t M, const voi
     // BF_TOKRED_SLICES / BF_TOKRED_TILE (384 or 192 rows) override the defaults.
     // Workgroups per launch: the kernel runs on the side stream beside the caller's data-gradient kernels (192 one-per-CU workgroups,
     // gemm_frame.hip); both queues end up equally long, so what counts is the sum of their CU-time.  Measured in the step (targets of
-    // 48 / 64 / 80 / 96 / 128 workgroups: 681 / 693 / 701 / 707 / 699 samples/s): ~96, from which the slice count follows per shape
-    // (QKV 6 tiles x 16, fc1 / fc2 8 x 12, out-projection 4 tiles of 192 x 192 x 16).
+    // 48 / 64 / 80 / 96 / 128 workgroups: 681 / 693 / 701 / 707 / 699 samples/s before the embed / debed rework; after it, same box,
+    // 80 / 96 / 112 / 128 / 160 / 192 / 256: 765 / 768 / 768 / 771 / 767 / 766 / 766): 128, from which the slice count follows per shape
+    // (QKV 12 tiles of 192 x 192 x 10, fc1 / fc2 8 tiles of 384 x 192 x 16, out-projection 4 tiles of 192 x 192 x 16).
     static const int slices_env = bf_knob("BF_TOKRED_SLICES", 0);      // sweeps: a fixed slice count / tile height / workgroup target
     static const int tile_env = bf_knob("BF_TOKRED_TILE", 0);
-    static const int wgs_env = bf_knob("BF_TOKRED_WGS", 96);
+    static const int wgs_env = bf_knob("BF_TOKRED_WGS", 128);
     if (pp) {
         const long halves = M / HR;
         const int tiles_k0 = Kin / PTN;
