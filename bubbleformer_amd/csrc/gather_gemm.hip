@@ -12,6 +12,7 @@
 // weight load.
 #include "bf_common.h"
 #include <algorithm>
+#include <stdint.h>
 
 namespace {
 
@@ -478,16 +479,17 @@ extern "C" int bf_scatter_gemm(int dtype, const void* a, const void* w, int w_kn
     return 0;
 }
 
-// runs per frame: a divisor of the 32-row tiles per frame, about two workgroups per CU in all
-static int wgrad_runs(int F, int tpf) {
-    int rpf = 1;
+// runs per frame: a divisor of the 32-row tiles per frame, about two workgroups per CU in all, as many as the workspace holds slabs for
+static int wgrad_runs(int F, int tpf, int64_t ws_floats) {
+    int rpf = 0;
     for (int r = 1; r <= tpf; ++r)
-        if (tpf % r == 0 && (long)F * r <= 512) rpf = r;
+        if (tpf % r == 0 && (long)F * r <= 512 && (int64_t)F * r * (4 * 96 * 96) <= ws_floats) rpf = r;
     return rpf;
 }
+// the workspace of the preferred launch; any workspace of at least frames * 36864 floats is accepted (fewer, longer runs)
 extern "C" int64_t bf_gather_wgrad_ws_floats(int F, int gh, int gw) {
     if (F <= 0 || gh <= 0 || gw <= 0 || ((long)gh * gw) % 32) return 0;
-    return (int64_t)F * wgrad_runs(F, (int)((long)gh * gw / 32)) * (4 * 96 * 96);
+    return (int64_t)F * wgrad_runs(F, (int)((long)gh * gw / 32), INT64_MAX) * (4 * 96 * 96);
 }
 // dW[(q, c)][k] (transposed = 0, [384][96]) or dW[k][(q, c)] (transposed = 1, [96][384]) is WRITTEN.  0 = done, 1 = shape not covered.
 extern "C" int bf_gather_wgrad(int dtype, const void* fine, const void* coarse, const float* fsc, const float* fsh, const float* csc, const float* csh,
@@ -500,9 +502,9 @@ extern "C" int bf_gather_wgrad(int dtype, const void* fine, const void* coarse, 
     BF_REQUIRE(fine && coarse && out && ws, "bf_gather_wgrad: null pointer");
     BF_REQUIRE((((uintptr_t)fine | (uintptr_t)coarse) & 15) == 0, "bf_gather_wgrad: operands must be 16-byte aligned");
     const int tpf = (int)((long)gh * gw / 32);
-    const int rpf = wgrad_runs(F, tpf);
+    const int rpf = wgrad_runs(F, tpf, ws_floats);
+    if (rpf < 1) return 1;
     const long nwg = (long)F * rpf;
-    if (ws_floats < nwg * (4 * 96 * 96)) return 1;
     hipStream_t st = (hipStream_t)stream;
     WgradArgs a{(const bf16*)fine, (const bf16*)coarse, fsc, fsh, csc, csh, ws, F, gh, gw, rpf, tpf / rpf};
     {

@@ -250,7 +250,8 @@ int bf_scatter_gemm(int dtype, const void* a, const void* w, int w_kn, const flo
 /* ... and their weight gradients: dW[(q, c)][k] = sum_p ff(fine[pixel(p, q)][c]) * fc(coarse[p][k]), fine [frames][2gh][2gw][C0], coarse
  * [frames*gh*gw][Kc]; at most one side through GELU(x * sc + sh) ([frames][96] each; the embed stages transform the fine side, the debed
  * stages the coarse side).  out is WRITTEN: [4*C0][Kc] (transposed = 0) or [Kc][4*C0] (transposed = 1); per-workgroup slabs summed in a
- * fixed order (bit-reproducible).  ws: bf_gather_wgrad_ws_floats floats.  Returns 1 (nothing launched) for: fp32, C0 != 96, Kc != 96,
+ * fixed order (bit-reproducible).  ws: bf_gather_wgrad_ws_floats floats for the preferred launch (anything from frames * 36864 floats
+ * up is accepted: fewer, longer runs).  Returns 1 (nothing launched) for: fp32, C0 != 96, Kc != 96,
  * gh*gw % 32, both sides transformed, a workspace too small. */
 int64_t bf_gather_wgrad_ws_floats(int frames, int gh, int gw);
 int bf_gather_wgrad(int dtype, const void* fine, const void* coarse, const float* fsc, const float* fsh, const float* csc, const float* csh,

@@ -293,6 +293,32 @@ def test_config4_inference_trunk_equals_the_stage_forwards(B, monkeypatch):
         assert torch.equal(f3, s3) and not torch.equal(f3, f2)
 
 
+def test_config1_training_step_takes_the_streaming_embed_debed_kernels():
+    """A bf16 training step at the configs[1] clip size runs the round-3 kernels at the two ends of the model, not their generic fallbacks:
+    the library's own launch profile names the one-pass embed tail, the last-debed backward passes, the gather / scatter stage GEMMs and
+    the gather weight gradients, and no sliced InstanceNorm backward touches a full-resolution map (what remains is the 48 x 48 and
+    24 x 24 maps: 2 phases x 4 norms)."""
+    import ctypes, json
+    from bubbleformer_amd import _lib as L
+    B, T, H, W, seed = 1, 16, 192, 192, 12
+    m = _model(seed, torch.bfloat16, T)
+    x, y, c = (t.cuda() for t in _inputs(B, T, H, W, seed))
+    h = L.lib()
+    h.bf_prof_enable(1)
+    loss, _ = m.forward_loss(x, c, y)
+    loss.backward()
+    torch.cuda.synchronize()
+    buf = ctypes.create_string_buffer(1 << 15)
+    h.bf_prof_report(buf, len(buf))
+    h.bf_prof_enable(0)
+    names = json.loads(buf.value.decode())
+    for k in ("embed_tail_bwd", "debed_last_bwd<stats>", "debed_last_bwd<apply>", "gather_gemm<gelu>", "gather_gemm<plain>", "scatter_gemm<gelu>",
+              "scatter_gemm<plain>", "gather_wgrad<fine gelu>", "gather_wgrad<coarse gelu>"):
+        assert k in names, (k, sorted(names))
+    assert names["gather_gemm<gelu>"]["calls"] == 2 and names["scatter_gemm<gelu>"]["calls"] == 2
+    assert names["gather_wgrad<fine gelu>"]["calls"] == 2 and names["gather_wgrad<coarse gelu>"]["calls"] == 2
+
+
 def test_inference_operators_are_registered_with_the_dispatcher():
     """torch.ops.bubbleformer_amd.trunk_eval / frame_linear (torch_ops.py): schema + fake-tensor implementation pass torch.library.opcheck,
     the eval forward shows up under its operator name in the profiler, and the model's prediction goes through it."""

@@ -943,7 +943,9 @@ def test_gather_wgrad_2x2_stage(Fr, gh, gw, variant):
     L.check(lib.bf_gather_wgrad(1, _p(fine), _p(coarse), *fs, *cs, _p(out), tr, Fr, gh, gw, C0, C0, _p(ws), nws, _stream()), "gather_wgrad")
     assert torch.equal(first, out)
     assert lib.bf_gather_wgrad(0, _p(fine), _p(coarse), *fs, *cs, _p(out), tr, Fr, gh, gw, C0, C0, _p(ws), nws, _stream()) == 1            # fp32
-    assert lib.bf_gather_wgrad(1, _p(fine), _p(coarse), *fs, *cs, _p(out), tr, Fr, gh, gw, C0, C0, _p(ws), nws - 1, _stream()) == 1        # workspace
+    assert lib.bf_gather_wgrad(1, _p(fine), _p(coarse), *fs, *cs, _p(out), tr, Fr, gh, gw, C0, C0, _p(ws), Fr * 36864 - 1, _stream()) == 1        # workspace: not one slab per frame
+    L.check(lib.bf_gather_wgrad(1, _p(fine), _p(coarse), *fs, *cs, _p(out), tr, Fr, gh, gw, C0, C0, _p(ws), Fr * 36864, _stream()), "one run per frame")
+    assert _rel(out.t() if tr else out, ref) < 3e-3
     assert lib.bf_gather_wgrad(1, _p(fine), _p(coarse), _p(sc), _p(sh), _p(sc), _p(sh), _p(out), tr, Fr, gh, gw, C0, C0, _p(ws), nws, _stream()) == 1
 
 
