@@ -55,7 +55,7 @@ __device__ __forceinline__ float bf_bits_f(short b) { return __uint_as_float(((u
 __device__ __forceinline__ short f_bf_bits(float x) { return __builtin_bit_cast(short, (bf16)x); }
 
 struct TailArgs {
-    const bf16 *dy1, *w1, *y0, *patches;
+    const bf16 *dy1, *w1, *y0, *patches, *w0;     // y0 may be null: the stage-0 rows are then rebuilt from the patch rows (y0 = W0 . patch)
     const float *sc, *sh, *mean, *rstd;
     float* part;
     int F, gh1, gw1, tpw, cpf;        // stage-1 grid, 32-row tiles per wave, row runs per frame
@@ -63,19 +63,22 @@ struct TailArgs {
 
 constexpr int TWAVES = 4;
 template <int NCB> constexpr int tail_npart() { return 16 * NCB * 16 + 256 + 16 + 2 * 16 * NCB; }      // G | M2 | P1 | s1 | s2
-template <int NCB, int NKS> constexpr int tail_tiles_bytes() { return (32 * NKS * (16 * NCB + 8) + TWAVES * (32 * (16 * NCB + 8) + 32 * 24)) * 2; }
-template <int NCB, int NKS> constexpr int tail_lds_bytes() { return tail_tiles_bytes<NCB, NKS>() + 16 * NCB * 16; }
+// the weight slice + per wave {y0 tile (YMAP only), patch tile}; the final reduction (4 rows of partials) reuses the region
+template <int NCB, int NKS, bool YMAP> constexpr int tail_tiles_bytes() {
+    const int tiles = (32 * NKS * (16 * NCB + 8) + TWAVES * ((YMAP ? 32 * (16 * NCB + 8) : 0) + 32 * 24)) * 2, red = TWAVES * tail_npart<NCB>() * 4;
+    return tiles > red ? tiles : red;
+}
+template <int NCB, int NKS, bool YMAP> constexpr int tail_lds_bytes() { return tail_tiles_bytes<NCB, NKS, YMAP>() + 16 * NCB * 16; }
 
-template <int NCB, int NKS>
+template <int NCB, int NKS, bool YMAP>
 __global__ void __launch_bounds__(64 * TWAVES, 2) embed_tail_bwd_kernel(TailArgs a) {
     constexpr int C0 = 16 * NCB, C1 = 32 * NKS, LDW = C0 + 8, LDY = C0 + 8, LDP = 24, CPR = C0 / 8;
     constexpr int NPART = tail_npart<NCB>();
-    static_assert(TWAVES * NPART * 4 <= tail_tiles_bytes<NCB, NKS>(), "the final reduction reuses the tiles");
     extern __shared__ __attribute__((aligned(16))) char smem_tail[];
     bf16* Wt = reinterpret_cast<bf16*>(smem_tail);                                   // [C1][LDW]: this q's columns of the stage-1 weight
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    bf16* ytile = Wt + C1 * LDW + wave * (32 * LDY + 32 * LDP);                      // [32][LDY] raw stage-0 rows of the tile
-    bf16* ptile = ytile + 32 * LDY;                                                  // [32][LDP] their patch rows
+    bf16* ytile = Wt + C1 * LDW + wave * ((YMAP ? 32 * LDY : 0) + 32 * LDP);         // [32][LDY] raw stage-0 rows of the tile (YMAP)
+    bf16* ptile = ytile + (YMAP ? 32 * LDY : 0);                                     // [32][LDP] their patch rows
     const int i16 = lane & 15, g = lane >> 4;
     // (run, q) with q fastest; workgroups of one XCD (blockIdx % 8 under round-robin placement; speed only) take consecutive ones, so
     // the four q of a run read their dy1 rows from the same L2
@@ -91,7 +94,7 @@ __global__ void __launch_bounds__(64 * TWAVES, 2) embed_tail_bwd_kernel(TailArgs
         *reinterpret_cast<bf16x8*>(Wt + k * LDW + 8 * ch) = *reinterpret_cast<const bf16x8*>(a.w1 + (long)k * (4 * C0) + q * C0 + 8 * ch);
     }
     // per-(frame, channel) constants {sc, sh, rstd, -mean * rstd}: one 16-byte LDS read per channel block and tile instead of 4 NCB live registers
-    float4* cst = reinterpret_cast<float4*>(smem_tail + tail_tiles_bytes<NCB, NKS>());
+    float4* cst = reinterpret_cast<float4*>(smem_tail + tail_tiles_bytes<NCB, NKS, YMAP>());
     for (int c = tid; c < C0; c += 64 * TWAVES) {
         const long o = (long)f * C0 + c;
         const float r = a.rstd[o];
@@ -115,8 +118,15 @@ __global__ void __launch_bounds__(64 * TWAVES, 2) embed_tail_bwd_kernel(TailArgs
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
 
+    // !YMAP: y0[pixel][c] = sum_k patch[pixel][k] W0[c][k] per tile, one v_mfma_f32_16x16x16_bf16 per (row block, channel block): A = the
+    // patch rows (lane = pixel, k = 4g..4g+3: an 8-byte load), B = this lane's row of W0 -- the result lands in the accumulator layout
+    s16x4 w0f[YMAP ? 1 : NCB], pa[2];
+    if (!YMAP) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) w0f[cb] = *reinterpret_cast<const s16x4*>(a.w0 + (16 * cb + i16) * 16 + 4 * g);
+    }
     bf16x8 af[2][NKS];
-    u32x4 yr[NCB], pr;
+    u32x4 yr[YMAP ? NCB : 1], pr;
     // a 16-row block of the stage-1 grid lies inside one image row (gw1 % 16 == 0): its stage-0 pixels of position q are 2 apart
     auto pixel0 = [&](int tt, int rb) __attribute__((always_inline)) -> long {
         const unsigned pl = 32u * (unsigned)tt + 16u * (unsigned)rb, y = pl / gw1, x0 = pl - y * gw1;
@@ -124,8 +134,13 @@ __global__ void __launch_bounds__(64 * TWAVES, 2) embed_tail_bwd_kernel(TailArgs
     };
     auto issue_rows = [&](int tt) __attribute__((always_inline)) {
         const long p0 = pixel0(tt, 0), p1 = pixel0(tt, 1);
+        if (YMAP) {
 #pragma unroll
-        for (int j = 0; j < NCB; ++j) yr[j] = *reinterpret_cast<const u32x4*>(a.y0 + (j < NCB / 2 ? p0 : p1) * C0 + yg0 + 32 * (j % (NCB / 2)));
+            for (int j = 0; j < NCB; ++j) yr[j] = *reinterpret_cast<const u32x4*>(a.y0 + (j < NCB / 2 ? p0 : p1) * C0 + yg0 + 32 * (j % (NCB / 2)));
+        } else {
+            pa[0] = *reinterpret_cast<const s16x4*>(a.patches + (p0 + 2 * i16) * 16 + 4 * g);
+            pa[1] = *reinterpret_cast<const s16x4*>(a.patches + (p1 + 2 * i16) * 16 + 4 * g);
+        }
         pr = *reinterpret_cast<const u32x4*>(a.patches + (phi ? p1 : p0) * 16 + poff);
     };
     auto issue_a = [&](int tt) __attribute__((always_inline)) {
@@ -140,9 +155,12 @@ __global__ void __launch_bounds__(64 * TWAVES, 2) embed_tail_bwd_kernel(TailArgs
     issue_a(tt0);
     for (int t = 0; t < a.tpw; ++t) {
         const int tt = tt0 + t;
+        if (YMAP) {
 #pragma unroll
-        for (int j = 0; j < NCB; ++j) *reinterpret_cast<u32x4*>(ytile + yl0 + (j / (NCB / 2)) * 16 * LDY + 32 * (j % (NCB / 2))) = yr[j];
+            for (int j = 0; j < NCB; ++j) *reinterpret_cast<u32x4*>(ytile + yl0 + (j / (NCB / 2)) * 16 * LDY + 32 * (j % (NCB / 2))) = yr[j];
+        }
         *reinterpret_cast<u32x4*>(ptile + plds) = pr;
+        const s16x4 pa0 = pa[0], pa1 = pa[1];
         wsync();
         if (t + 1 < a.tpw) issue_rows(tt + 1);            // in flight under the products and the epilogue below
         // ---- dact[pixel][c] = sum_co dy1[pixel][co] W1[co][(q, c)]: lane (c = 16 cb + i16) holds pixels 16 rb + 4 g + r
@@ -167,14 +185,24 @@ __global__ void __launch_bounds__(64 * TWAVES, 2) embed_tail_bwd_kernel(TailArgs
         accP1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, accP1, 0, 0, 0);
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
-            const s16x4 y0v = tr4(ytile, LDY, 4 * g, 16 * cb, lane), y1v = tr4(ytile, LDY, 16 + 4 * g, 16 * cb, lane);
+            float yy[2][4];
+            if (YMAP) {
+                const s16x4 y0v = tr4(ytile, LDY, 4 * g, 16 * cb, lane), y1v = tr4(ytile, LDY, 16 + 4 * g, 16 * cb, lane);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { yy[0][r] = bf_bits_f(y0v[r]); yy[1][r] = bf_bits_f(y1v[r]); }
+            } else {      // rounded to bf16 like the rows the forward normalised
+                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 m0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa0, w0f[cb], z4, 0, 0, 0), m1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa1, w0f[cb], z4, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { yy[0][r] = (float)(bf16)m0[r]; yy[1][r] = (float)(bf16)m1[r]; }
+            }
             const float4 k4 = cst[16 * cb + i16];
             s16x8 ddp;
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float y = bf_bits_f(rb ? y1v[r] : y0v[r]);
+                    const float y = yy[rb][r];
                     const float dd = acc[rb][cb][r] * dgelu_fast(fmaf(y, k4.x, k4.y));
                     s1[cb] += dd;
                     s2[cb] = fmaf(dd, fmaf(y, k4.z, k4.w), s2[cb]);
@@ -292,7 +320,7 @@ extern "C" int bf_embed_tail_bwd(int dtype, const void* dy1, const void* w1c, co
     const long S1 = (long)gh1 * gw1;
     int tpw, cpf;
     if (!tail_plan(S1, &tpw, &cpf)) return 1;
-    BF_REQUIRE(dy1 && w1c && y0 && patches && w0c && sc && sh && mean && rstd && in_w && dwprep && ws, "bf_embed_tail_bwd: null pointer");
+    BF_REQUIRE(dy1 && w1c && patches && w0c && sc && sh && mean && rstd && in_w && dwprep && ws, "bf_embed_tail_bwd: null pointer");
     BF_REQUIRE((((uintptr_t)dy1 | (uintptr_t)w1c | (uintptr_t)y0 | (uintptr_t)patches) & 15) == 0, "bf_embed_tail_bwd: operands must be 16-byte aligned");
     const long nwg = (long)F * cpf * 4;
     BF_REQUIRE(nwg < (1L << 30), "bf_embed_tail_bwd: grid too large");
@@ -303,22 +331,23 @@ extern "C" int bf_embed_tail_bwd(int dtype, const void* dy1, const void* w1c, co
     float* part = ws;
     float* slab = part + nwg * NPART;
     float* sums = slab + (size_t)F * C0 * 16;
-    TailArgs a{(const bf16*)dy1, (const bf16*)w1c, (const bf16*)y0, (const bf16*)patches, sc, sh, mean, rstd, part, F, gh1, gw1, tpw, cpf};
+    TailArgs a{(const bf16*)dy1, (const bf16*)w1c, (const bf16*)y0, (const bf16*)patches, (const bf16*)w0c, sc, sh, mean, rstd, part, F, gh1, gw1, tpw, cpf};
     {
         const double rows = (double)F * S1;
         BfProfScope prof(st, "embed_tail_bwd", 2.0 * rows * C1 * 4 * C0 + 2.0 * rows * 4 * (C0 + 2) * 16, rows * C1 * 2.0 + rows * 4 * (C0 + 16) * 2.0);
-#define BF_TAIL_GO(NKS)                                                                                                                    \
+#define BF_TAIL_GO(NKS, YM)                                                                                                                \
         do {                                                                                                                              \
-            constexpr int lds = tail_lds_bytes<6, NKS>();                                                                                 \
+            constexpr int lds = tail_lds_bytes<6, NKS, YM>();                                                                             \
             static bool attr_done = false;                                                                                                \
             if (!attr_done) {                                                                                                             \
-                hipError_t e_ = hipFuncSetAttribute((const void*)embed_tail_bwd_kernel<6, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+                hipError_t e_ = hipFuncSetAttribute((const void*)embed_tail_bwd_kernel<6, NKS, YM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
                 if (e_ != hipSuccess) return bf_fail(e_, __FILE__, __LINE__);                                                             \
                 attr_done = true;                                                                                                         \
             }                                                                                                                             \
-            hipLaunchKernelGGL((embed_tail_bwd_kernel<6, NKS>), dim3((unsigned)nwg), dim3(64 * TWAVES), lds, st, a);                      \
+            hipLaunchKernelGGL((embed_tail_bwd_kernel<6, NKS, YM>), dim3((unsigned)nwg), dim3(64 * TWAVES), lds, st, a);                  \
         } while (0)
-        if (C1 == 96) BF_TAIL_GO(3); else BF_TAIL_GO(6);
+        if (y0) { if (C1 == 96) BF_TAIL_GO(3, true); else BF_TAIL_GO(6, true); }
+        else { if (C1 == 96) BF_TAIL_GO(3, false); else BF_TAIL_GO(6, false); }
 #undef BF_TAIL_GO
         BF_CHECK_LAUNCH();
     }

@@ -1272,7 +1272,8 @@ extern "C" int bf_embed_bwd(const bf_dims* dims, const bf_embed_params* p, const
             const int64_t need = bf_embed_tail_ws_floats((int)d.F, sv.gh[1], sv.gw[1], cp, sv.Kp);
             if (tail_on && need > 0 && need + (int64_t)cp * sv.Kp <= sc.tokred_floats) {
                 float* dwprep = sc.tokred_ws + need;
-                const int trc = bf_embed_tail_bwd(d.dtype, dy, sv.wc[1], sv.y[0], sv.patches, sv.wc[0], sv.sc[0], sv.sh[0], sv.mean[0], sv.rstd[0],
+                static const bool tail_map = bf_knob("BF_EMBED_TAIL_MAP", 0) != 0;      // 1: read the stored stage-0 map instead of rebuilding its rows
+                const int trc = bf_embed_tail_bwd(d.dtype, dy, sv.wc[1], tail_map ? sv.y[0] : nullptr, sv.patches, sv.wc[0], sv.sc[0], sv.sh[0], sv.mean[0], sv.rstd[0],
                                                   p->in_w[0], dwprep, g->in_w[0], g->in_b[0], (int)d.F, sv.gh[1], sv.gw[1], sv.C[1], cp, sv.Kp,
                                                   sc.tokred_ws, need, s);
                 if (trc < 0) return trc;

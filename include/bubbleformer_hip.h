@@ -230,7 +230,7 @@ int bf_in_stats_merge_slices(int dtype, int frames, int S, int C, int rows, cons
 /* The tail of the HMLPEmbed backward when the input needs no gradient (layers/patching.py:24-56 under autograd): the stage-1 data
  * gradient dy1 [frames*gh1*gw1][C1] times w1c [C1][4*C0] (the stage-1 weight, columns (2*ky + kx)*C0 + c), GELU', the stage-0 InstanceNorm
  * backward and the stage-0 weight gradient in one pass that never writes the [frames*4*gh1*gw1][C0] gradient map.  y0: raw stage-0
- * output, patches [..][Kp] (bf_embed_first), w0c [C0][Kp], sc / sh / mean / rstd [frames][C0] of the stage-0 InstanceNorm, in_w its
+ * output, or NULL (its rows are then rebuilt from the patch rows: y0 = W0 . patch); patches [..][Kp] (bf_embed_first), w0c [C0][Kp], sc / sh / mean / rstd [frames][C0] of the stage-0 InstanceNorm, in_w its
  * weight.  dwprep [C0][Kp] is WRITTEN (bf_wgrad_unprep folds it into the gradient), d_in_w / d_in_b [C0] are accumulated (optional).
  * ws: bf_embed_tail_ws_floats floats.  Returns 1 (nothing launched) for shapes it does not take: fp32, C0 != 96, C1 not in {96, 192}, Kp != 16,
  * gw1 % 16, gh1*gw1 % 128, or a workspace that is too small. */

@@ -992,6 +992,12 @@ def test_embed_backward_tail_one_pass(Fr, gh1, gw1, C1):
     first = dwprep.clone()
     L.check(lib.bf_embed_tail_bwd(1, *args, Fr, gh1, gw1, C1, C0, Kp, _p(ws), nws, _stream()), "embed_tail_bwd")
     assert torch.equal(first, dwprep)                      # fixed summation order: bit-reproducible
+    # without the stored stage-0 map: its rows are rebuilt from the patch rows (y0 = W0 . patch, rounded like the stored ones)
+    dw2, db2 = torch.full((C0,), 2.0, device="cuda"), torch.full((C0,), -1.0, device="cuda")
+    args2 = [_p(t) if t is not None else None for t in (dy1, W1, None, patches, W0, sc, sh, mean, rstd, in_w, dwprep, dw2, db2)]
+    dwprep.fill_(float("nan"))
+    L.check(lib.bf_embed_tail_bwd(1, *args2, Fr, gh1, gw1, C1, C0, Kp, _p(ws), nws, _stream()), "embed_tail_bwd (rebuilt rows)")
+    assert _rel(dwprep, first) < 1e-5 and _rel(dw2 - 2.0, wr.grad) < 1e-2 and _rel(db2 + 1.0, br.grad) < 1e-2
     # declined shapes: nothing launched
     assert lib.bf_embed_tail_bwd(0, *args, Fr, gh1, gw1, C1, C0, Kp, _p(ws), nws, _stream()) == 1        # fp32
     assert lib.bf_embed_tail_bwd(1, *args, Fr, gh1, gw1 + 8, C1, C0, Kp, _p(ws), nws, _stream()) == 1    # gw1 % 16
