@@ -519,14 +519,16 @@ extern "C" int bf_gemm_tokred(int dtype, int Nout, int Kin, int64_t M, const voi
     // gemm_frame.hip); both queues end up equally long, so what counts is the sum of their CU-time.  Measured in the step (targets of
     // 48 / 64 / 80 / 96 / 128 workgroups: 681 / 693 / 701 / 707 / 699 samples/s before the embed / debed rework; after it, same box,
     // 80 / 96 / 112 / 128 / 160 / 192 / 256: 765 / 768 / 768 / 771 / 767 / 766 / 766): 128, from which the slice count follows per shape
-    // (QKV 12 tiles of 192 x 192 x 10, fc1 / fc2 8 tiles of 384 x 192 x 16, out-projection 4 tiles of 192 x 192 x 16).
+    // (QKV 12 tiles of 192 x 192 x 10, fc1 / fc2 16 x 8, out-projection 4 x 16).
     static const int slices_env = bf_knob("BF_TOKRED_SLICES", 0);      // sweeps: a fixed slice count / tile height / workgroup target
     static const int tile_env = bf_knob("BF_TOKRED_TILE", 0);
     static const int wgs_env = bf_knob("BF_TOKRED_WGS", 128);
     if (pp) {
         const long halves = M / HR;
         const int tiles_k0 = Kin / PTN;
-        const bool big = Nout % 384 == 0 && tile_env != 192 && (tile_env == 384 || (Nout / 384) * tiles_k0 * MAX_SLICES >= wgs_env);
+        // 384-row tiles stage 25 % fewer bytes per FLOP, 192-row tiles give twice the workgroups to place beside the caller's kernels: in the
+        // step 192 wins (same box: 762 against 759 mixed and 755 all-384 samples/s); BF_TOKRED_TILE=384 keeps the other form reachable
+        const bool big = Nout % 384 == 0 && tile_env == 384;
         const int tm = big ? 384 : 192;
         int nslice = slices_env > 0 ? slices_env : std::max(1, wgs_env / ((Nout / tm) * tiles_k0));
         nslice = (int)std::max<long>(1, std::min<long>({(long)nslice, (long)MAX_SLICES, halves / 4}));
