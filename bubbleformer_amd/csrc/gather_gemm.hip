@@ -31,6 +31,7 @@ __device__ __forceinline__ bf16x8 cat8(s16x4 lo, s16x4 hi) {
 }
 
 struct GatherArgs {
+    const bf16 *patches, *w0; // REB: the fine map is W0 . patch ([pixels][16] x [C0][16]) and is rebuilt per tile instead of read
     const bf16* map;          // [F][2 gh][2 gw][C0]
     const bf16* w;            // kn: [4 C0][N] (n contiguous), else [N][4 C0] (k contiguous)
     bf16* out;                // [F gh gw][N]
@@ -40,7 +41,7 @@ struct GatherArgs {
 
 template <int NCB, int NNB> constexpr int gather_lds_bytes() { return 16 * NNB * (64 * NCB + 8) * 2; }
 
-template <int NCB, int NNB, bool PRO>
+template <int NCB, int NNB, bool PRO, bool REB = false>
 __global__ void __launch_bounds__(64 * GW, 2) gather_gemm_kernel(GatherArgs a) {
     constexpr int C0 = 16 * NCB, N = 16 * NNB, K = 4 * C0, LDK = K + 8, NS = C0 / 32;
     static_assert(C0 % 32 == 0 && NNB % 2 == 0, "32-channel slabs, column blocks in pairs");
@@ -70,15 +71,29 @@ __global__ void __launch_bounds__(64 * GW, 2) gather_gemm_kernel(GatherArgs a) {
     float csc[PRO ? NS : 1][8], csh[PRO ? NS : 1][8];
     int cf = -1;
     // B-operand registers of one 2x2 position: [row block][slab], lane (coarse row i16, channels 32 s + 8 g ..)
-    bf16x8 cur[2][NS], nxt[2][NS];
-    auto issue = [&](int tt, int q, bf16x8 (&dst)[2][NS]) __attribute__((always_inline)) {
+    // REB: only the 8 bytes of the pixel's patch row this lane multiplies (k = 4g..4g+3) travel; the map rows come out of one
+    // v_mfma_f32_16x16x16_bf16 per 16 channels (A = this lane's row of W0, B = the patch rows) as 4 consecutive channels per lane, so
+    // slab s takes its k-slots in the order {32 s + 4 g + j} U {32 s + 16 + 4 g + j} -- the weight operand is read in the same order
+    constexpr int NR = REB ? 1 : NS;
+    bf16x8 cur[2][NR], nxt[2][NR];
+    s16x4 w0f[REB ? NCB : 1];
+    if (REB) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) w0f[cb] = *reinterpret_cast<const s16x4*>(a.w0 + (16 * cb + i16) * 16 + 4 * g);
+    }
+    auto issue = [&](int tt, int q, bf16x8 (&dst)[2][NR]) __attribute__((always_inline)) {
         const unsigned f = (unsigned)tt / tpf, tl = (unsigned)tt - f * tpf;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             const unsigned pl = 32u * tl + 16u * rb + (unsigned)i16, y = pl / gw, x = pl - y * gw;     // per lane: a 16-row block may wrap an image row
             const long pix = ((long)f * (2 * a.gh) + 2 * y + (q >> 1)) * (2L * a.gw) + 2 * x + (q & 1);
+            if (REB) {
+                const s16x4 v = *reinterpret_cast<const s16x4*>(a.patches + pix * 16 + 4 * g);
+                dst[rb][0] = __builtin_bit_cast(bf16x8, s16x8{v[0], v[1], v[2], v[3], 0, 0, 0, 0});
+            } else {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) dst[rb][s] = *reinterpret_cast<const bf16x8*>(a.map + pix * C0 + 32 * s + 8 * g);
+                for (int s = 0; s < NS; ++s) dst[rb][s] = *reinterpret_cast<const bf16x8*>(a.map + pix * C0 + 32 * s + 8 * g);
+            }
         }
     };
     issue(t_beg, 0, cur);
@@ -90,7 +105,10 @@ __global__ void __launch_bounds__(64 * GW, 2) gather_gemm_kernel(GatherArgs a) {
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { csc[s][j] = a.sc[(long)f * C0 + 32 * s + 8 * g + j]; csh[s][j] = a.sh[(long)f * C0 + 32 * s + 8 * g + j]; }
+                    for (int j = 0; j < 8; ++j) {
+                        const int c = REB ? 32 * s + 16 * (j >> 2) + 4 * g + (j & 3) : 32 * s + 8 * g + j;
+                        csc[s][j] = a.sc[(long)f * C0 + c]; csh[s][j] = a.sh[(long)f * C0 + c];
+                    }
             }
         }
         f32x4 acc[NNB][2];
@@ -105,14 +123,26 @@ __global__ void __launch_bounds__(64 * GW, 2) gather_gemm_kernel(GatherArgs a) {
                 bf16x8 fb[2];
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb) {
-                    if (PRO) {
+                    if (REB) {
+                        const s16x8 pv = __builtin_bit_cast(s16x8, cur[rb][0]);
+                        const s16x4 pb = {pv[0], pv[1], pv[2], pv[3]};
+                        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                        const f32x4 lo = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0f[2 * s], pb, z4, 0, 0, 0), hi = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0f[2 * s + 1], pb, z4, 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {      // rounded to bf16 like the rows the statistics were taken of
+                            fb[rb][j] = (bf16)gelu_fast(fmaf((float)(bf16)lo[j], csc[s][j], csh[s][j]));
+                            fb[rb][4 + j] = (bf16)gelu_fast(fmaf((float)(bf16)hi[j], csc[s][4 + j], csh[s][4 + j]));
+                        }
+                    } else if (PRO) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) fb[rb][j] = (bf16)gelu_fast(fmaf((float)cur[rb][s][j], csc[s][j], csh[s][j]));
                     } else fb[rb] = cur[rb][s];
                 }
 #pragma unroll
                 for (int nb = 0; nb < NNB; ++nb) {
-                    const bf16x8 aw = *reinterpret_cast<const bf16x8*>(Wt + (16 * nb + i16) * LDK + C0 * q + 32 * s + 8 * g);
+                    const bf16* wrow = Wt + (16 * nb + i16) * LDK + C0 * q + 32 * s;
+                    const bf16x8 aw = REB ? cat8(*reinterpret_cast<const s16x4*>(wrow + 4 * g), *reinterpret_cast<const s16x4*>(wrow + 16 + 4 * g))
+                                          : *reinterpret_cast<const bf16x8*>(wrow + 8 * g);
 #pragma unroll
                     for (int rb = 0; rb < 2; ++rb) acc[nb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw, fb[rb], acc[nb][rb], 0, 0, 0);
                 }
@@ -121,7 +151,7 @@ __global__ void __launch_bounds__(64 * GW, 2) gather_gemm_kernel(GatherArgs a) {
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                for (int s = 0; s < NS; ++s) cur[rb][s] = nxt[rb][s];
+                for (int s = 0; s < NR; ++s) cur[rb][s] = nxt[rb][s];
         }
         // acc[nb][rb]: coarse row 16 rb + i16, columns 16 nb + 4 g .. +3.  Exchanging the odd lane rows of block 2 pp with the even lane
         // rows of block 2 pp + 1 leaves 8 consecutive columns at 32 pp + 16 (g & 1) + 8 (g >> 1)
@@ -287,12 +317,13 @@ __global__ void __launch_bounds__(64 * GW, 2) scatter_gemm_kernel(ScatterArgs a)
 // tile is double-buffered), global loads one step ahead.  Partials: one [384][96] fp32 slab per workgroup, summed in a fixed order.
 constexpr int WW = 8;                                   // waves per workgroup
 struct WgradArgs {
+    const bf16 *patches, *w0;                           // FREB: fine = W0 . patch, rebuilt per step (see gather_gemm_kernel)
     const bf16 *fine, *coarse;
     const float *fsc, *fsh, *csc, *csh;                 // [F][96] each, or null
     float* slab;                                        // [workgroups][384][96]
     int F, gh, gw, rpf, steps;                          // runs per frame, 32-row steps per run
 };
-template <bool FPRO, bool CPRO>
+template <bool FPRO, bool CPRO, bool FREB = false>
 __global__ void __launch_bounds__(64 * WW, 4) gather_wgrad_kernel(WgradArgs a) {
     constexpr int C = 96, HC = 48, LDF = HC + 8, LDC = C + 8;
     __shared__ __attribute__((aligned(16))) bf16 ctile[2][32 * LDC];
@@ -312,12 +343,25 @@ __global__ void __launch_bounds__(64 * WW, 4) gather_wgrad_kernel(WgradArgs a) {
     const int crow = tid / 12, cch = 8 * (tid - 12 * crow);
     const bool cth = tid < 32 * 12;
     bf16x8 fr[3], cr;
+    s16x4 pa[2], w0f[3];                                // FREB: patch rows of the two 16-row blocks (lane = row i16, k = 4g..), this lane's rows of W0
+    if (FREB) {
+#pragma unroll
+        for (int cb = 0; cb < 3; ++cb) w0f[cb] = *reinterpret_cast<const s16x4*>(a.w0 + (HC * half + 16 * cb + i16) * 16 + 4 * g);
+    }
     auto issue = [&](int st) __attribute__((always_inline)) {
         const unsigned tl = (unsigned)(run * a.steps + st);                      // 32-row tile inside the frame
-        const unsigned pl = 32u * tl + (unsigned)frow, y = pl / gw, x = pl - y * gw;
-        const bf16* src = a.fine + (((long)f * (2 * a.gh) + 2 * y + (q >> 1)) * (2L * a.gw) + 2 * x + (q & 1)) * C + HC * half + fc0;
+        if (FREB) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) fr[j] = *reinterpret_cast<const bf16x8*>(src + 16 * j);
+            for (int rb = 0; rb < 2; ++rb) {
+                const unsigned pl = 32u * tl + 16u * rb + (unsigned)i16, y = pl / gw, x = pl - y * gw;
+                pa[rb] = *reinterpret_cast<const s16x4*>(a.patches + (((long)f * (2 * a.gh) + 2 * y + (q >> 1)) * (2L * a.gw) + 2 * x + (q & 1)) * 16 + 4 * g);
+            }
+        } else {
+            const unsigned pl = 32u * tl + (unsigned)frow, y = pl / gw, x = pl - y * gw;
+            const bf16* src = a.fine + (((long)f * (2 * a.gh) + 2 * y + (q >> 1)) * (2L * a.gw) + 2 * x + (q & 1)) * C + HC * half + fc0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) fr[j] = *reinterpret_cast<const bf16x8*>(src + 16 * j);
+        }
         if (cth) cr = *reinterpret_cast<const bf16x8*>(a.coarse + ((long)f * a.gh * a.gw + 32L * tl + crow) * C + cch);
     };
     f32x4 acc[3][6];
@@ -328,6 +372,25 @@ __global__ void __launch_bounds__(64 * WW, 4) gather_wgrad_kernel(WgradArgs a) {
     issue(0);
     for (int st = 0; st < a.steps; ++st) {
         bf16* ct = ctile[st & 1];
+        if (FREB) {      // D[c][pixel] = W0 rows x patch rows: lane (pixel i16, channels 16 cb + 4 g .. +3) -> an 8-byte piece of the tile row
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4w;
+            int ko = HC * half + 4 * g;              // an offset the compiler cannot see through: the 12 constant pairs stay in LDS, not in 24 registers
+            asm volatile("" : "+v"(ko));
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 3; ++cb) {
+                    const f32x4 y4 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0f[cb], pa[rb], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    bf16x4w o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float2 k2 = kf[ko + 16 * cb + e];
+                        o[e] = (bf16)gelu_fast(fmaf((float)(bf16)y4[e], k2.x, k2.y));
+                    }
+                    *reinterpret_cast<bf16x4w*>(ftile + (16 * rb + i16) * LDF + 16 * cb + 4 * g) = o;
+                    __builtin_amdgcn_sched_barrier(0);      // one block at a time: six results in flight would not fit beside the 72 accumulators
+                }
+        } else
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             bf16x8 v = fr[j];
@@ -406,15 +469,15 @@ int gg_cus() {
 
 }  // namespace
 
-// 0 = done, 1 = shape not covered (nothing launched)
-extern "C" int bf_gather_gemm(int dtype, const void* map, const void* w, int w_kn, const float* sc, const float* sh, void* out, int F, int gh,
-                              int gw, int C0, int N, bf_stream_t stream) {
+static int gather_gemm_launch(int dtype, const void* map, const void* patches, const void* w0c, const void* w, int w_kn, const float* sc, const float* sh,
+                              void* out, int F, int gh, int gw, int C0, int N, bf_stream_t stream) {
     if (dtype != BF_DTYPE_BF16 || C0 != 96 || N != 96) return 1;
     if (F <= 0 || gh <= 0 || gw <= 0 || ((long)gh * gw) % 32) return 1;
     static const bool off = bf_knob("BF_GATHER_GEMM", 1) == 0;
     if (off) return 1;
-    BF_REQUIRE(map && w && out && (!sc == !sh), "bf_gather_gemm: bad arguments");
-    BF_REQUIRE((((uintptr_t)map | (uintptr_t)w | (uintptr_t)out) & 15) == 0, "bf_gather_gemm: operands must be 16-byte aligned");
+    const bool reb = map == nullptr;
+    BF_REQUIRE((map || (patches && w0c && sc)) && w && out && (!sc == !sh), "bf_gather_gemm: bad arguments");
+    BF_REQUIRE((((uintptr_t)map | (uintptr_t)patches | (uintptr_t)w0c | (uintptr_t)w | (uintptr_t)out) & 15) == 0, "bf_gather_gemm: operands must be 16-byte aligned");
     const long tiles = (long)F * gh * gw / 32;
     BF_REQUIRE(tiles < (1L << 30), "bf_gather_gemm: too many rows");
     hipStream_t st = (hipStream_t)stream;
@@ -422,24 +485,38 @@ extern "C" int bf_gather_gemm(int dtype, const void* map, const void* w, int w_k
     // as few workgroups as give every wave the same number of tiles as a full grid would (each loads the whole weight first)
     const long rounds = (tiles + 2L * cus * GW - 1) / (2L * cus * GW), nwaves = (tiles + rounds - 1) / rounds;
     const int grid = (int)((nwaves + GW - 1) / GW);
-    GatherArgs a{(const bf16*)map, (const bf16*)w, (bf16*)out, sc, sh, w_kn, F, gh, gw, (int)tiles};
+    GatherArgs a{(const bf16*)patches, (const bf16*)w0c, (const bf16*)map, (const bf16*)w, (bf16*)out, sc, sh, w_kn, F, gh, gw, (int)tiles};
     constexpr int lds = gather_lds_bytes<6, 6>();
     const double rows = (double)F * gh * gw;
-    BfProfScope prof(st, sc ? "gather_gemm<gelu>" : "gather_gemm<plain>", 2.0 * rows * 4 * C0 * N, rows * (4.0 * C0 + N) * 2.0);
-#define BF_GG_GO(PRO)                                                                                                                      \
+    BfProfScope prof(st, reb ? "gather_gemm<gelu,rebuilt>" : sc ? "gather_gemm<gelu>" : "gather_gemm<plain>", 2.0 * rows * 4 * C0 * N,
+                     rows * ((reb ? 4.0 * 16 : 4.0 * C0) + N) * 2.0);
+#define BF_GG_GO(PRO, REB)                                                                                                                 \
     do {                                                                                                                                  \
         static bool attr_done = false;                                                                                                    \
         if (!attr_done) {                                                                                                                 \
-            hipError_t e_ = hipFuncSetAttribute((const void*)gather_gemm_kernel<6, 6, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            hipError_t e_ = hipFuncSetAttribute((const void*)gather_gemm_kernel<6, 6, PRO, REB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
             if (e_ != hipSuccess) return bf_fail(e_, __FILE__, __LINE__);                                                                 \
             attr_done = true;                                                                                                             \
         }                                                                                                                                 \
-        hipLaunchKernelGGL((gather_gemm_kernel<6, 6, PRO>), dim3(grid), dim3(64 * GW), lds, st, a);                                       \
+        hipLaunchKernelGGL((gather_gemm_kernel<6, 6, PRO, REB>), dim3(grid), dim3(64 * GW), lds, st, a);                                  \
     } while (0)
-    if (sc) BF_GG_GO(true); else BF_GG_GO(false);
+    if (reb) BF_GG_GO(true, true); else if (sc) BF_GG_GO(true, false); else BF_GG_GO(false, false);
 #undef BF_GG_GO
     BF_CHECK_LAUNCH();
     return 0;
+}
+// 0 = done, 1 = shape not covered (nothing launched)
+extern "C" int bf_gather_gemm(int dtype, const void* map, const void* w, int w_kn, const float* sc, const float* sh, void* out, int F, int gh,
+                              int gw, int C0, int N, bf_stream_t stream) {
+    BF_REQUIRE(map, "bf_gather_gemm: null map");
+    return gather_gemm_launch(dtype, map, nullptr, nullptr, w, w_kn, sc, sh, out, F, gh, gw, C0, N, stream);
+}
+// the same with the fine map given as its factors: map[pixel][c] = sum_k patches[pixel][k] * w0c[c][k] (Kp = 16: the first HMLPEmbed stage),
+// rebuilt per tile and rounded to bf16 like a stored map -- the 2x2 stage behind bf_embed_first without reading (or needing) its output
+extern "C" int bf_gather_gemm_rebuilt(int dtype, const void* patches, const void* w0c, const void* w, int w_kn, const float* sc, const float* sh, void* out,
+                                      int F, int gh, int gw, int C0, int N, bf_stream_t stream) {
+    BF_REQUIRE(patches && w0c && sc && sh, "bf_gather_gemm_rebuilt: null pointer");
+    return gather_gemm_launch(dtype, nullptr, patches, w0c, w, w_kn, sc, sh, out, F, gh, gw, C0, N, stream);
 }
 
 // 0 = done, 1 = shape not covered (nothing launched).  stat_part (optional): the slice partials, 128-row slices, at ws + 2*frames*C0 of the
@@ -492,25 +569,42 @@ extern "C" int64_t bf_gather_wgrad_ws_floats(int F, int gh, int gw) {
     return (int64_t)F * wgrad_runs(F, (int)((long)gh * gw / 32), INT64_MAX) * (4 * 96 * 96);
 }
 // dW[(q, c)][k] (transposed = 0, [384][96]) or dW[k][(q, c)] (transposed = 1, [96][384]) is WRITTEN.  0 = done, 1 = shape not covered.
+static int gather_wgrad_launch(int dtype, const void* fine, const void* patches, const void* w0c, const void* coarse, const float* fsc, const float* fsh,
+                               const float* csc, const float* csh, float* out, int transposed, int F, int gh, int gw, int C0, int Kc, float* ws,
+                               int64_t ws_floats, bf_stream_t stream);
 extern "C" int bf_gather_wgrad(int dtype, const void* fine, const void* coarse, const float* fsc, const float* fsh, const float* csc, const float* csh,
                                float* out, int transposed, int F, int gh, int gw, int C0, int Kc, float* ws, int64_t ws_floats, bf_stream_t stream) {
+    BF_REQUIRE(fine, "bf_gather_wgrad: null pointer");
+    return gather_wgrad_launch(dtype, fine, nullptr, nullptr, coarse, fsc, fsh, csc, csh, out, transposed, F, gh, gw, C0, Kc, ws, ws_floats, stream);
+}
+// the fine side given as its factors (fine[pixel][c] = sum_k patches[pixel][k] * w0c[c][k], Kp = 16) and transformed by GELU(x * fsc + fsh)
+extern "C" int bf_gather_wgrad_rebuilt(int dtype, const void* patches, const void* w0c, const void* coarse, const float* fsc, const float* fsh, float* out,
+                                       int transposed, int F, int gh, int gw, int C0, int Kc, float* ws, int64_t ws_floats, bf_stream_t stream) {
+    BF_REQUIRE(patches && w0c && fsc && fsh, "bf_gather_wgrad_rebuilt: null pointer");
+    return gather_wgrad_launch(dtype, nullptr, patches, w0c, coarse, fsc, fsh, nullptr, nullptr, out, transposed, F, gh, gw, C0, Kc, ws, ws_floats, stream);
+}
+static int gather_wgrad_launch(int dtype, const void* fine, const void* patches, const void* w0c, const void* coarse, const float* fsc, const float* fsh,
+                               const float* csc, const float* csh, float* out, int transposed, int F, int gh, int gw, int C0, int Kc, float* ws,
+                               int64_t ws_floats, bf_stream_t stream) {
     if (dtype != BF_DTYPE_BF16 || C0 != 96 || Kc != 96) return 1;
     if (F <= 0 || gh <= 0 || gw <= 0 || ((long)gh * gw) % 32) return 1;
     if ((fsc && csc) || (!fsc != !fsh) || (!csc != !csh)) return 1;
     static const bool off = bf_knob("BF_GATHER_WGRAD", 1) == 0;
     if (off) return 1;
-    BF_REQUIRE(fine && coarse && out && ws, "bf_gather_wgrad: null pointer");
-    BF_REQUIRE((((uintptr_t)fine | (uintptr_t)coarse) & 15) == 0, "bf_gather_wgrad: operands must be 16-byte aligned");
+    BF_REQUIRE((fine || (patches && w0c)) && coarse && out && ws, "bf_gather_wgrad: null pointer");
+    BF_REQUIRE((((uintptr_t)fine | (uintptr_t)patches | (uintptr_t)w0c | (uintptr_t)coarse) & 15) == 0, "bf_gather_wgrad: operands must be 16-byte aligned");
     const int tpf = (int)((long)gh * gw / 32);
     const int rpf = wgrad_runs(F, tpf, ws_floats);
     if (rpf < 1) return 1;
     const long nwg = (long)F * rpf;
     hipStream_t st = (hipStream_t)stream;
-    WgradArgs a{(const bf16*)fine, (const bf16*)coarse, fsc, fsh, csc, csh, ws, F, gh, gw, rpf, tpf / rpf};
+    WgradArgs a{(const bf16*)patches, (const bf16*)w0c, (const bf16*)fine, (const bf16*)coarse, fsc, fsh, csc, csh, ws, F, gh, gw, rpf, tpf / rpf};
     {
         const double rows = (double)F * gh * gw;
-        BfProfScope prof(st, fsc ? "gather_wgrad<fine gelu>" : csc ? "gather_wgrad<coarse gelu>" : "gather_wgrad<plain>", 2.0 * rows * 384 * 96, rows * (384 + 96) * 2.0);
-        if (fsc) hipLaunchKernelGGL((gather_wgrad_kernel<true, false>), dim3((unsigned)nwg), dim3(64 * WW), 0, st, a);
+        BfProfScope prof(st, !fine ? "gather_wgrad<fine gelu,rebuilt>" : fsc ? "gather_wgrad<fine gelu>" : csc ? "gather_wgrad<coarse gelu>" : "gather_wgrad<plain>",
+                         2.0 * rows * 384 * 96, rows * ((fine ? 384 : 64) + 96) * 2.0);
+        if (!fine) hipLaunchKernelGGL((gather_wgrad_kernel<true, false, true>), dim3((unsigned)nwg), dim3(64 * WW), 0, st, a);
+        else if (fsc) hipLaunchKernelGGL((gather_wgrad_kernel<true, false>), dim3((unsigned)nwg), dim3(64 * WW), 0, st, a);
         else if (csc) hipLaunchKernelGGL((gather_wgrad_kernel<false, true>), dim3((unsigned)nwg), dim3(64 * WW), 0, st, a);
         else hipLaunchKernelGGL((gather_wgrad_kernel<false, false>), dim3((unsigned)nwg), dim3(64 * WW), 0, st, a);
         BF_CHECK_LAUNCH();

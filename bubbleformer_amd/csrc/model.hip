@@ -1144,6 +1144,19 @@ struct DebedSaved {
 extern "C" int64_t bf_embed_saved_bytes(const bf_dims* s) { D d; if (get_dims(s, &d) || d.nst < 1) return -1; return (int64_t)EmbedSaved(d, nullptr).bytes; }
 extern "C" int64_t bf_debed_saved_bytes(const bf_dims* s) { D d; if (get_dims(s, &d) || d.nst < 1) return -1; return (int64_t)DebedSaved(d, nullptr).bytes; }
 
+// saved records whose stage-0 map was NOT stored by the forward (host-side memory of a per-call decision; the record itself is device memory)
+namespace {
+std::vector<const void*> g_embed_lean;
+void embed_lean_set(const void* saved, bool lean) {
+    for (size_t i = 0; i < g_embed_lean.size(); ++i)
+        if (g_embed_lean[i] == saved) { if (!lean) { g_embed_lean[i] = g_embed_lean.back(); g_embed_lean.pop_back(); } return; }
+    if (lean) g_embed_lean.push_back(saved);
+}
+bool embed_lean_get(const void* saved) {
+    for (const void* p : g_embed_lean) if (p == saved) return true;
+    return false;
+}
+}  // namespace
 extern "C" int bf_embed_fwd(const bf_dims* dims, const bf_embed_params* p, const float* x, const float* fluid, void* out, void* saved,
                             void* scratch, bf_stream_t s) {
     D d; TRY(get_dims(dims, &d));
@@ -1175,9 +1188,16 @@ extern "C" int bf_embed_fwd(const bf_dims* dims, const bf_embed_params* p, const
             const int S0 = sv.gh[0] * sv.gw[0];
             static const bool part_on = bf_knob("BF_EMBED_STATS", 1) != 0;
             const bool part_ok = part_on && n > 1 && bf_in_ws_floats(d.dtype, (int)d.F, S0, sv.C[0]) >= (int64_t)2 * d.F * sv.C[0] * (1 + (S0 + 255) / 256);      // the sliced workspace holds 256-row slices
-            const int rc = bf_embed_first(d.dtype, x, wc, sv.patches, sv.y[0], (int)d.F, sv.C[0], d.cin, H / 2, W / 2, sv.Kp,
+            // lean: the stage-0 map is W0 . patch -- when every consumer of this call's saved record can rebuild its rows (the streaming
+            // stage-1 kernels, the one-pass backward tail) it is not stored at all; g_embed_lean remembers the decision for the backward
+            static const bool lean_on = bf_knob("BF_EMBED_LEAN", 1) != 0;
+            const bool lean = lean_on && part_ok && d.dtype == BF_DTYPE_BF16 && sv.Kp == 16 && d.cin <= 4 && sv.C[0] == 96 && sv.C[1] == 96 && (W / 2) % 16 == 0 &&
+                              sv.gw[1] % 16 == 0 && ((long)sv.gh[1] * sv.gw[1]) % 128 == 0 && S0 >= 1024;
+            const int rc = bf_embed_first(d.dtype, x, wc, sv.patches, lean ? nullptr : sv.y[0], (int)d.F, sv.C[0], d.cin, H / 2, W / 2, sv.Kp,
                                           part_ok ? sc.in_ws + (size_t)2 * d.F * sv.C[0] : nullptr, st);
             if (rc < 0) return rc;
+            if (rc == 1 && lean) return bf_fail_msg("bf_embed_fwd: the first-stage kernel declined a shape the lean path was chosen for", __FILE__, __LINE__);
+            embed_lean_set(saved, lean);
             stats_done = rc == 0 && part_ok;
             if (rc == 1) {
                 TRY(bf_im2col_nchw(d.dtype, x, sv.patches, (int)d.F, d.cin, H, W, sv.Kp, st));
@@ -1189,8 +1209,11 @@ extern "C" int bf_embed_fwd(const bf_dims* dims, const bf_embed_params* p, const
         } else {
             const int cp = sv.C[i - 1];
             // the 96 -> 96 channel stages stream their map once through a weight-stationary kernel (gather_gemm.hip)
-            const int grc = bf_gather_gemm(d.dtype, sv.y[i - 1], sv.wc[i], 0, sv.sc[i - 1], sv.sh[i - 1], sv.y[i], (int)d.F, sv.gh[i], sv.gw[i], cp, sv.C[i], st);
+            const bool reb = i == 1 && embed_lean_get(saved);
+            const int grc = reb ? bf_gather_gemm_rebuilt(d.dtype, sv.patches, sv.wc[0], sv.wc[i], 0, sv.sc[0], sv.sh[0], sv.y[i], (int)d.F, sv.gh[i], sv.gw[i], cp, sv.C[i], st)
+                                : bf_gather_gemm(d.dtype, sv.y[i - 1], sv.wc[i], 0, sv.sc[i - 1], sv.sh[i - 1], sv.y[i], (int)d.F, sv.gh[i], sv.gw[i], cp, sv.C[i], st);
             if (grc < 0) return grc;
+            if (grc == 1 && reb) return bf_fail_msg("bf_embed_fwd: the rebuilt-rows stage kernel declined a shape the lean path was chosen for", __FILE__, __LINE__);
             if (grc == 1) {
                 bf_operand A = op_plain(sv.y[i - 1], cp, BF_LAY_KC);
                 op_gather(A, sv.gw[i], sv.gh[i], cp);
@@ -1207,6 +1230,7 @@ extern "C" int bf_embed_fwd(const bf_dims* dims, const bf_embed_params* p, const
                                                      sv.mean[0], sv.rstd[0], sv.sc[0], sv.sh[0], sc.in_ws, st);
             if (mrc < 0) return mrc;
             if (mrc == 0) continue;
+            if (embed_lean_get(saved)) return bf_fail_msg("bf_embed_fwd: slice statistics declined on the lean path", __FILE__, __LINE__);
         }
         if (last) {       // the tokens (InstanceNorm affine, FiLM folded in) leave the statistics kernel itself where a frame fits its registers
             TRY(bf_in_stats_apply(d.dtype, sv.y[i], (int)d.F, sv.gh[i] * sv.gw[i], sv.C[i], p->in_w[i], p->in_b[i], film ? sv.gb : nullptr, d.T,
@@ -1251,9 +1275,23 @@ extern "C" int bf_embed_bwd(const bf_dims* dims, const bf_embed_params* p, const
         TRY(fk.begin(&ss));
         // dWprep[co][k] = sum_p dy[p][co] * act(patch)[p][k]: the 96-channel stages as one stream over the map with slabs summed in a fixed
         // order (gather_gemm.hip; its slabs live in t1b, which nothing else of this call touches), else split-K with fp32 atomics
-        const int wrc = bf_gather_wgrad(d.dtype, sv.y[i - 1], dy, sv.sc[i - 1], sv.sh[i - 1], nullptr, nullptr, sc.wg, 1, (int)d.F, sv.gh[i], sv.gw[i], cp,
-                                        sv.C[i], (float*)sc.t1b, sc.t1b_floats, ss);
+        const bool lean = embed_lean_get(saved);
+        if (i == 1 && lean && dx_in) {      // the input wants a gradient after all: the generic chain below reads the map, so store it now (y0 = patches @ W0^T)
+            bf_operand A0 = op_plain(sv.patches, sv.Kp, BF_LAY_KC);
+            bf_operand B0 = op_plain(sv.wc[0], sv.Kp, BF_LAY_KC);
+            bf_epilogue e0 = epi_store(sv.y[0], sv.C[0]);
+            TRY(bf_gemm(d.dtype, (int)sv.P[0], sv.C[0], sv.Kp, &A0, &B0, &e0, 1, st));
+            embed_lean_set(saved, false);
+            TRY(fk.join());                 // the side stream forked before the map existed
+            TRY(fk.begin(&ss));
+        }
+        const bool reb = i == 1 && embed_lean_get(saved);
+        const int wrc = reb ? bf_gather_wgrad_rebuilt(d.dtype, sv.patches, sv.wc[0], dy, sv.sc[0], sv.sh[0], sc.wg, 1, (int)d.F, sv.gh[i], sv.gw[i], cp, sv.C[i],
+                                                      (float*)sc.t1b, sc.t1b_floats, ss)
+                            : bf_gather_wgrad(d.dtype, sv.y[i - 1], dy, sv.sc[i - 1], sv.sh[i - 1], nullptr, nullptr, sc.wg, 1, (int)d.F, sv.gh[i], sv.gw[i], cp,
+                                              sv.C[i], (float*)sc.t1b, sc.t1b_floats, ss);
         if (wrc < 0) return wrc;
+        if (wrc == 1 && reb) return bf_fail_msg("bf_embed_bwd: the rebuilt-rows weight gradient declined a shape the lean path was chosen for", __FILE__, __LINE__);
         if (wrc == 1) {
             ZERO_ON(ss, sc.wg, (size_t)sv.C[i] * K4 * 4);
             bf_operand A = op_plain(dy, sv.C[i], BF_LAY_XC);
@@ -1273,7 +1311,7 @@ extern "C" int bf_embed_bwd(const bf_dims* dims, const bf_embed_params* p, const
             if (tail_on && need > 0 && need + (int64_t)cp * sv.Kp <= sc.tokred_floats) {
                 float* dwprep = sc.tokred_ws + need;
                 static const bool tail_map = bf_knob("BF_EMBED_TAIL_MAP", 0) != 0;      // 1: read the stored stage-0 map instead of rebuilding its rows
-                const int trc = bf_embed_tail_bwd(d.dtype, dy, sv.wc[1], tail_map ? sv.y[0] : nullptr, sv.patches, sv.wc[0], sv.sc[0], sv.sh[0], sv.mean[0], sv.rstd[0],
+                const int trc = bf_embed_tail_bwd(d.dtype, dy, sv.wc[1], (tail_map && !embed_lean_get(saved)) ? sv.y[0] : nullptr, sv.patches, sv.wc[0], sv.sc[0], sv.sh[0], sv.mean[0], sv.rstd[0],
                                                   p->in_w[0], dwprep, g->in_w[0], g->in_b[0], (int)d.F, sv.gh[1], sv.gw[1], sv.C[1], cp, sv.Kp,
                                                   sc.tokred_ws, need, s);
                 if (trc < 0) return trc;
@@ -1282,6 +1320,7 @@ extern "C" int bf_embed_bwd(const bf_dims* dims, const bf_embed_params* p, const
                     return fk.join();
                 }
             }
+            if (embed_lean_get(saved)) return bf_fail_msg("bf_embed_bwd: the one-pass tail declined on the lean path (no stored stage-0 map)", __FILE__, __LINE__);
         }
         void* dact = buf(i - 1);
         {   // d(act patch)[p][k] = sum_co dy[p][co] * Wprep[co][k], scattered back to the input grid

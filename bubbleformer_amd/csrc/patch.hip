@@ -261,14 +261,16 @@ __global__ void __launch_bounds__(NT) debed_last_bwd_kernel(const float* __restr
 #pragma unroll
             for (int k = 0; k < 4 * T; ++k) { const float v2 = (float)o[k]; s1[k] += v2; s2[k] += v2 * v2; }      // of the values as stored
         }
-        bf16* dst = dact + p * Ci + (perm ? 8 * lg : 4 * T * lg);
-        const int qs = perm ? 32 : 8;
+        if (dact) {                                     // (bf_embed_first without a map: only the patch rows and the statistics leave)
+            bf16* dst = dact + p * Ci + (perm ? 8 * lg : 4 * T * lg);
+            const int qs = perm ? 32 : 8;
 #pragma unroll
-        for (int q = 0; q < 4 * T / 8; ++q) {
-            bf16x8 o8;
+            for (int q = 0; q < 4 * T / 8; ++q) {
+                bf16x8 o8;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o8[j] = o[8 * q + j];
-            *reinterpret_cast<bf16x8*>(dst + qs * q) = o8;
+                for (int j = 0; j < 8; ++j) o8[j] = o[8 * q + j];
+                *reinterpret_cast<bf16x8*>(dst + qs * q) = o8;
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
@@ -673,7 +675,7 @@ extern "C" int bf_debed_last(int dtype, const void* act, const float* sc, const 
 static int debed_last_bwd_launch(int dtype, const float* dpred, const float* pred, const float* y, const float* coef, const float* gscale,
                                  const void* wc, void* dpm, void* dact, int frames, int Ci, int Co, int h, int w, int Np, float* part,
                                  bf_stream_t stream) {
-    BF_REQUIRE(wc && dpm && dact && (dpred || (pred && y && coef)) && frames > 0 && Ci > 0 && Co > 0 && h > 0 && w > 0, "bf_debed_last_bwd: bad arguments");
+    BF_REQUIRE(wc && dpm && (dact || part) && (dpred || (pred && y && coef)) && frames > 0 && Ci > 0 && Co > 0 && h > 0 && w > 0, "bf_debed_last_bwd: bad arguments");
     if (dtype != BF_DTYPE_BF16 || Np != 16 || Co > 4 || Ci % 32 != 0 || Ci > 128 || w % 16 != 0) return 1;      // caller keeps bf_nchw2pm + GEMM
     static const bool off = bf_knob("BF_DEBED_LAST_BWD", 1) == 0;
     if (off) return 1;
@@ -746,7 +748,7 @@ extern "C" int bf_debed_last_bwd_norm(int dtype, const float* dpred, const float
 // partials bf_in_stats_merge_slices turns into the stage's InstanceNorm statistics, so that y0 is not read again for them.
 extern "C" int bf_embed_first(int dtype, const float* x, const void* wc, void* patches, void* y0, int frames, int C0, int cin, int h2, int w2,
                               int Kp, float* stat_part, bf_stream_t stream) {
-    BF_REQUIRE(x && wc && patches && y0, "bf_embed_first: null pointer");
+    BF_REQUIRE(x && wc && patches && (y0 || stat_part), "bf_embed_first: null pointer");      // y0 may be null when its statistics are all that is wanted of it
     static const bool off = bf_knob("BF_EMBED_FIRST", 1) == 0;
     if (off) return 1;
     return debed_last_bwd_launch(dtype, x, nullptr, nullptr, nullptr, nullptr, wc, patches, y0, frames, C0, cin, h2, w2, Kp, stat_part, stream);

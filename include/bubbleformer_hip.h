@@ -223,6 +223,9 @@ int bf_debed_last_bwd_norm(int dtype, const float* dpred, const float* pred, con
  * Same kernel and declined shapes as bf_debed_last_bwd (returns 1). */
 int bf_embed_first(int dtype, const float* x, const void* wc, void* patches, void* y0, int frames, int C0, int cin, int h2, int w2,
                    int Kp, float* stat_part, bf_stream_t stream);
+/* y0 may be NULL when stat_part is given: the map is then not stored at all -- its consumers rebuild its rows from `patches` and `wc`
+ * (bf_gather_gemm_rebuilt, bf_gather_wgrad_rebuilt, bf_embed_tail_bwd with y0 = NULL), which is 226 MB less to write and three reads of it
+ * less per training step at the bench shape. */
 /* stat_part (optional): {mean, centred second moment} of y0 per 256-row slice, [frames][ceil(h2*w2/256)][C0][2]; finished by
  * bf_in_stats_merge_slices(..., rows = 256, ws) with ws + 2*frames*C0 == stat_part (the layout bf_in_stats uses for long frames). */
 int bf_in_stats_merge_slices(int dtype, int frames, int S, int C, int rows, const float* w, const float* b, const float* g, int gdiv,
@@ -256,6 +259,12 @@ int bf_scatter_gemm(int dtype, const void* a, const void* w, int w_kn, const flo
 int64_t bf_gather_wgrad_ws_floats(int frames, int gh, int gw);
 int bf_gather_wgrad(int dtype, const void* fine, const void* coarse, const float* fsc, const float* fsh, const float* csc, const float* csh,
                     float* out, int transposed, int frames, int gh, int gw, int C0, int Kc, float* ws, int64_t ws_floats, bf_stream_t stream);
+/* bf_gather_gemm / bf_gather_wgrad with the fine map given as its factors, map[pixel][c] = sum_k patches[pixel][k] * w0c[c][k] (Kp = 16: the
+ * output of bf_embed_first), rebuilt per tile and rounded to bf16 like a stored map; the fine side is transformed by GELU(x * sc + sh). */
+int bf_gather_gemm_rebuilt(int dtype, const void* patches, const void* w0c, const void* w, int w_kn, const float* sc, const float* sh, void* out,
+                           int frames, int gh, int gw, int C0, int N, bf_stream_t stream);
+int bf_gather_wgrad_rebuilt(int dtype, const void* patches, const void* w0c, const void* coarse, const float* fsc, const float* fsh, float* out,
+                            int transposed, int frames, int gh, int gw, int C0, int Kc, float* ws, int64_t ws_floats, bf_stream_t stream);
 int64_t bf_embed_tail_ws_floats(int frames, int gh1, int gw1, int C0, int Kp);
 int bf_embed_tail_bwd(int dtype, const void* dy1, const void* w1c, const void* y0, const void* patches, const void* w0c, const float* sc,
                       const float* sh, const float* mean, const float* rstd, const float* in_w, float* dwprep, float* d_in_w, float* d_in_b,

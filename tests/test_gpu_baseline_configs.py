@@ -312,11 +312,12 @@ def test_config1_training_step_takes_the_streaming_embed_debed_kernels():
     h.bf_prof_report(buf, len(buf))
     h.bf_prof_enable(0)
     names = json.loads(buf.value.decode())
-    for k in ("embed_tail_bwd", "debed_last_bwd<stats>", "debed_last_bwd<apply>", "gather_gemm<gelu>", "gather_gemm<plain>", "scatter_gemm<gelu>",
-              "scatter_gemm<plain>", "gather_wgrad<fine gelu>", "gather_wgrad<coarse gelu>"):
+    for k in ("embed_tail_bwd", "debed_last_bwd<stats>", "debed_last_bwd<apply>", "gather_gemm<gelu>", "gather_gemm<gelu,rebuilt>", "gather_gemm<plain>",
+              "scatter_gemm<gelu>", "scatter_gemm<plain>", "gather_wgrad<fine gelu>", "gather_wgrad<fine gelu,rebuilt>", "gather_wgrad<coarse gelu>"):
         assert k in names, (k, sorted(names))
-    assert names["gather_gemm<gelu>"]["calls"] == 2 and names["scatter_gemm<gelu>"]["calls"] == 2
-    assert names["gather_wgrad<fine gelu>"]["calls"] == 2 and names["gather_wgrad<coarse gelu>"]["calls"] == 2
+    # the first embed stage's 226 MB map is not stored: the stage behind it and its weight gradient rebuild its rows from the patch rows
+    assert names["gather_gemm<gelu,rebuilt>"]["calls"] == 1 and names["gather_gemm<gelu>"]["calls"] == 1 and names["scatter_gemm<gelu>"]["calls"] == 2
+    assert names["gather_wgrad<fine gelu,rebuilt>"]["calls"] == 1 and names["gather_wgrad<fine gelu>"]["calls"] == 1 and names["gather_wgrad<coarse gelu>"]["calls"] == 2
 
 
 def test_inference_operators_are_registered_with_the_dispatcher():

@@ -949,6 +949,37 @@ def test_gather_wgrad_2x2_stage(Fr, gh, gw, variant):
     assert lib.bf_gather_wgrad(1, _p(fine), _p(coarse), _p(sc), _p(sh), _p(sc), _p(sh), _p(out), tr, Fr, gh, gw, C0, C0, _p(ws), nws, _stream()) == 1
 
 
+@pytest.mark.parametrize("Fr,gh,gw", [(3, 2, 16), (2, 12, 32), (5, 48, 48), (3, 24, 24)])
+def test_stage_kernels_with_the_map_given_as_its_factors(Fr, gh, gw):
+    """bf_gather_gemm_rebuilt / bf_gather_wgrad_rebuilt: the fine map is W0 . patch (the first HMLPEmbed stage) and is rebuilt per tile from
+    the 16-wide patch rows instead of read -- against the same kernels on the stored map bf16(patches @ W0^T): the rows are rounded the
+    same way, so only the order of the fp32 accumulation differs."""
+    from bubbleformer_amd import _lib as L
+    from bubbleformer_amd.ops import _p, _stream
+    lib = L.lib()
+    C0, N = 96, 96
+    g = torch.Generator(device="cuda").manual_seed(59)
+    P = Fr * gh * gw
+    patches = (torch.randn(4 * P, 16, device="cuda", generator=g) + 0.2).bfloat16()
+    W0 = (torch.randn(C0, 16, device="cuda", generator=g) / 3).bfloat16()
+    fine = (patches.float() @ W0.float().t()).bfloat16().view(Fr, 2 * gh, 2 * gw, C0)
+    W = (torch.randn(N, 4 * C0, device="cuda", generator=g) / 16).bfloat16()              # [n][k]
+    sc, sh = 0.5 + torch.rand(Fr, C0, device="cuda", generator=g), 0.3 * torch.randn(Fr, C0, device="cuda", generator=g)
+    a = torch.full((P, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    b = torch.full((P, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    L.check(lib.bf_gather_gemm(1, _p(fine), _p(W), 0, _p(sc), _p(sh), _p(a), Fr, gh, gw, C0, N, _stream()), "gather_gemm")
+    L.check(lib.bf_gather_gemm_rebuilt(1, _p(patches), _p(W0), _p(W), 0, _p(sc), _p(sh), _p(b), Fr, gh, gw, C0, N, _stream()), "gather_gemm_rebuilt")
+    assert torch.isfinite(b.float()).all() and _rel(b, a) < 2e-3          # bf16 outputs of two fp32 summation orders
+    coarse = torch.randn(P, C0, device="cuda", generator=g).bfloat16()
+    nws = lib.bf_gather_wgrad_ws_floats(Fr, gh, gw)
+    ws = torch.full((nws,), float("nan"), device="cuda")
+    o1 = torch.full((C0, 4 * C0), float("nan"), device="cuda")
+    o2 = torch.full((C0, 4 * C0), float("nan"), device="cuda")
+    L.check(lib.bf_gather_wgrad(1, _p(fine), _p(coarse), _p(sc), _p(sh), None, None, _p(o1), 1, Fr, gh, gw, C0, C0, _p(ws), nws, _stream()), "gather_wgrad")
+    L.check(lib.bf_gather_wgrad_rebuilt(1, _p(patches), _p(W0), _p(coarse), _p(sc), _p(sh), _p(o2), 1, Fr, gh, gw, C0, C0, _p(ws), nws, _stream()), "gather_wgrad_rebuilt")
+    assert torch.isfinite(o2).all() and _rel(o2, o1) < 1e-5
+
+
 @pytest.mark.parametrize("Fr,gh1,gw1,C1", [(3, 8, 16, 96), (2, 12, 32, 192), (5, 48, 48, 96)])
 def test_embed_backward_tail_one_pass(Fr, gh1, gw1, C1):
     """bf_embed_tail_bwd (embed_tail.hip): the stage-1 data gradient, GELU', the stage-0 InstanceNorm backward and the stage-0 weight

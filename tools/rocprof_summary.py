@@ -73,9 +73,9 @@ def normalise(name: str) -> str:
     m = re.search(r"scatter_gemm_kernel<\d, \d, (true|false)>", name)
     if m:
         return "scatter_gemm<%s>" % ("gelu" if m.group(1) == "true" else "plain")
-    m = re.search(r"gather_wgrad_kernel<(true|false), (true|false)>", name)
+    m = re.search(r"gather_wgrad_kernel<(true|false), (true|false), (true|false)>", name)
     if m:
-        return "gather_wgrad<%s>" % ("fine gelu" if m.group(1) == "true" else "coarse gelu" if m.group(2) == "true" else "plain")
+        return "gather_wgrad<%s>" % ("fine gelu,rebuilt" if m.group(3) == "true" else "fine gelu" if m.group(1) == "true" else "coarse gelu" if m.group(2) == "true" else "plain")
     m = re.search(r"debed_last_inbwd_kernel<\d, (\d)>", name)
     if m:
         return "debed_last_bwd<%s>" % ("stats" if m.group(1) == "1" else "apply")
