@@ -67,9 +67,9 @@ def normalise(name: str) -> str:
     if "tokred_reduce_kernel" in name:
         return "tokred_reduce_kernel"
     # round-3 embed / debed kernels (gather_gemm.hip, embed_tail.hip, patch.hip)
-    m = re.search(r"gather_gemm_kernel<\d, \d, (true|false)>", name)
+    m = re.search(r"gather_gemm_kernel<\d, \d, (true|false), (true|false)>", name)
     if m:
-        return "gather_gemm<%s>" % ("gelu" if m.group(1) == "true" else "plain")
+        return "gather_gemm<%s>" % ("gelu,rebuilt" if m.group(2) == "true" else "gelu" if m.group(1) == "true" else "plain")
     m = re.search(r"scatter_gemm_kernel<\d, \d, (true|false)>", name)
     if m:
         return "scatter_gemm<%s>" % ("gelu" if m.group(1) == "true" else "plain")
@@ -82,6 +82,8 @@ def normalise(name: str) -> str:
     m = re.search(r"tokred_narrow_kernel<\d, (true|false)>", name)
     if m:
         return "tokred_narrow<%s>" % ("gelu" if m.group(1) == "true" else "plain")
+    if "debed_last_bwd_kernel" in name:
+        return "patch16_kernel (embed_first / debed_last_bwd)"      # one kernel: the K = 16 contraction at either end of the model
     for key in ("gather_wgrad_reduce_kernel", "embed_tail_bwd_kernel", "embed_tail_frame_kernel", "embed_tail_sum_kernel", "tokred_narrow_reduce_kernel", "dl_slice_sum_kernel",
                 "dl_param_reduce_kernel"):
         if key in name:
