@@ -109,6 +109,7 @@ SIGNATURES = {
     "bf_gather_wgrad": (C.c_int, [C.c_int, vp, vp, fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, C.c_int64, vp]),
     "bf_gather_gemm_rebuilt": (C.c_int, [C.c_int, vp, vp, vp, C.c_int, fp, fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "bf_gather_wgrad_rebuilt": (C.c_int, [C.c_int, vp, vp, vp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, C.c_int64, vp]),
+    "bf_stage_chain_head": (C.c_int, [vp, vp, vp]),
     "bf_embed_tail_ws_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "bf_embed_tail_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, fp, fp, fp, fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     fp, C.c_int64, vp]),

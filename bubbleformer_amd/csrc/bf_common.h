@@ -48,6 +48,9 @@ int bf_attn_bwd_partials(int dtype, const void* qkv, const void* dout, void* dqk
 // InstanceNorm statistics of x fused with out = resid + x * sc + sh (norm.hip; internal)
 int bf_in_stats_apply(int dtype, const void* x, int frames, int S, int C, const float* w, const float* b, const float* g, int gdiv, const float* gb,
                       float* mean, float* rstd, float* sc, float* sh, float* ws, const void* resid, void* out, hipStream_t stream);
+int bf_in_stats_apply_chain(int dtype, const void* x, int frames, int S, int C, const float* w, const float* b, const float* g, int gdiv, const float* gb,
+                            float* mean, float* rstd, float* sc, float* sh, float* ws, const void* resid, void* out, const float* nw, const float* nb,
+                            float* nmean, float* nrstd, float* nsc, float* nsh, void* nxn, bool* chained, hipStream_t stream);
 // out = z * m[(row / S) / fdiv] (norm.hip; internal)
 int bf_wprep_multi(int dtype, int n, const int* mode, const float* const* src, void* const* dst, const int* R, const int* K, const int* Kp, hipStream_t st);
 int bf_frame_scale(int dtype, const void* z, const float* m, int fdiv, void* out, long nrows, int S, int C, hipStream_t st);

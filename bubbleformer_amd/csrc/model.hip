@@ -652,6 +652,25 @@ extern "C" void bf_side_defer(int on) { g_side_defer = on != 0; }
 extern "C" int bf_side_join(bf_stream_t s) { return side_join_pending((hipStream_t)s); }
 
 // ================================================================================================= temporal block
+// Chained stage heads: a stage that ends in `out = resid + InstanceNorm(z)` (the spatial stage's MLP branch) can leave the next stage's
+// opening InstanceNorm(out) behind in the same launch (norm.hip, InChain).  bf_stage_chain_head arms it with the next temporal stage's
+// parameters and saved record; the stage that consumed it remembers the record, and that stage's forward skips its own norm1.
+namespace {
+struct NextHead { bool armed = false; const float *w = nullptr, *b = nullptr; float *mean = nullptr, *rstd = nullptr, *sc = nullptr, *sh = nullptr; void* xn = nullptr; const void* saved = nullptr; } g_next_head;
+const void* g_head_done_for = nullptr;
+}  // namespace
+extern "C" int bf_stage_chain_head(const bf_dims* dims, const bf_temporal_params* next_p, void* next_saved) {
+    g_next_head.armed = false;
+    if (!dims || !next_p || !next_saved) return 0;          // disarm
+    D d; TRY(get_dims(dims, &d));
+    TemporalSaved sv(d, next_saved);
+    g_next_head.w = next_p->norm1_w; g_next_head.b = next_p->norm1_b;
+    g_next_head.mean = sv.mean1; g_next_head.rstd = sv.rstd1; g_next_head.sc = sv.sc1; g_next_head.sh = sv.sh1; g_next_head.xn = sv.xn;
+    g_next_head.saved = next_saved;
+    g_next_head.armed = true;
+    return 0;
+}
+
 extern "C" int bf_temporal_fwd(const bf_dims* dims, const bf_temporal_params* p, const void* x, void* out, void* saved, void* scratch,
                                const float* drop, bf_stream_t s) {
     D d; TRY(get_dims(dims, &d));
@@ -674,8 +693,10 @@ extern "C" int bf_temporal_fwd(const bf_dims* dims, const bf_temporal_params* p,
         else TRY(wviews(d, 2, src, dst, n, out, st, &prep));
         win_c = out[0]; wout_c = out[1];
     }
-    TRY(bf_in_stats_apply(d.dtype, x, (int)d.F, (int)d.S, d.E, p->norm1_w, p->norm1_b, nullptr, 1, nullptr, sv.mean1, sv.rstd1, sv.sc1, sv.sh1, sc.in_ws,
-                          nullptr, sv.xn, st));
+    if (g_head_done_for == saved) g_head_done_for = nullptr;      // the stage in front left norm1's statistics and xn behind (bf_stage_chain_head)
+    else
+        TRY(bf_in_stats_apply(d.dtype, x, (int)d.F, (int)d.S, d.E, p->norm1_w, p->norm1_b, nullptr, 1, nullptr, sv.mean1, sv.rstd1, sv.sc1, sv.sh1, sc.in_ws,
+                              nullptr, sv.xn, st));
     TRY(qkv_gemm(d, sv.xn, win_c, p->input_head_b, sv.qkv, st));
     // sequences along T for every (b, y, x): token = b*T*S + pos + t*S
     TRY(bf_attn_fwd(d.dtype, sv.qkv, sv.o, (long)d.B * d.S, d.T, d.S, (long)d.T * d.S, 1, d.S, d.heads, d.d, p->qnorm_w, p->qnorm_b,
@@ -783,6 +804,7 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
                               const float* drop_att, const float* drop_mlp, bf_stream_t s) {
     D d; TRY(get_dims(dims, &d));
     BF_REQUIRE(p && x && out && saved && scratch, "bf_spatial_fwd: null pointer");
+    g_head_done_for = nullptr;         // (a chained head is consumed by the temporal stage called right after the spatial stage that made it)
     hipStream_t st = (hipStream_t)s;
     TRY(side_join_pending(st));
     SpatialSaved sv(d, saved);
@@ -846,6 +868,15 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
             BF_CHECK_LAUNCH();
         }
         g3 = sv.gtab; g3div = 1;
+    }
+    if (g_next_head.armed) {
+        const NextHead h = g_next_head;
+        g_next_head.armed = false;
+        bool chained = false;
+        TRY(bf_in_stats_apply_chain(d.dtype, sv.z, (int)d.F, (int)d.S, d.E, p->mlp_norm_w, p->mlp_norm_b, g3, g3div, nullptr, sv.mean3, sv.rstd3, sv.sc3, sv.sh3,
+                                    sc.in_ws, sv.x1, out, h.w, h.b, h.mean, h.rstd, h.sc, h.sh, h.xn, &chained, st));
+        g_head_done_for = chained ? h.saved : nullptr;
+        return 0;
     }
     TRY(bf_in_stats_apply(d.dtype, sv.z, (int)d.F, (int)d.S, d.E, p->mlp_norm_w, p->mlp_norm_b, g3, g3div, nullptr, sv.mean3, sv.rstd3,
                           sv.sc3, sv.sh3, sc.in_ws, sv.x1, out, st));

@@ -85,12 +85,18 @@ __device__ __forceinline__ void reduce_rows(float (&v)[NV][Chunk<T>::N], float* 
 // grid: (frames, ceil(C / 64)).  Two-pass (mean, then centred second moment) -- no E[x^2]-E[x]^2.
 constexpr int MAXR = 6;   // rows a thread may keep in registers (frames of up to RG * MAXR tokens are read from memory once)
 
+// The next InstanceNorm in line, applied to the rows this kernel has just produced (fused apply only): a stage that ends in
+// out = resid + x * sc + sh is followed by a stage that opens with xn = InstanceNorm(out) -- the frame is still in registers, so the second
+// statistics and xn cost one more pair of reductions instead of a launch and a read of `out`.  Same rows per thread, same reduction tree,
+// same formulae as a separate launch on `out`: bit-identical results.
+struct InChain { const float *w, *b; float *mean, *rstd, *sc, *sh; void* xn; };
+
 template <typename T, bool CACHED>
 __global__ void __launch_bounds__(NT) in_stats_kernel(const T* __restrict__ x, int S, int C, const float* __restrict__ w,
                                                      const float* __restrict__ b, const float* __restrict__ g, int gdiv,
                                                      const float* __restrict__ gb, float* __restrict__ mean,
                                                      float* __restrict__ rstd, float* __restrict__ sc, float* __restrict__ sh,
-                                                     const T* __restrict__ resid, T* __restrict__ out) {
+                                                     const T* __restrict__ resid, T* __restrict__ out, InChain ch) {
     constexpr int CH = Chunk<T>::N, LC = Geo<T>::LC, RG = Geo<T>::RG;
     __shared__ float sm[NT * CH];
     const int f = blockIdx.x, c0 = blockIdx.y * CPB;
@@ -171,6 +177,51 @@ __global__ void __launch_bounds__(NT) in_stats_kernel(const T* __restrict__ x, i
 #pragma unroll
                     for (int j = 0; j < CH; ++j) oo.set(j, fmaf(keep[q].get(j), aa[j], ss[j]) + (resid ? rr.get(j) : 0.f));
                     oo.store(out + off);
+                    keep[q] = oo;                   // (chain) the rows as stored
+                }
+            }
+        }
+        if (out && ch.xn) {       // block-uniform: every thread takes part in the reductions
+#pragma unroll
+            for (int j = 0; j < CH; ++j) acc[0][j] = 0.f;
+#pragma unroll
+            for (int q = 0; q < MAXR; ++q) {
+                if (cv && rg + RG * q < S) {
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) acc[0][j] += keep[q].get(j);
+                }
+            }
+            reduce_rows<T, 1>(acc, sm);
+            float mu2[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) { mu2[j] = acc[0][j] / (float)S; acc[0][j] = 0.f; }
+#pragma unroll
+            for (int q = 0; q < MAXR; ++q) {
+                if (cv && rg + RG * q < S) {
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) { const float d = keep[q].get(j) - mu2[j]; acc[0][j] = fmaf(d, d, acc[0][j]); }
+                }
+            }
+            reduce_rows<T, 1>(acc, sm);
+            if (cv) {
+                float a2[CH], s2[CH];
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const float r = rsqrtf(acc[0][j] / (float)S + BF_IN_EPS);
+                    const long o = (long)f * C + c + j;
+                    a2[j] = r * ch.w[c + j];
+                    s2[j] = fmaf(-mu2[j], a2[j], ch.b[c + j]);
+                    if (rg == 0) { ch.mean[o] = mu2[j]; ch.rstd[o] = r; ch.sc[o] = a2[j]; ch.sh[o] = s2[j]; }
+                }
+#pragma unroll
+                for (int q = 0; q < MAXR; ++q) {
+                    const int s = rg + RG * q;
+                    if (s < S) {
+                        Chunk<T> oo;
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) oo.set(j, fmaf(keep[q].get(j), a2[j], s2[j]) + 0.f);
+                        oo.store(reinterpret_cast<T*>(ch.xn) + ((long)f * S + s) * C + c);
+                    }
                 }
             }
         }
@@ -578,7 +629,9 @@ extern "C" int64_t bf_in_ws_floats(int dtype, int frames, int S, int C) {
 // statistics, optionally followed by out = resid + x * sc + sh in the same kernel (short frames); *applied tells the caller
 static int in_stats_impl(int dtype, const void* x, int frames, int S, int C, const float* w, const float* b,
                          const float* g, int gdiv, const float* gb, float* mean, float* rstd, float* sc, float* sh,
-                         float* ws, const void* resid, void* out, bool* applied, bf_stream_t stream) {
+                         float* ws, const void* resid, void* out, bool* applied, bf_stream_t stream, const InChain* chain = nullptr,
+                         bool* chained = nullptr) {
+    if (chained) *chained = false;
     if (applied) *applied = false;
     BF_REQUIRE(x && w && b && mean && rstd && sc && sh, "bf_in_stats: null pointer");
     BF_REQUIRE(frames > 0 && S > 0 && C > 0, "bf_in_stats: empty");
@@ -614,14 +667,16 @@ static int in_stats_impl(int dtype, const void* x, int frames, int S, int C, con
     const void* RS = fuse ? resid : nullptr;
     void* OU = fuse ? out : nullptr;
     if (applied) *applied = fuse;
+    InChain ch{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (chain && fuse && C % CPB == 0) { ch = *chain; if (chained) *chained = true; }      // whole 64-channel blocks only: the chained reductions are block-uniform
     if (dtype == BF_DTYPE_BF16) {
         BF_REQUIRE(chunk_ok<bf16>(C), "bf_in_stats: C must be a multiple of 8 (bf16)");
-        if (S <= Geo<bf16>::RG * MAXR) hipLaunchKernelGGL((in_stats_kernel<bf16, true>), grid, dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh, (const bf16*)RS, (bf16*)OU);
-        else hipLaunchKernelGGL((in_stats_kernel<bf16, false>), grid, dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh, (const bf16*)RS, (bf16*)OU);
+        if (S <= Geo<bf16>::RG * MAXR) hipLaunchKernelGGL((in_stats_kernel<bf16, true>), grid, dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh, (const bf16*)RS, (bf16*)OU, ch);
+        else hipLaunchKernelGGL((in_stats_kernel<bf16, false>), grid, dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh, (const bf16*)RS, (bf16*)OU, ch);
     } else {
         BF_REQUIRE(chunk_ok<float>(C), "bf_in_stats: C must be a multiple of 4 (f32)");
-        if (S <= Geo<float>::RG * MAXR) hipLaunchKernelGGL((in_stats_kernel<float, true>), grid, dim3(NT), 0, (hipStream_t)stream, (const float*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh, (const float*)RS, (float*)OU);
-        else hipLaunchKernelGGL((in_stats_kernel<float, false>), grid, dim3(NT), 0, (hipStream_t)stream, (const float*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh, (const float*)RS, (float*)OU);
+        if (S <= Geo<float>::RG * MAXR) hipLaunchKernelGGL((in_stats_kernel<float, true>), grid, dim3(NT), 0, (hipStream_t)stream, (const float*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh, (const float*)RS, (float*)OU, ch);
+        else hipLaunchKernelGGL((in_stats_kernel<float, false>), grid, dim3(NT), 0, (hipStream_t)stream, (const float*)x, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh, (const float*)RS, (float*)OU, ch);
     }
     BF_CHECK_LAUNCH();
     return 0;
@@ -651,6 +706,18 @@ int bf_in_stats_apply(int dtype, const void* x, int frames, int S, int C, const 
                       float* mean, float* rstd, float* sc, float* sh, float* ws, const void* resid, void* out, hipStream_t stream) {
     bool applied = false;
     if (int rc = in_stats_impl(dtype, x, frames, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh, ws, resid, out, &applied, (bf_stream_t)stream)) return rc;
+    if (applied) return 0;
+    return bf_affine_apply(dtype, x, resid, sc, sh, out, (int64_t)frames * S, S, C, (bf_stream_t)stream);
+}
+
+// ... and, where the fused apply runs, the NEXT InstanceNorm (affine nw / nb) of `out` in the same launch: its statistics and
+// nxn = InstanceNorm(out).  *chained tells the caller whether that happened (else it runs the second norm itself).
+int bf_in_stats_apply_chain(int dtype, const void* x, int frames, int S, int C, const float* w, const float* b, const float* g, int gdiv, const float* gb,
+                            float* mean, float* rstd, float* sc, float* sh, float* ws, const void* resid, void* out, const float* nw, const float* nb,
+                            float* nmean, float* nrstd, float* nsc, float* nsh, void* nxn, bool* chained, hipStream_t stream) {
+    bool applied = false;
+    const InChain ch{nw, nb, nmean, nrstd, nsc, nsh, nxn};
+    if (int rc = in_stats_impl(dtype, x, frames, S, C, w, b, g, gdiv, gb, mean, rstd, sc, sh, ws, resid, out, &applied, (bf_stream_t)stream, &ch, chained)) return rc;
     if (applied) return 0;
     return bf_affine_apply(dtype, x, resid, sc, sh, out, (int64_t)frames * S, S, C, (bf_stream_t)stream);
 }

@@ -27,11 +27,15 @@ class SpaceTimeBlock(nn.Module):
         self.spatial = AxialAttentionBlock(embed_dim=embed_dim, num_heads=num_heads, drop_path=drop_path, attn_scale=attn_scale,
                                            feat_scale=feat_scale)
 
-    def forward_tokens(self, tok: torch.Tensor, drops=None) -> torch.Tensor:
-        """drops: optional (temporal [B], axial attention [B*T], MLP [B*T]) stochastic-depth factors drawn by the caller."""
+    def forward_tokens(self, tok: torch.Tensor, drops=None, chain_to=None) -> torch.Tensor:
+        """drops: optional (temporal [B], axial attention [B*T], MLP [B*T]) stochastic-depth factors drawn by the caller.
+        chain_to: the temporal block that consumes this block's output (its opening InstanceNorm can ride in this block's last launch)."""
+        tok = self.temporal.forward_tokens(tok) if drops is None else self.temporal.forward_tokens(tok, drops[0])
+        if chain_to is not None and tok.is_cuda:
+            ops.chain_next(chain_to.stage_params())
         if drops is None:
-            return self.spatial.forward_tokens(self.temporal.forward_tokens(tok))
-        return self.spatial.forward_tokens(self.temporal.forward_tokens(tok, drops[0]), drops[1], drops[2])
+            return self.spatial.forward_tokens(tok)
+        return self.spatial.forward_tokens(tok, drops[1], drops[2])
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: (B, T, emb, H, W) -> same."""
@@ -95,7 +99,7 @@ class _AxialBase(nn.Module):
             ops.prepare_stages(tok, b0.temporal.num_heads, b0.temporal.attn_scale, b0.spatial.feat_scale, stages)
         try:
             for i, blk in enumerate(self.blocks):
-                tok = blk.forward_tokens(tok, drops[i])
+                tok = blk.forward_tokens(tok, drops[i], self.blocks[i + 1].temporal if i + 1 < len(self.blocks) else None)
         finally:
             ops.discard_prepared()       # records nobody consumed (an exception above) must not meet a later call with newer weights
         return tok

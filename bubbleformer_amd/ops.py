@@ -197,6 +197,16 @@ def as_reference_layout(tok: torch.Tensor) -> torch.Tensor:
 _PREPARED: dict = {}      # (kind, pointer of the stage's first parameter) -> (dims key, saved record with prepared weights)
 
 
+_CHAIN = {"next": None}
+
+
+def chain_next(params) -> None:
+    """Announce the temporal stage that will consume the output of the spatial stage called next (its parameters in
+    ``_lib.TEMPORAL_FIELDS`` order): when both were prepared by `prepare_stages` for the same shape, that stage's opening InstanceNorm
+    is computed by the spatial stage's last launch (bf_stage_chain_head; bit-identical results, one launch and one read less)."""
+    _CHAIN["next"] = _stage_key("temporal", [_f32c(p) for p in params]) if _PREPARED and os.environ.get("BF_STAGE_CHAIN", "1") != "0" else None
+
+
 def _stage_key(kind: str, params) -> tuple:
     return kind, next(p.data_ptr() for p in params if p is not None)
 
@@ -409,6 +419,11 @@ class _BlockFn(torch.autograd.Function):
         if pre is not None and (pre[0] != _dims_key(d) or (pre[2] is None) != (drop_b is None) or
                                 (drop_b is not None and pre[2].data_ptr() != drop_b.data_ptr())):
             pre = None                                  # prepared for another shape or another stochastic-depth table: prepare here
+        nxt, _CHAIN["next"] = _CHAIN["next"], None
+        if kind == "spatial" and nxt is not None:       # the next temporal stage's opening InstanceNorm rides in this stage's last launch
+            pn = _PREPARED.get(nxt)
+            if pn is not None and pn[0] == _dims_key(d):
+                L.check(lib.bf_stage_chain_head(C.byref(d), C.byref(pn[3]), _p(pn[1])), "bf_stage_chain_head")
         if kind == "temporal":
             st = pre[3] if pre else L.TemporalParams(*[_p(p) for p in params])
             saved = pre[1] if pre else _saved(lib.bf_temporal_saved_bytes(C.byref(d)), x.device, "bf_temporal_saved_bytes")

@@ -364,6 +364,12 @@ int bf_trunk_eval_prepare(const bf_dims* dims, int n, const int32_t* kinds, cons
 int bf_trunk_eval_fwd(const bf_dims* dims, int n, const int32_t* kinds, const void* const* params, const void* weights, const void* x,
                       void* out, void* scratch, bf_stream_t stream);
 /* x, out, dout, dx: [N][E] activations.  Gradients ACCUMULATE into `g` (zero it first). */
+/* Chained stage heads (optional, forward only): arm the NEXT temporal stage's opening InstanceNorm (norm1 of next_p, written into next_saved)
+ * to be computed by the tail of the spatial stage called next, whose output it normalises -- one launch and one read of the activation
+ * less per block pair; bf_temporal_fwd on next_saved then skips its own norm1.  Results are bit-identical to the unchained calls.
+ * NULL arguments disarm.  A spatial stage that cannot chain (fp32 frames longer than the register cache, ...) leaves the norm to the
+ * temporal stage as usual. */
+int bf_stage_chain_head(const bf_dims* dims, const bf_temporal_params* next_p, void* next_saved);
 /* Stochastic depth (timm DropPath at layers/attention.py:123,309,317): `drop*` are the per-sample factors (0 or 1/keep) the
  * caller drew -- [B] for the temporal block (dim 0 = batch), [B*T] each for the two branches of the axial block -- or NULL. */
 int bf_temporal_fwd(const bf_dims* d, const bf_temporal_params* p, const void* x, void* out, void* saved, void* scratch,

@@ -293,6 +293,35 @@ def test_config4_inference_trunk_equals_the_stage_forwards(B, monkeypatch):
         assert torch.equal(f3, s3) and not torch.equal(f3, f2)
 
 
+def test_config1_chained_stage_heads_change_no_bit(monkeypatch):
+    """bf_stage_chain_head: the temporal stage's opening InstanceNorm computed by the tail of the spatial stage in front of it (one launch and
+    one read of the activation less per block pair) gives the prediction, the loss, d(clip) and every deterministic gradient family bit
+    for bit as the unchained calls do; and the chained launch really replaces 11 statistics launches of the 12-block trunk."""
+    import ctypes, json
+    from bubbleformer_amd import _lib as L
+    B, T, H, W, seed = 1, 16, 192, 192, 12
+    h = L.lib()
+
+    def run():
+        h.bf_prof_enable(1)
+        prod = _product(B, T, H, W, seed, torch.bfloat16)
+        torch.cuda.synchronize()
+        buf = ctypes.create_string_buffer(1 << 15)
+        h.bf_prof_report(buf, len(buf))
+        h.bf_prof_enable(0)
+        return prod, json.loads(buf.value.decode())["in_stats"]["calls"]
+
+    p1, n1 = run()
+    monkeypatch.setenv("BF_STAGE_CHAIN", "0")
+    p2, n2 = run()
+    assert n2 - n1 == 11, (n1, n2)
+    assert p1[1] == p2[1] and torch.equal(p1[0], p2[0]) and torch.equal(p1[2], p2[2])
+    exact = ("input_head.weight", "input_head.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
+    for k in p1[3]:
+        if k.startswith("blocks.") and k.endswith(exact):
+            assert torch.equal(p1[3][k], p2[3][k]), k
+
+
 def test_config1_training_step_takes_the_streaming_embed_debed_kernels():
     """A bf16 training step at the configs[1] clip size runs the round-3 kernels at the two ends of the model, not their generic fallbacks:
     the library's own launch profile names the one-pass embed tail, the last-debed backward passes, the gather / scatter stage GEMMs and
