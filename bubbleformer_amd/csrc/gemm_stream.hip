@@ -35,6 +35,7 @@ struct StreamArgs {
     const float* bias; const float* colscale; const float* colshift; const float* rowscale; int rpg;
     int aux_mode; const bf16* aux; long ld_aux; bf16* gelu_out;
     int KS, mt, nb, ng;       // K chunks, 256-row tiles, column blocks per team, column groups (nb * ng blocks in all)
+    int mh, hunit;            // 128-row half tiles; the weight-stationary kernel deals rows in units of `hunit` of them (1; 2 = whole tiles only)
     int stagger;
     int dbg;      // timing experiments (BF_STREAM_DEBUG): 1 no DMA waits, 2 every tile reads the rows of tile 0, 4 no LDS reads / MFMA, 8 no stores
 };
@@ -72,9 +73,15 @@ __global__ void __launch_bounds__(512) stream_gemm_kernel(StreamArgs a) {
     // column groups (team_split): team t holds group t % ng and is the (t / ng)-th of that group's teams, which share the row tiles
     const int grp = team % a.ng, rank = team / a.ng, gteams = (nteams - grp + a.ng - 1) / a.ng;
     const int c_nb = grp * a.nb + j % a.nb;
-    const int t_beg = (int)((long)a.mt * rank / gteams), t_end = (int)((long)a.mt * (rank + 1) / gteams);
-    if (t_beg >= t_end) return;
-    const int total_steps = (t_end - t_beg) * KS;
+    // Rows are dealt in HALF tiles (128 rows): a run of an odd number of them ends in a tile whose upper half belongs to the next team.
+    // Waves 4-7 own exactly that half (DMA pieces 16..31 = rows 128..255, fragments of rows 128..255, the stores of those rows): in that
+    // tile they issue nothing, multiply nothing and store nothing -- they only keep the barriers.  72 full tiles over 21 teams are 3 or
+    // 4 each (the launch lasts 4); 144 halves are 6 or 7 (3.5).
+    const int h_beg = a.hunit * (int)((long)(a.mh / a.hunit) * rank / gteams), h_end = a.hunit * (int)((long)(a.mh / a.hunit) * (rank + 1) / gteams);
+    if (h_beg >= h_end) return;
+    const int ntile = (h_end - h_beg + 1) >> 1;
+    const bool odd_run = (h_end - h_beg) & 1;
+    const int total_steps = ntile * KS;
 
     // ---- DMA geometry: piece p = rows 8p .. 8p+7 of a chunk; lane -> row 8p + (lane >> 3), LDS chunk (lane & 7) = global chunk
     // (lane & 7) ^ ((row >> 1) & 7) of that row (lds_off<bf16, false, 64>).  A chunk: 32 pieces, 4 per wave; W chunk: 16, 2 per wave.
@@ -96,12 +103,14 @@ __global__ void __launch_bounds__(512) stream_gemm_kernel(StreamArgs a) {
     int issued = 0;                                  // vector-memory operations this wave has issued so far (DMA, loads, stores)
     // ---- DMA issue cursor (one chunk in front of the compute loop, across tile boundaries)
     int i_ks = 0, i_left = total_steps, i_slot = 0;
-    const bf16* i_row = a.A + (long)((a.dbg & 2) ? 0 : t_beg) * BM * a.lda;
+    const bf16* i_row = a.A + (long)((a.dbg & 2) ? 0 : h_beg) * (BM / 2) * a.lda;
     auto issue_A = [&]() {
         const unsigned dst = ldsA + (unsigned)i_slot * (unsigned)(ACHUNK * 2);
+        if (!(odd_run && i_left <= KS && wave >= 4)) {      // (a chunk of the run's last, half tile: rows 128..255 are not this team's)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) glds16(i_row + roffA[t] + i_ks * BK, dst + t * 1024u);
-        issued += 4;
+            for (int t = 0; t < 4; ++t) glds16(i_row + roffA[t] + i_ks * BK, dst + t * 1024u);
+            issued += 4;
+        }
         i_slot ^= 1;
         --i_left;
         if (++i_ks == KS) { i_ks = 0; if (!(a.dbg & 2)) i_row += (long)BM * a.lda; }
@@ -156,8 +165,8 @@ __global__ void __launch_bounds__(512) stream_gemm_kernel(StreamArgs a) {
     const bool has_rs = CS && a.rowscale != nullptr;
     int aux_mark = 0;
     int slot = 0;
-    for (int t = t_beg; t < t_end; ++t) {
-        const int m0 = t * BM;
+    auto run_tile = [&](int tt) __attribute__((always_inline)) {
+        const int m0 = h_beg * (BM / 2) + tt * BM;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -263,6 +272,19 @@ __global__ void __launch_bounds__(512) stream_gemm_kernel(StreamArgs a) {
             }
         }
         issued += GELU2 ? 16 : 8;
+    };
+    // the full tiles by all eight waves; the closing half tile of an odd run by waves 0-3 alone -- waves 4-7 (whose rows, DMA pieces and
+    // stores it does not contain) only keep its KS barriers, after their own pieces of the resident weight have landed
+    const int nfull = odd_run ? ntile - 1 : ntile;
+    for (int tt = 0; tt < nfull; ++tt) run_tile(tt);
+    if (odd_run) {
+        if (wave < 4) run_tile(ntile - 1);
+        else
+            for (int ks = 0; ks < KS; ++ks) {
+                wait_vm<0>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
     }
 }
 
@@ -524,7 +546,8 @@ int num_cus() {
 // A team is one workgroup per column block of ONE column group, on one XCD (wpx workgroups each).  All NB blocks in one team is the
 // least re-reading of the token rows, but 12 blocks (N = 1536: fc1, the fc2 data gradient) leave room for 2 teams of 12 on an XCD's 32
 // workgroups: 16 teams for 72 row tiles = 5 tiles for some, with a quarter of the CUs unused.  Two groups of 6 blocks: 5 teams per XCD,
-// 20 per group, 4 tiles at most.  Pick the split with the shortest longest run; ties go to fewer groups (fewer reads of the rows).
+// 20 per group, 4 tiles at most.  With rows dealt in half tiles (stream_gemm_kernel) three groups of 4 blocks do better still: 21-22 teams
+// per group, 7 half tiles at most.  Pick the split with the shortest longest run; ties go to fewer groups (fewer reads of the rows).
 bool team_split(int NB, int mt, int wpx, int* nb, int* ng) {
     static const int force = bf_knob("BF_STREAM_GROUPS", 0);
     int best = 0, best_cost = 0;
@@ -568,9 +591,11 @@ int bf_gemm_stream_try(int M, int N, int K, const bf_operand* A, const bf_operan
     a.A = (const bf16*)A->p; a.lda = A->ld; a.W = (const bf16*)B->p; a.ldw = B->ld; a.C = (bf16*)E->c; a.ldc = E->ldc;
     a.bias = E->bias; a.colscale = E->colscale; a.colshift = E->colshift; a.rowscale = E->rowscale; a.rpg = E->rows_per_group > 0 ? E->rows_per_group : 1;
     a.aux_mode = E->aux_mode; a.aux = (const bf16*)E->aux; a.ld_aux = E->ld_aux; a.gelu_out = (bf16*)E->gelu_out;
-    a.KS = K / BK; a.mt = M / BM;
+    a.KS = K / BK; a.mt = M / BM; a.mh = M / (BM / 2);
+    static const int half_on = bf_knob("BF_STREAM_HALF", 1);
+    a.hunit = half_on ? 1 : 2;
     const int grid = (num_cus() / 8) * 8;
-    if (!team_split(N / BNB, a.mt, grid / 8, &a.nb, &a.ng)) return 1;
+    if (!team_split(N / BNB, (use_pp || !half_on) ? a.mt : a.mh, grid / 8, &a.nb, &a.ng)) return 1;      // rows are dealt in half tiles by the weight-stationary kernel
     static const int dbg = bf_knob("BF_STREAM_DEBUG", 0);
     a.dbg = dbg;
     static const int stagger = bf_knob("BF_STREAM_STAGGER", 1);
