@@ -84,6 +84,8 @@ SIGNATURES = {
     "bf_gemm_tokred": (C.c_int, [C.c_int, C.c_int, C.c_int, i64, vp, i64, vp, i64, fp, C.c_int, fp, fp, i64, vp]),
     "bf_gemm_tokred_ws_floats": (i64, [C.c_int, C.c_int, i64]),
     "bf_gemm_inbwd_frames": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, vp, vp, vp, C.c_int, fp, fp, fp, fp, fp, C.c_int, vp]),
+    "bf_gemm_inbwd_frames_chain": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, vp, vp, vp, C.c_int, fp, fp, fp, fp, fp, C.c_int,
+                                             vp, vp, fp, fp, fp, fp, C.c_int, fp, vp]),
     "bf_in_stats": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, fp, fp, fp, C.c_int, fp, fp, fp, fp, fp, fp, vp]),
     "bf_in_ws_floats": (i64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "bf_affine_apply": (C.c_int, [C.c_int, vp, vp, fp, fp, vp, i64, C.c_int, C.c_int, vp]),
@@ -110,6 +112,7 @@ SIGNATURES = {
     "bf_gather_gemm_rebuilt": (C.c_int, [C.c_int, vp, vp, vp, C.c_int, fp, fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "bf_gather_wgrad_rebuilt": (C.c_int, [C.c_int, vp, vp, vp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, C.c_int64, vp]),
     "bf_stage_chain_head": (C.c_int, [vp, vp, vp]),
+    "bf_stage_chain_tail": (C.c_int, [vp, vp, C.c_int]),
     "bf_embed_tail_ws_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "bf_embed_tail_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, fp, fp, fp, fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     fp, C.c_int64, vp]),

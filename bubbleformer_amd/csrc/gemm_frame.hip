@@ -271,6 +271,10 @@ struct PairArgs {
     const float* fscale; int fdiv;
     bf16* out2;                         // MODE 1, optional: out2 = out * fscale[row / fdiv] (the stochastic-depth-scaled copy the next kernels read)
     int whole;                          // MODE 0: 1 = the tile is ONE frame of 288 tokens (24 x 12 grids: BASELINE configs[3]) instead of two of 144
+    // MODE 0, optional chain (two-frame tiles only): `out` is also the incoming gradient of ANOTHER InstanceNorm (statistics cmean / crstd of
+    // cz, affine weight cw, optional post scale cg[(frame / cgdiv)][column]) whose backward is the next kernel in line -- it is applied here,
+    // to the rows as stored: cdz = crstd cw cg (out - (s1 + xh s2) / S), partials {s1, s2} to cws (the layout of ws)
+    const bf16* cz; bf16* cdz; const float *cmean, *crstd, *cw, *cg; int cgdiv; float* cws;
 };
 
 // LDS-DMA with a wave-uniform 64-bit base in SGPRs and a per-lane 32-bit byte offset: one offset register serves every piece of a wave
@@ -320,7 +324,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
     // nk - 2, frame 1: the slot of step nk - 3 -- both were read by every wave before this wave's last load segment starts); no register
     // is written asynchronously.  Piece p = w4 + 4t (t < 9) = rows 4p .. 4p+3 of the frame, 256 bytes each.
     const unsigned voffX = (unsigned)(((long)(lane >> 4) * a.ldx + 8 * (lane & 15)) * 2);
-    const bf16* sX = MODE == 0 ? a.x + ((long)m0 + 144 * GRP + 4 * w4) * a.ldx + n0 : nullptr;
+    const bf16* sX = MODE != 1 ? a.x + ((long)m0 + 144 * GRP + 4 * w4) * a.ldx + n0 : nullptr;
     const long pieceX = 16 * a.ldx;
     int xslot = 0;
 
@@ -338,8 +342,8 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
     // step body: nothing is carried through the loop in registers)
     uint4 ad[9];
     float mu[8], rs[8], ww[8];
-    const int fidx = (MODE == 0 && a.whole) ? fidx0 : fidx0 + GRP;
-    const long pbase = MODE == 0 ? (long)fidx * a.N + col0 : 0;
+    const int fidx = (MODE != 1 && a.whole) ? fidx0 : fidx0 + GRP;
+    const long pbase = MODE != 1 ? (long)fidx * a.N + col0 : 0;
     auto kstep = [&](auto last_tag, int s) __attribute__((always_inline)) {
         constexpr bool LAST = decltype(last_tag)::value;
         // ======== load segment: fragments of step s; DMA of step s + 2 into the slot that held step s - 1 (every wave finished reading
@@ -351,7 +355,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
 #pragma unroll
                 for (int i = 0; i < 9; ++i) ad[i] = *reinterpret_cast<const uint4*>(a.add + (row0 + 16 * i) * a.ldx + col0);
             }
-            if constexpr (MODE == 0) {
+            if constexpr (MODE != 1) {
                 const float4 m0 = *reinterpret_cast<const float4*>(a.mean + pbase), m1 = *reinterpret_cast<const float4*>(a.mean + pbase + 4);
                 const float4 r0 = *reinterpret_cast<const float4*>(a.rstd + pbase), r1 = *reinterpret_cast<const float4*>(a.rstd + pbase + 4);
                 const float4 w0 = *reinterpret_cast<const float4*>(a.w + col0), w1 = *reinterpret_cast<const float4*>(a.w + col0 + 4);
@@ -372,7 +376,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
         if constexpr (!LAST) {
             if (s + 2 < nk) { issue(sl2); wait_vm<PG>(); }
             else wait_vm<0>();
-        } else if constexpr (MODE == 0) {           // last step: the x rows land under its MFMAs (waited for before the barrier that ends them)
+        } else if constexpr (MODE != 1) {           // last step: the x rows land under its MFMAs (waited for before the barrier that ends them)
             xslot = GRP == 0 ? sl2 : (slot == PNSLOT - 1 ? 0 : slot + 1);
             const unsigned dst = __builtin_amdgcn_readfirstlane(ring + (unsigned)xslot * (unsigned)PSLOT_BYTES + (unsigned)w4 * 1024u);
 #pragma unroll
@@ -389,17 +393,18 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (LAST && MODE == 0 && GRP == 1) wait_vm<0>();           // this wave's x pieces: visible to the workgroup after the barrier below
+        if (LAST && MODE != 1 && GRP == 1) wait_vm<0>();           // this wave's x pieces: visible to the workgroup after the barrier below
         __builtin_amdgcn_s_barrier();
         slot = slot == PNSLOT - 1 ? 0 : slot + 1;
     };
     for (int s = 0; s + 1 < nk; ++s) kstep(std::false_type{}, s);
     kstep(std::true_type{}, nk - 1);
     if constexpr (GRP == 0) {
-        if constexpr (MODE == 0) wait_vm<0>();                      // ... and likewise for waves 0-3
+        if constexpr (MODE != 1) wait_vm<0>();                      // ... and likewise for waves 0-3
         __builtin_amdgcn_s_barrier();                               // pairs with the extra barrier of waves 4-7: everybody's x pieces have landed
     }
 
+    constexpr bool chain = MODE == 2;      // its own instantiation: the code below costs the unchained kernel 13 spilled registers and 1.5 us per launch
     // ---- epilogue.  acc[i][j]: row 16 i + li, columns 16 j + 4 lg .. + 3.  After exchanging the odd lane rows of tile 0 with the even
     // lane rows of tile 1 a lane holds 8 consecutive columns at c8.
     float v[9][8];
@@ -495,6 +500,67 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
             }
             *reinterpret_cast<bf16x8*>(a.out + (row0 + 16 * i) * a.ldx + col0) = o;
         }
+        if constexpr (chain) {      // the next InstanceNorm backward in line, on the rows just stored (144-token frames: whole frame columns sit in this wave)
+            // its rows are requested only now: before this point the kernel has no registers to park them in (248 of 256 in use), and a
+            // spill next to hand-counted vmcnt is not an option; the ~2 us of exposed latency cost less than the launch they replace
+            // (the rows just stored are read back -- same lane, same addresses, L2-hot -- rather than kept)
+            __builtin_amdgcn_sched_barrier(0);      // ... and the scheduler must not lift these loads into the epilogue above
+            uint4 zr[9];
+            bf16x8 ov[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                zr[i] = *reinterpret_cast<const uint4*>(a.cz + (row0 + 16 * i) * a.ldx + col0);
+                ov[i] = *reinterpret_cast<const bf16x8*>(a.out + (row0 + 16 * i) * a.ldx + col0);
+            }
+            const long cb = (long)fidx * a.N + col0;
+            float m3[8], r3[8], k3[8];
+            {
+                const float4 m0 = *reinterpret_cast<const float4*>(a.cmean + cb), m1 = *reinterpret_cast<const float4*>(a.cmean + cb + 4);
+                const float4 r0 = *reinterpret_cast<const float4*>(a.crstd + cb), r1 = *reinterpret_cast<const float4*>(a.crstd + cb + 4);
+                const float4 w0 = *reinterpret_cast<const float4*>(a.cw + col0), w1 = *reinterpret_cast<const float4*>(a.cw + col0 + 4);
+                m3[0] = m0.x; m3[1] = m0.y; m3[2] = m0.z; m3[3] = m0.w; m3[4] = m1.x; m3[5] = m1.y; m3[6] = m1.z; m3[7] = m1.w;
+                r3[0] = r0.x; r3[1] = r0.y; r3[2] = r0.z; r3[3] = r0.w; r3[4] = r1.x; r3[5] = r1.y; r3[6] = r1.z; r3[7] = r1.w;
+                k3[0] = w0.x; k3[1] = w0.y; k3[2] = w0.z; k3[3] = w0.w; k3[4] = w1.x; k3[5] = w1.y; k3[6] = w1.z; k3[7] = w1.w;
+                if (a.cg) {
+                    const long gbase = (long)(fidx / a.cgdiv) * a.N + col0;
+                    const float4 g0 = *reinterpret_cast<const float4*>(a.cg + gbase), g1 = *reinterpret_cast<const float4*>(a.cg + gbase + 4);
+                    k3[0] *= g0.x; k3[1] *= g0.y; k3[2] *= g0.z; k3[3] *= g0.w; k3[4] *= g1.x; k3[5] *= g1.y; k3[6] *= g1.z; k3[7] *= g1.w;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) k3[q] *= r3[q];
+            }
+            float c1[8], c2[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { c1[q] = 0.f; c2[q] = 0.f; }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const bf16x8 z8 = __builtin_bit_cast(bf16x8, zr[i]);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float dd = (float)ov[i][q], xh = ((float)z8[q] - m3[q]) * r3[q];
+                    c1[q] += dd;
+                    c2[q] += dd * xh;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { c1[q] = row16_sum(c1[q]); c2[q] = row16_sum(c2[q]); }
+            if (li == 0 && a.cws) {
+                float* wp = a.cws + cb * 2;
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) *reinterpret_cast<float4*>(wp + 2 * q) = make_float4(c1[q], c2[q], c1[q + 1], c2[q + 1]);
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const bf16x8 z8 = __builtin_bit_cast(bf16x8, zr[i]);
+                bf16x8 o;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float dd = (float)ov[i][q], xh = ((float)z8[q] - m3[q]) * r3[q];
+                    o[q] = (bf16)(k3[q] * (dd - (c1[q] + xh * c2[q]) * (1.f / 144.f)));
+                }
+                *reinterpret_cast<bf16x8*>(a.cdz + (row0 + 16 * i) * a.ldx + col0) = o;
+            }
+        }
     }
 }
 
@@ -505,7 +571,7 @@ __global__ void __launch_bounds__(512) gemm_pair_kernel(PairArgs a) {
     const int seq = xcd_remap(blockIdx.x, gridDim.x);       // the column blocks of a frame pair run back to back on one XCD: its rows come through one L2
     const int fp = seq / a.nt;
     const int m0 = fp * PM, n0 = (seq - fp * a.nt) * PN;
-    const int f0 = (MODE == 0 && a.whole) ? fp : 2 * fp;
+    const int f0 = (MODE != 1 && a.whole) ? fp : 2 * fp;
     if (wave < 4) pair_body<MODE, 0>(a, smem, lane, wave, m0, n0, f0);
     else pair_body<MODE, 1>(a, smem, lane, wave - 4, m0, n0, f0);
 }
@@ -531,9 +597,29 @@ bool pair_shape_ok(int M, int N, int K, int64_t lda, int64_t ldb) {
 
 }  // namespace
 
+struct InbwdChain { const void* z; void* dz; const float *mean, *rstd, *w, *g; int gdiv; float* ws; };
+static int inbwd_frames_impl(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, const void* x,
+                             const void* add, void* out, int S, const float* mean, const float* rstd, const float* w, float* ws,
+                             const float* fscale, int fdiv, const InbwdChain* ch, bf_stream_t stream);
 extern "C" int bf_gemm_inbwd_frames(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, const void* x,
                                     const void* add, void* out, int S, const float* mean, const float* rstd, const float* w, float* ws,
                                     const float* fscale, int fdiv, bf_stream_t stream) {
+    return inbwd_frames_impl(dtype, M, N, K, A, lda, B, ldb, x, add, out, S, mean, rstd, w, ws, fscale, fdiv, nullptr, stream);
+}
+// ... with the backward of a SECOND InstanceNorm applied to `out` in the same launch (the norm whose output gradient `out` is: the spatial
+// stage's MLP-branch norm behind a temporal stage's norm1): dz = crstd cw cg (out - (s1 + xh s2) / S), xh = (z - cmean) crstd, partials {s1, s2}
+// to cws.  Returns 1 (nothing launched) where the frame-pair kernel with two 144-token frames per tile does not apply.
+extern "C" int bf_gemm_inbwd_frames_chain(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, const void* x,
+                                          const void* add, void* out, int S, const float* mean, const float* rstd, const float* w, float* ws,
+                                          const float* fscale, int fdiv, const void* cz, void* cdz, const float* cmean, const float* crstd,
+                                          const float* cw, const float* cg, int cgdiv, float* cws, bf_stream_t stream) {
+    BF_REQUIRE(cz && cdz && cmean && crstd && cw, "bf_gemm_inbwd_frames_chain: null pointer");
+    const InbwdChain ch{cz, cdz, cmean, crstd, cw, cg, cgdiv > 0 ? cgdiv : 1, cws};
+    return inbwd_frames_impl(dtype, M, N, K, A, lda, B, ldb, x, add, out, S, mean, rstd, w, ws, fscale, fdiv, &ch, stream);
+}
+static int inbwd_frames_impl(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, const void* x,
+                             const void* add, void* out, int S, const float* mean, const float* rstd, const float* w, float* ws,
+                             const float* fscale, int fdiv, const InbwdChain* ch, bf_stream_t stream) {
     BF_REQUIRE(A && B && x && out && mean && rstd && w, "bf_gemm_inbwd_frames: null pointer");
     static const bool off = bf_knob("BF_FUSE_INBWD", 1) == 0;
     if (off || dtype != BF_DTYPE_BF16 || (S != FM && S != PM) || M <= 0 || M % S || N <= 0 || N % FN || K < FK || K % FK || lda % 8 || ldb % 8) return 1;
@@ -543,9 +629,16 @@ extern "C" int bf_gemm_inbwd_frames(int dtype, int M, int N, int K, const void* 
         a.A = (const bf16*)A; a.lda = lda; a.B = (const bf16*)B; a.ldb = ldb; a.N = N; a.nk = K / PK; a.nt = N / PN;
         a.x = (const bf16*)x; a.add = (const bf16*)add; a.out = (bf16*)out; a.ldx = N;
         a.mean = mean; a.rstd = rstd; a.w = w; a.ws = ws; a.fscale = fscale; a.fdiv = fdiv > 0 ? fdiv : 1; a.out2 = nullptr;
-        BfProfScope prof((hipStream_t)stream, "gemm_pair<inbwd>", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * N * (add ? 3 : 2)));
-        return launch_pair<0>(a, M, (hipStream_t)stream);
+        a.cz = nullptr; a.cdz = nullptr; a.cmean = a.crstd = a.cw = a.cg = nullptr; a.cgdiv = 1; a.cws = nullptr;
+        if (ch) {
+            if (a.whole || (((uintptr_t)ch->z | (uintptr_t)ch->dz) & 15)) return 1;
+            a.cz = (const bf16*)ch->z; a.cdz = (bf16*)ch->dz; a.cmean = ch->mean; a.crstd = ch->rstd; a.cw = ch->w; a.cg = ch->g; a.cgdiv = ch->gdiv; a.cws = ch->ws;
+        }
+        BfProfScope prof((hipStream_t)stream, ch ? "gemm_pair<inbwd,chain>" : "gemm_pair<inbwd>", 2.0 * M * N * K,
+                         2.0 * ((double)M * K + (double)N * K + (double)M * N * ((add ? 3 : 2) + (ch ? 2 : 0))));
+        return ch ? launch_pair<2>(a, M, (hipStream_t)stream) : launch_pair<0>(a, M, (hipStream_t)stream);
     }
+    if (ch) return 1;
     if (S != FM) return 1;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_inbwd_frames_kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -582,6 +675,7 @@ int bf_gemm_pair_scaled(int M, int N, int K, const bf_operand* A, const bf_opera
     a.x = nullptr; a.add = E->aux_mode == BF_AUX_ADD ? (const bf16*)E->aux : nullptr; a.out = (bf16*)E->c; a.ldx = N;
     a.mean = nullptr; a.rstd = nullptr; a.w = nullptr; a.ws = nullptr; a.fscale = rowfac; a.fdiv = rows_per_group > 0 ? rows_per_group : 1;
     a.out2 = rowfac ? (bf16*)out2 : nullptr; a.whole = 0;
+    a.cz = nullptr; a.cdz = nullptr; a.cmean = a.crstd = a.cw = a.cg = nullptr; a.cgdiv = 1; a.cws = nullptr;
     if (a.out2 && ((uintptr_t)out2 & 15)) return 1;
     BfProfScope prof(st, a.add ? "gemm_pair<add>" : "gemm_pair<plain>", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * N * (a.add ? 2 : 1)));
     return launch_pair<1>(a, M, st);

@@ -553,9 +553,19 @@ void* bwd_scratch(const D& d, void* scratch) {
 }
 // A data gradient dy @ W whose consumer is the backward of the InstanceNorm that fed the projection: when a frame is one
 // 144-row GEMM tile the two run as ONE kernel (gemm_frame.hip); otherwise GEMM into `tmp`, then the InstanceNorm backward.
+// the backward of the NEXT InstanceNorm in line, applied by the same launch where the frame-pair kernel covers it (bf_gemm_inbwd_frames_chain)
+struct TailNorm { const void* z; void* dz; const float *mean, *rstd, *w, *g; int gdiv; float* ws; bool* done; };
 struct InFuse { const void* x; const void* add; void* dx; const float* mean; const float* rstd; const float* w; const float* b; float* ws;
-                const float* fscale = nullptr; int fdiv = 1; };      // fscale: optional per-frame-group factor on dy (stochastic depth)
+                const float* fscale = nullptr; int fdiv = 1;         // fscale: optional per-frame-group factor on dy (stochastic depth)
+                const TailNorm* tail = nullptr; };
 int dgrad_inbwd(const D& d, const void* dy, int Kdim, const void* w_xc, int Nout, void* tmp, const InFuse& f, hipStream_t st) {
+    if (f.tail) {
+        const TailNorm& t = *f.tail;
+        const int crc = bf_gemm_inbwd_frames_chain(d.dtype, (int)d.N, Nout, Kdim, dy, Kdim, w_xc, Nout, f.x, f.add, f.dx, (int)d.S, f.mean, f.rstd, f.w, f.ws,
+                                                   f.fscale, f.fdiv, t.z, t.dz, t.mean, t.rstd, t.w, t.g, t.gdiv, t.ws, st);
+        if (crc < 0) return crc;
+        if (crc == 0) { *t.done = true; return 0; }
+    }
     const int rc = bf_gemm_inbwd_frames(d.dtype, (int)d.N, Nout, Kdim, dy, Kdim, w_xc, Nout, f.x, f.add, f.dx, (int)d.S, f.mean, f.rstd, f.w, f.ws,
                                         f.fscale, f.fdiv, st);
     if (rc <= 0) return rc;
@@ -659,6 +669,19 @@ namespace {
 struct NextHead { bool armed = false; const float *w = nullptr, *b = nullptr; float *mean = nullptr, *rstd = nullptr, *sc = nullptr, *sh = nullptr; void* xn = nullptr; const void* saved = nullptr; } g_next_head;
 const void* g_head_done_for = nullptr;
 }  // namespace
+// ... and the mirror image in the backward: the temporal stage's last kernel (QKV data gradient + norm1 backward) produces the output
+// gradient of the spatial stage in front of it, whose backward opens with its MLP-branch InstanceNorm.  bf_stage_chain_tail arms that
+// norm's backward (the spatial stage's parameters, saved record and whether its MLP branch carried stochastic depth) for the temporal
+// backward called next; the spatial backward on the same record then finds dz and the partial sums in place.
+namespace {
+struct NextTail { bool armed = false; const bf_spatial_params* p = nullptr; const void* saved = nullptr; bool drop = false; } g_next_tail;
+const void* g_tail_done_for = nullptr;
+}  // namespace
+extern "C" int bf_stage_chain_tail(const bf_spatial_params* prev_p, const void* prev_saved, int has_drop_mlp) {
+    g_next_tail.armed = prev_p && prev_saved;
+    g_next_tail.p = prev_p; g_next_tail.saved = prev_saved; g_next_tail.drop = has_drop_mlp != 0;
+    return 0;
+}
 extern "C" int bf_stage_chain_head(const bf_dims* dims, const bf_temporal_params* next_p, void* next_saved) {
     g_next_head.armed = false;
     if (!dims || !next_p || !next_saved) return 0;          // disarm
@@ -742,7 +765,28 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
                                                d.attn_scale ? g->attn_scale_factor : nullptr};
     }
     void* dxn = sc.t1;      // don is dead
-    const InFuse fu1{x, dout, dx, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, sc.in_ws};             // dqkv @ W_in, then norm1's backward + residual
+    InFuse fu1{x, dout, dx, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, sc.in_ws};             // dqkv @ W_in, then norm1's backward + residual
+    // Chained tail (bf_stage_chain_tail): dx is the output gradient of the spatial stage in front, whose backward opens with its MLP-branch
+    // InstanceNorm -- applied here, into THAT stage's scratch set (the other one: its earlier user's side work is joined first, as the
+    // spatial stage itself would at its start).
+    TailNorm tn;
+    bool tail_done = false;
+    if (g_next_tail.armed) {
+        const NextTail h = g_next_tail;
+        g_next_tail.armed = false;
+        static const bool chain_on = bf_knob("BF_BWD_CHAIN", 1) != 0;
+        if (chain_on && fk.deferred && d.dtype == BF_DTYPE_BF16 && d.S == 144 && d.F % 2 == 0) {
+            const int oset = g_scratch_parity ^ 1;
+            TRY(side_join_pending(st, oset));
+            Scratch so(d, (char*)scratch + (size_t)oset * Scratch(d, nullptr).bytes);
+            SpatialSaved ps(d, const_cast<void*>(h.saved));
+            tn = TailNorm{ps.z, so.t1, ps.mean3, ps.rstd3, h.p->mlp_norm_w, h.drop ? ps.gtab : h.p->gamma_mlp, h.drop ? 1 : (int)d.F, so.in_ws3, &tail_done};
+            fu1.tail = &tn;
+        }
+        g_tail_done_for = nullptr;
+        TRY(linear_bwd(d, sc, dqkv, 3 * d.E, sv.xn, d.E, BF_PRO_NONE, nullptr, nullptr, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk, &fu1, true));
+        if (tail_done) g_tail_done_for = h.saved;
+    } else
     TRY(linear_bwd(d, sc, dqkv, 3 * d.E, sv.xn, d.E, BF_PRO_NONE, nullptr, nullptr, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk, &fu1, true));
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws, (int)d.F, d.E, p->norm1_w, p->norm1_b, nullptr, 1, g->norm1_w, g->norm1_b, nullptr, nullptr, nullptr, nullptr};
     TRY(launch_reduce_jobs(jobs, st));
@@ -901,13 +945,17 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     // out = x1 + gamma_mlp * IN(z)
     void* dz = sc.t1;
     ReduceJobs jobs;        // parameter-gradient reductions, all launched together at the end
+    const bool tail_done = g_tail_done_for == saved;      // the temporal stage behind left dz and the partial sums in place (bf_stage_chain_tail)
+    g_tail_done_for = nullptr;
     if (drop_mlp) {   // gtab[f][c] = drop_mlp[f] * gamma_mlp[c] was the scale: d gamma_mlp = sum_f drop_mlp[f] * (w s2 + b s1), folded in the reduction
-        TRY(bf_in_bwd_partials(d.dtype, dout, sv.z, nullptr, dz, (int)d.F, (int)d.S, d.E, sv.mean3, sv.rstd3, p->mlp_norm_w, p->mlp_norm_b, sv.gtab, 1, 0, sc.in_ws3, st));
+        if (!tail_done)
+            TRY(bf_in_bwd_partials(d.dtype, dout, sv.z, nullptr, dz, (int)d.F, (int)d.S, d.E, sv.mean3, sv.rstd3, p->mlp_norm_w, p->mlp_norm_b, sv.gtab, 1, 0, sc.in_ws3, st));
         jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws3, (int)d.F, d.E, p->mlp_norm_w, p->mlp_norm_b, sv.gtab, 1, g->mlp_norm_w, g->mlp_norm_b, nullptr, nullptr,
                                            drop_mlp, g->gamma_mlp};
     } else {
-        TRY(bf_in_bwd_partials(d.dtype, dout, sv.z, nullptr, dz, (int)d.F, (int)d.S, d.E, sv.mean3, sv.rstd3, p->mlp_norm_w, p->mlp_norm_b, p->gamma_mlp,
-                               (int)d.F, 0, sc.in_ws3, st));
+        if (!tail_done)
+            TRY(bf_in_bwd_partials(d.dtype, dout, sv.z, nullptr, dz, (int)d.F, (int)d.S, d.E, sv.mean3, sv.rstd3, p->mlp_norm_w, p->mlp_norm_b, p->gamma_mlp,
+                                   (int)d.F, 0, sc.in_ws3, st));
         jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws3, (int)d.F, d.E, p->mlp_norm_w, p->mlp_norm_b, p->gamma_mlp, (int)d.F, g->mlp_norm_w, g->mlp_norm_b,
                                            g->gamma_mlp, nullptr, nullptr, nullptr};
     }

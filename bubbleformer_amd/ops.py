@@ -198,6 +198,7 @@ _PREPARED: dict = {}      # (kind, pointer of the stage's first parameter) -> (d
 
 
 _CHAIN = {"next": None}
+_LAST_SPATIAL = {"v": None}
 
 
 def chain_next(params) -> None:
@@ -439,6 +440,15 @@ class _BlockFn(torch.autograd.Function):
         else:
             rc = fwd(C.byref(d), C.byref(st), _p(x), _p(out), _p(saved), _p(scratch_for(d, x.device)), _p(drop_a), _p(drop_b), _stream())
         L.check(rc, f"bf_{kind}_fwd")
+        # Backward chain (bf_stage_chain_tail): a temporal stage fed by a spatial stage's output remembers that stage -- its backward's last
+        # kernel produces that stage's output gradient and can open that stage's backward (the MLP-branch InstanceNorm) in the same launch
+        last, _LAST_SPATIAL["v"] = _LAST_SPATIAL["v"], None
+        ctx.prev_spatial = None
+        if kind == "spatial":
+            if x.dtype == torch.bfloat16 and os.environ.get("BF_STAGE_CHAIN", "1") != "0":
+                _LAST_SPATIAL["v"] = (out.data_ptr(), (tuple(x.shape), x.dtype), st, saved, drop_b is not None, params)
+        elif last is not None and last[0] == x.data_ptr() and last[1] == (tuple(x.shape), x.dtype):
+            ctx.prev_spatial = last[2:]
         ctx.drops = (drop_a, drop_b)
         ctx.kind, ctx.cfg = kind, (heads, attn_scale, feat_scale)
         ctx.save_for_backward(x, saved, *[p for p in params if p is not None])
@@ -463,7 +473,11 @@ class _BlockFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         drop_a, drop_b = ctx.drops
         if ctx.kind == "temporal":
+            ps = getattr(ctx, "prev_spatial", None)
+            if ps is not None and direct:       # (the chained norm's partial sums are reduced by the spatial stage's own backward, which must follow)
+                L.check(lib.bf_stage_chain_tail(C.byref(ps[0]), _p(ps[1]), 1 if ps[2] else 0), "bf_stage_chain_tail")
             rc = bwd(C.byref(d), C.byref(st), C.byref(gs), _p(x), _p(dout), _p(dx), _p(saved), _p(scratch_for(d, x.device)), _p(drop_a), _stream())
+            lib.bf_stage_chain_tail(None, None, 0)
         else:
             rc = bwd(C.byref(d), C.byref(st), C.byref(gs), _p(x), _p(dout), _p(dx), _p(saved), _p(scratch_for(d, x.device)), _p(drop_a),
                      _p(drop_b), _stream())

@@ -106,6 +106,15 @@ int bf_gemm_inbwd_frames(int dtype, int M, int N, int K, const void* A, int64_t 
                          const void* add, void* out, int S, const float* mean, const float* rstd, const float* w, float* ws,
                          const float* fscale /* optional: dy of frame f is multiplied by fscale[f / fdiv] (stochastic depth) */, int fdiv,
                          bf_stream_t stream);
+/* ... and the backward of a SECOND InstanceNorm applied to `out` in the same launch: the norm whose output gradient `out` is (in the model: the
+ * MLP-branch norm of the spatial stage in front of a temporal stage, autograd of layers/attention.py:305-317 behind :77-78).  cz: that norm's
+ * input rows, cmean / crstd its statistics [frames][N], cw its weight, cg an optional post scale [frames / cgdiv][N] (layer scale, or the
+ * stochastic-depth table).  cdz = crstd cw cg (out - (s1 + xh s2) / S), xh = (cz - cmean) crstd; partials {s1, s2} to cws (ws layout).
+ * Returns 1 (nothing launched) where the two-frames-per-tile kernel does not apply (S != 144, odd frame counts, fp32). */
+int bf_gemm_inbwd_frames_chain(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, const void* x,
+                               const void* add, void* out, int S, const float* mean, const float* rstd, const float* w, float* ws,
+                               const float* fscale, int fdiv, const void* cz, void* cdz, const float* cmean, const float* crstd,
+                               const float* cw, const float* cg, int cgdiv, float* cws, bf_stream_t stream);
 
 /* Token-reduction GEMM (weight gradient of a 1x1 conv / Linear: autograd of layers/attention.py:78,121,210,299, linear_layers.py:18-25):
  *   out[Nout][Kin] = (accumulate ? out : 0) + sum_tok dy[tok][Nout] * x[tok][Kin],  colsum[Nout] likewise + sum_tok dy[tok][:]  (optional)
@@ -370,6 +379,11 @@ int bf_trunk_eval_fwd(const bf_dims* dims, int n, const int32_t* kinds, const vo
  * NULL arguments disarm.  A spatial stage that cannot chain (fp32 frames longer than the register cache, ...) leaves the norm to the
  * temporal stage as usual. */
 int bf_stage_chain_head(const bf_dims* dims, const bf_temporal_params* next_p, void* next_saved);
+/* The mirror image in the backward: the temporal stage's last kernel produces the output gradient of the spatial stage in front of it (prev_p,
+ * prev_saved; has_drop_mlp: its MLP branch carried stochastic-depth factors), whose backward opens with its MLP-branch InstanceNorm -- armed
+ * here, that norm's backward is applied by the temporal backward called next (bf_gemm_inbwd_frames_chain) and bf_spatial_bwd on prev_saved
+ * skips it.  bf16, 144-token frames, an even number of frames; otherwise nothing changes.  NULL arguments disarm. */
+int bf_stage_chain_tail(const bf_spatial_params* prev_p, const void* prev_saved, int has_drop_mlp);
 /* Stochastic depth (timm DropPath at layers/attention.py:123,309,317): `drop*` are the per-sample factors (0 or 1/keep) the
  * caller drew -- [B] for the temporal block (dim 0 = batch), [B*T] each for the two branches of the axial block -- or NULL. */
 int bf_temporal_fwd(const bf_dims* d, const bf_temporal_params* p, const void* x, void* out, void* saved, void* scratch,

@@ -322,6 +322,38 @@ def test_config1_chained_stage_heads_change_no_bit(monkeypatch):
             assert torch.equal(p1[3][k], p2[3][k]), k
 
 
+def test_config1_backward_chain_matches_the_separate_norm_backward(monkeypatch):
+    """bf_stage_chain_tail inside a TrainStep (deferred side work, the only mode it arms in): the temporal stage's last kernel also applies the
+    backward of the spatial stage's MLP-branch InstanceNorm in front of it.  Against the same step with the chains off: same loss bit
+    for bit (the forward chain changes no bit), gradients equal to rounding (the frame sums of the chained norm are taken in another order
+    and on fp32-in-register rows), and the launch profile shows 11 chained kernels and 11 statistics-backward launches less."""
+    import ctypes, json
+    from bubbleformer_amd import _lib as L
+    from bubbleformer_amd.trainer import TrainStep
+    B, T, H, W, seed = 2, 16, 192, 192, 12
+    h = L.lib()
+    x, y, c = (t.cuda() for t in _inputs(B, T, H, W, seed))
+
+    def run():
+        m = _model(seed, torch.bfloat16, T)       # (drop_path = 0: the two runs see the same network)
+        step = TrainStep(m, lr=0.0, weight_decay=0.0)
+        h.bf_prof_enable(1)
+        loss = float(step(x, c, y))
+        torch.cuda.synchronize()
+        buf = ctypes.create_string_buffer(1 << 15)
+        h.bf_prof_report(buf, len(buf))
+        h.bf_prof_enable(0)
+        return loss, step.flat.grad.detach().clone(), json.loads(buf.value.decode())
+
+    l1, g1, n1 = run()
+    monkeypatch.setenv("BF_STAGE_CHAIN", "0")
+    l2, g2, n2 = run()
+    assert n1.get("gemm_pair<inbwd,chain>", {}).get("calls", 0) == 11, sorted(n1)
+    assert n2["in_bwd"]["calls"] - n1["in_bwd"]["calls"] == 11
+    assert l1 == l2
+    assert float((g1 - g2).norm()) < 2e-3 * float(g2.norm())
+
+
 def test_config1_training_step_takes_the_streaming_embed_debed_kernels():
     """A bf16 training step at the configs[1] clip size runs the round-3 kernels at the two ends of the model, not their generic fallbacks:
     the library's own launch profile names the one-pass embed tail, the last-debed backward passes, the gather / scatter stage GEMMs and

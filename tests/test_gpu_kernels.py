@@ -458,6 +458,45 @@ def _check_gemm_inbwd_frames(K, Fr, Kd, N, with_add, S=144):
     assert K.gemm_inbwd_frames(A.float(), W.float(), x.view(M, N).float(), S, mean, rstd, w) is None
 
 
+@pytest.mark.parametrize("Fr,Kd,N,with_g", [(4, 1152, 384, True), (6, 384, 256, False)])
+def test_gemm_inbwd_frame_pairs_with_a_chained_second_norm(K, Fr, Kd, N, with_g):
+    """bf_gemm_inbwd_frames_chain: the frame-pair data-gradient kernel also applies the backward of the InstanceNorm whose output gradient it
+    has just produced -- against the unchained kernel followed by bf_in_bwd on its output (same bf16 rows in, so only the order of the
+    frame sums differs)."""
+    from bubbleformer_amd import _lib as L
+    from bubbleformer_amd.ops import _p, _stream
+    lib = L.lib()
+    S, M = 144, Fr * 144
+    g = torch.Generator(device="cuda").manual_seed(61)
+    A = (torch.randn(M, Kd, device="cuda", generator=g) * 0.5).bfloat16()
+    W = (torch.randn(Kd, N, device="cuda", generator=g) / Kd ** 0.5).bfloat16()
+    x = (torch.randn(Fr, S, N, device="cuda", generator=g) * 1.5 + 0.3).bfloat16()
+    add = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+    w, b = torch.randn(N, device="cuda", generator=g), torch.randn(N, device="cuda", generator=g)
+    mean, rstd, _, _ = K.in_stats(x, Fr, S, N, w, b)
+    z = (torch.randn(Fr, S, N, device="cuda", generator=g) * 0.7 - 0.2).bfloat16()
+    w3, b3 = torch.randn(N, device="cuda", generator=g), torch.randn(N, device="cuda", generator=g)
+    mean3, rstd3, _, _ = K.in_stats(z, Fr, S, N, w3, b3)
+    gt = (0.5 + torch.rand(Fr, N, device="cuda", generator=g)) if with_g else None
+    ref_dx, ref_ws = K.gemm_inbwd_frames(A, W, x.view(M, N), S, mean, rstd, w, add=add)
+    ref_dz, ref_dw3, ref_db3 = K.in_bwd(ref_dx.view(Fr, S, N), z, Fr, S, N, mean3, rstd3, w3, b3, g=gt, gdiv=1)
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    dz = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ws = torch.zeros(Fr * N * 2, device="cuda")
+    cws = torch.full((Fr * N * 2,), float("nan"), device="cuda")
+    rc = lib.bf_gemm_inbwd_frames_chain(1, M, N, Kd, _p(A), A.stride(0), _p(W), W.stride(0), _p(x), _p(add), _p(out), S, _p(mean), _p(rstd), _p(w), _p(ws),
+                                        None, 1, _p(z), _p(dz), _p(mean3), _p(rstd3), _p(w3), _p(gt), 1, _p(cws), _stream())
+    L.check(rc, "bf_gemm_inbwd_frames_chain")
+    assert torch.equal(out, ref_dx) and torch.equal(ws, ref_ws)
+    assert torch.isfinite(dz.float()).all() and _rel(dz, ref_dz.view(M, N)) < 4e-3
+    s = cws.view(Fr, N, 2)
+    gsum = gt if with_g else torch.ones(Fr, N, device="cuda")
+    assert _rel((gsum * s[..., 1]).sum(0), ref_dw3) < 1e-3 and _rel((gsum * s[..., 0]).sum(0), ref_db3) < 1e-3
+    # 288-token frames (one per tile): declined
+    assert lib.bf_gemm_inbwd_frames_chain(1, 288 * 2, N, Kd, _p(A), A.stride(0), _p(W), W.stride(0), _p(x), _p(add), _p(out), 288, _p(mean), _p(rstd), _p(w), _p(ws),
+                                          None, 1, _p(z), _p(dz), _p(mean3), _p(rstd3), _p(w3), _p(gt), 1, _p(cws), _stream()) == 1
+
+
 def _attn_call(L_lib, qkv, dout, geo, heads, d, prm, generic):
     """Run attention fwd + bwd through the C ABI; returns (out, dqkv, param grads)."""
     import ctypes as C
