@@ -47,8 +47,8 @@ def normalise(name: str) -> str:
         aux, g2, _ = m.groups()
         return "stream_pp<%s>" % ("gelu2" if g2 in ("true", "1") else {"0": "plain", "1": "add", "2": "dgelu"}[aux])
     m = re.search(r"gemm_pair_kernel<(\d)>", name) or re.search(r"gemm_pair_kernelILi(\d)E", name)
-    if m:      # MODE 0: data gradient + InstanceNorm backward; MODE 1: plain data gradient (+ residual) -- the library's profiler names the latter <add>
-        return "gemm_pair<inbwd>" if m.group(1) == "0" else "gemm_pair<add>"
+    if m:      # MODE 0: data gradient + InstanceNorm backward; 1: plain data gradient (+ residual) -- the library's profiler names it <add>; 2: MODE 0 + the chained second norm
+        return {"0": "gemm_pair<inbwd>", "2": "gemm_pair<inbwd,chain>"}.get(m.group(1), "gemm_pair<add>")
     m = re.search(r"tokred_pp_reduce_kernel", name)
     if m:
         return "tokred_reduce_kernel"
