@@ -190,4 +190,6 @@ def lib():
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = lib().bf_last_error().decode(errors="replace")
+        if rc == 1 and not msg.startswith("declined"):      # a refusal that left no text of its own (the last-error text may be stale)
+            msg = "declined: the entry point does not cover this shape / dtype / workspace (nothing was launched)"
         raise BubbleformerHipError(f"{what} failed (code {rc}): {msg}")

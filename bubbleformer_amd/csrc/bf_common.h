@@ -73,6 +73,7 @@ constexpr int bf_knob(const char*, int dflt) { return dflt; }
 
 int bf_fail(hipError_t e, const char* file, int line);
 int bf_fail_msg(const char* msg, const char* file, int line);
+int bf_decline(const char* msg);      // returns 1 (shape not covered) and records why
 
 // ---------------------------------------------------------------- scalar conversions
 __device__ __forceinline__ float to_f(float x) { return x; }

@@ -13,6 +13,12 @@ int bf_fail_msg(const char* msg, const char* file, int line) {
     snprintf(g_err, sizeof(g_err), "%s:%d: %s", file, line, msg);
     return -1;
 }
+// a refusal (return code 1: shape / workspace not covered, nothing launched) also leaves its reason behind, so that a caller who treats
+// it as an error has a text to show
+int bf_decline(const char* msg) {
+    snprintf(g_err, sizeof(g_err), "declined (nothing launched): %s", msg);
+    return 1;
+}
 extern "C" const char* bf_last_error(void) { return g_err; }
 extern "C" int bf_abi_version(void) { return 1; }
 

@@ -351,7 +351,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
         const bf16* cA = reinterpret_cast<const bf16*>(smem + (size_t)slot * PSLOT_BYTES);
         const bf16* cB = reinterpret_cast<const bf16*>(smem + (size_t)slot * PSLOT_BYTES + PA_BYTES);
         if constexpr (LAST) {
-            if (a.add) {
+            if (MODE != 2 && a.add) {
 #pragma unroll
                 for (int i = 0; i < 9; ++i) ad[i] = *reinterpret_cast<const uint4*>(a.add + (row0 + 16 * i) * a.ldx + col0);
             }
@@ -405,6 +405,13 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
     }
 
     constexpr bool chain = MODE == 2;      // its own instantiation: the code below costs the unchained kernel 13 spilled registers and 1.5 us per launch
+    if constexpr (chain) {                 // the chained form has no registers for the residual-gradient rows during the last K-step (they spilled, beside
+        // hand-counted vmcnt): it asks for them here, and they travel under the column-sum pass below instead of under the MFMAs
+        if (a.add) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) ad[i] = *reinterpret_cast<const uint4*>(a.add + (row0 + 16 * i) * a.ldx + col0);
+        }
+    }
     // ---- epilogue.  acc[i][j]: row 16 i + li, columns 16 j + 4 lg .. + 3.  After exchanging the odd lane rows of tile 0 with the even
     // lane rows of tile 1 a lane holds 8 consecutive columns at c8.
     float v[9][8];

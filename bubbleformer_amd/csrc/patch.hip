@@ -704,13 +704,15 @@ extern "C" int bf_debed_last_bwd_norm(int dtype, const float* dpred, const float
                                       const void* wc, void* dpm, const void* ymap, const float* mean, const float* rstd, const float* in_w,
                                       const float* in_b, void* dx, float* d_in_w, float* d_in_b, int frames, int Ci, int Co, int h, int w, int Np,
                                       float* ws, int64_t ws_floats, bf_stream_t stream) {
-    if (dtype != BF_DTYPE_BF16 || Np != 16 || Co > 4 || Ci % 32 != 0 || Ci > 128 || w % 16 != 0) return 1;
+    if (dtype != BF_DTYPE_BF16 || Np != 16 || Co > 4 || Ci % 32 != 0 || Ci > 128 || w % 16 != 0)
+        return bf_decline("bf_debed_last_bwd_norm covers bf16, Np = 16, Co <= 4, Ci a multiple of 32 up to 128, w a multiple of 16");
     static const bool off = bf_knob("BF_DEBED_LAST_NORM", 1) == 0;
-    if (off) return 1;
+    if (off) return bf_decline("bf_debed_last_bwd_norm: switched off (BF_DEBED_LAST_NORM=0)");
     BF_REQUIRE(wc && dpm && ymap && mean && rstd && in_w && in_b && dx && ws && (dpred || (pred && y && coef)) && frames > 0 && Co > 0 && h > 0 && w > 0,
                "bf_debed_last_bwd_norm: bad arguments");
     const int GF = h * w / 16, nsl = bf_cdiv(GF, DL_GPW);
-    if (ws_floats < (int64_t)2 * frames * Ci * (1 + nsl)) return 1;
+    if (ws_floats < (int64_t)2 * frames * Ci * (1 + nsl))
+        return bf_decline("bf_debed_last_bwd_norm: workspace smaller than 2 * frames * Ci * (1 + slices) floats (bf_in_ws_floats)");
     float* tot = ws;
     float* part = ws + (size_t)2 * frames * Ci;
     dim3 grid(bf_cdiv(GF, (NT / 64) * DL_GPW), frames);

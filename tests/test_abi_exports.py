@@ -28,6 +28,20 @@ def test_library_exports_every_declared_symbol():
     assert h.bf_abi_version() == 1
 
 
+def test_register_audit_no_spills_beside_counted_waits():
+    """tools/register_audit.py over the compiler's per-kernel resource remarks of the in-tree build: no kernel compiled from a source file
+    with hand-counted `s_waitcnt vmcnt` waits (ring / pair / stream / token-reduction GEMM families) may spill or use scratch."""
+    from bubbleformer_amd import _lib
+    from tools import register_audit
+    if not os.path.isdir(register_audit.BUILD) or not any(f.endswith(".remarks") for f in os.listdir(register_audit.BUILD)):
+        _lib.build()
+    rows, bad, warn, missing = register_audit.audit()
+    assert not missing, missing
+    assert len(rows) > 100 and sum(1 for k in rows if k["counted_waits"]) >= 30
+    assert {"gemm_pair_kernel<0>", "gemm_pair_kernel<1>", "gemm_pair_kernel<2>", "tokred_pp_kernel<3>"} <= {k["kernel"] for k in rows}
+    assert not bad, [(k["kernel"], k.get("vgpr_spill"), k.get("scratch")) for k in bad]
+
+
 def test_no_cpu_fallback():
     from bubbleformer_amd import _lib
     from bubbleformer_amd.models import get_model

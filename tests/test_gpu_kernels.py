@@ -825,6 +825,10 @@ def test_debed_last_stage_backward_with_the_norm_in_front(Ci, Co, h, w, fused_lo
                                       Fr, Ci, Co, h, w, 16, _p(ws), nws, _stream()) == 1
     assert lib.bf_debed_last_bwd_norm(1, *src, _p(wc), _p(dpm), _p(ymap), _p(mean), _p(rstd), _p(in_w), _p(in_b), _p(dx), None, None,
                                       Fr, Ci, Co, h, w, 16, _p(ws), 2 * Fr * Ci, _stream()) == 1
+    # ... and a refusal says why (a caller that treats code 1 as an error has a text to show)
+    assert b"workspace" in lib.bf_last_error()
+    with pytest.raises(L.BubbleformerHipError, match="declined"):
+        L.check(1, "debed_last_bwd_norm")
 
 
 @pytest.mark.parametrize("cin,h2,w2", [(4, 96, 96), (3, 40, 32), (4, 33, 16)])
