@@ -54,6 +54,11 @@ class SpatialParams(C.Structure):
     _fields_ = [(n, fp) for n in SPATIAL_FIELDS]
 
 
+class FrameNorm(C.Structure):
+    """bf_frame_norm: an InstanceNorm folded into a frame-pair GEMM launch (bf_gemm_fwd_frames)."""
+    _fields_ = [("w", fp), ("b", fp), ("g", fp), ("gdiv", i32), ("mean", fp), ("rstd", fp), ("sc", fp), ("sh", fp), ("resid", vp), ("out", vp)]
+
+
 class EmbedParams(C.Structure):
     _fields_ = [("conv_w", fp * BF_MAX_STAGES), ("in_w", fp * BF_MAX_STAGES), ("in_b", fp * BF_MAX_STAGES), ("film_ln_w", fp),
                 ("film_ln_b", fp), ("film_w", fp), ("film_b", fp)]
@@ -73,6 +78,9 @@ SIGNATURES = {
     "bf_side_defer": (None, [C.c_int]),
     "bf_prep_stages": (C.c_int, [C.POINTER(Dims), C.c_int, C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]),
     "bf_stage_prepared": (None, [C.c_int]),
+    "bf_stage_chain_next": (C.c_int, [C.POINTER(Dims), C.c_int, vp, vp]),
+    "bf_gemm_fwd_frames": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, fp, fp, fp, fp, C.c_int, vp, vp, C.c_int,
+                                     C.POINTER(FrameNorm), C.POINTER(FrameNorm), vp]),
     "bf_trunk_eval_weights_bytes": (i64, [C.POINTER(Dims), C.c_int, C.POINTER(C.c_int32)]),
     "bf_trunk_eval_prepare": (C.c_int, [C.POINTER(Dims), C.c_int, C.POINTER(C.c_int32), C.POINTER(vp), vp, vp]),
     "bf_trunk_eval_fwd": (C.c_int, [C.POINTER(Dims), C.c_int, C.POINTER(C.c_int32), C.POINTER(vp), vp, vp, vp, vp, vp]),

@@ -124,6 +124,17 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// The linear epilogue of the streaming and the frame-pair kernels, written once (explicit fma) so that they agree bit for bit:
+//   v = acc + bias;  scaled: v = (v * cs + ch) * rs;  with a residual: v = (v * cs + ch) * rs + aux  (one fma: rs = 1 makes it a plain add)
+__device__ __forceinline__ float epi_lin(float acc, float bias, float cs, float ch, float rs, bool scaled) {
+    const float v = acc + bias;
+    return scaled ? fmaf(v, cs, ch) * rs : v;
+}
+__device__ __forceinline__ float epi_lin_add(float acc, float bias, float cs, float ch, float rs, bool scaled, float aux) {
+    const float v = acc + bias;
+    return scaled ? fmaf(fmaf(v, cs, ch), rs, aux) : v + aux;
+}
+
 template <typename T>
 __device__ __forceinline__ void store4(T* c, const float (&u)[4], bool full, int nleft) {
     if (full) {

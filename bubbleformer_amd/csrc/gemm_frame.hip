@@ -15,6 +15,7 @@
 // <= 168 VGPRs and 80 KB of LDS so that two workgroups share a CU.  bf16 only (the fp32 parity mode keeps the separate kernels).
 #include "gemm_common.h"
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 int bf_gemm_pair_scaled(int M, int N, int K, const bf_operand* A, const bf_operand* B, const bf_epilogue* E, void* out2, const float* rowfac,
@@ -264,6 +265,7 @@ constexpr int PM = 288, PN = 128, PK = 64;
 constexpr int PA_BYTES = PM * PK * 2, PB_BYTES = PK * PN * 2, PSLOT_BYTES = PA_BYTES + PB_BYTES, PNSLOT = 3;      // 36,864 + 16,384 = 53,248; x 3 = 159,744
 constexpr int PA_PIECES = PA_BYTES / 1024, PB_PIECES = PB_BYTES / 1024;                                           // 36, 16
 
+struct FwdNorm { const float *w, *b, *g; int gdiv; float *mean, *rstd, *sc, *sh; const bf16* resid; bf16* out; };
 struct PairArgs {
     const bf16* A; long lda; const bf16* B; long ldb; int N, nk, nt;
     const bf16* x; const bf16* add; bf16* out; long ldx;
@@ -275,6 +277,11 @@ struct PairArgs {
     // cz, affine weight cw, optional post scale cg[(frame / cgdiv)][column]) whose backward is the next kernel in line -- it is applied here,
     // to the rows as stored: cdz = crstd cw cg (out - (s1 + xh s2) / S), partials {s1, s2} to cws (the layout of ws)
     const bf16* cz; bf16* cdz; const float *cmean, *crstd, *cw, *cg; int cgdiv; float* cws;
+    // MODE 3 (the forward twin): out = lin(product) [+ add], lin(v) = ((v + bias) * cs + ch) * fscale[frame / fdiv]; then up to two InstanceNorms
+    // of the rows as stored, over the whole frame columns a wave holds: n1 (optional: y = resid + g * IN(out), the MLP-branch norm behind fc2) and
+    // n2 (optional: the NEXT stage's opening norm of the last tensor written, xn = IN(y) -- statistics, sc / sh and the normalised copy)
+    const float *bias, *cs, *ch;
+    FwdNorm n1, n2;
 };
 
 // LDS-DMA with a wave-uniform 64-bit base in SGPRs and a per-lane 32-bit byte offset: one offset register serves every piece of a wave
@@ -284,8 +291,59 @@ __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsig
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
+// ---- InstanceNorm statistics of the frame columns a wave of the frame-pair kernel holds, summed in EXACTLY the order in_stats_kernel (norm.hip)
+// sums a 144-token frame -- so that a norm folded into a producer's epilogue leaves the bits a separate launch would.  There thread (rg, lc) of 32
+// row groups adds its rows rg, rg + 32, .. in order, the row groups meet by a butterfly over rg bits 0, 1, 2 inside a wave, and the four waves
+// (rg >> 3) are added in wave order.  Here lane li holds rows 16 i + li: the even i are row group li, the odd i row group li + 16.
+template <int CTRL> __device__ __forceinline__ float dpp_get(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float stats_tree(float pe, float po, bool lo) {
+    pe = pe + dpp_get<0xB1>(pe); po = po + dpp_get<0xB1>(po);        // rg bit 0 (lane xor 1)
+    pe = pe + dpp_get<0x4E>(pe); po = po + dpp_get<0x4E>(po);        // rg bit 1 (lane xor 2)
+    pe = pe + dpp_get<0x141>(pe); po = po + dpp_get<0x141>(po);      // rg bit 2 (the other quad of the half row)
+    const float eo = dpp_get<0x140>(pe), oo = dpp_get<0x140>(po);    // the other half row's totals
+    float t = 0.f;
+    t += lo ? pe : eo;                                               // wave 0: row groups 0..7
+    t += lo ? eo : pe;                                               // wave 1: 8..15
+    t += lo ? po : oo;                                               // wave 2: 16..23
+    t += lo ? oo : po;                                               // wave 3: 24..31
+    return t;
+}
+__device__ __forceinline__ float bfq(const uint4& v, int q) { return (float)__builtin_bit_cast(bf16x8, v)[q]; }
+// mean and 1 / sqrt(var + eps) of 8 columns over the frame's 144 rows (y[i]: row 16 i + li, packed bf16), two passes
+__device__ __forceinline__ void frame_stats(const uint4 (&y)[9], bool lo, float (&mu)[8], float (&r)[8]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        float pe = 0.f, po = 0.f;
+#pragma unroll
+        for (int i = 0; i < 9; i += 2) pe += bfq(y[i], q);
+#pragma unroll
+        for (int i = 1; i < 9; i += 2) po += bfq(y[i], q);
+        mu[q] = stats_tree(pe, po, lo) / 144.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        float pe = 0.f, po = 0.f;
+#pragma unroll
+        for (int i = 0; i < 9; i += 2) { const float d = bfq(y[i], q) - mu[q]; pe = fmaf(d, d, pe); }
+#pragma unroll
+        for (int i = 1; i < 9; i += 2) { const float d = bfq(y[i], q) - mu[q]; po = fmaf(d, d, po); }
+        r[q] = rsqrtf(stats_tree(pe, po, lo) / 144.f + BF_IN_EPS);
+    }
+}
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
 template <int MODE, int GRP>
 __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem, int lane, int w4, int m0, int n0, int fidx0) {
+    constexpr bool INBWD = MODE == 0 || MODE == 2;      // the InstanceNorm backward behind the product (x rows staged in LDS)
     constexpr int PG = GRP == 0 ? 7 : 6;            // DMA pieces per wave per K-step: A pieces {w, w+8, w+16, w+24} (+ 32 + w for waves 0-3), B pieces {w, w+8}
     const int wave = GRP * 4 + w4;
     const unsigned ring = lds_addr(smem);
@@ -324,7 +382,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
     // nk - 2, frame 1: the slot of step nk - 3 -- both were read by every wave before this wave's last load segment starts); no register
     // is written asynchronously.  Piece p = w4 + 4t (t < 9) = rows 4p .. 4p+3 of the frame, 256 bytes each.
     const unsigned voffX = (unsigned)(((long)(lane >> 4) * a.ldx + 8 * (lane & 15)) * 2);
-    const bf16* sX = MODE != 1 ? a.x + ((long)m0 + 144 * GRP + 4 * w4) * a.ldx + n0 : nullptr;
+    const bf16* sX = INBWD ? a.x + ((long)m0 + 144 * GRP + 4 * w4) * a.ldx + n0 : nullptr;
     const long pieceX = 16 * a.ldx;
     int xslot = 0;
 
@@ -342,7 +400,8 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
     // step body: nothing is carried through the loop in registers)
     uint4 ad[9];
     float mu[8], rs[8], ww[8];
-    const int fidx = (MODE != 1 && a.whole) ? fidx0 : fidx0 + GRP;
+    const int fidx = (INBWD && a.whole) ? fidx0 : fidx0 + GRP;
+    float rsf = 1.f;                                   // MODE 3: the frame's stochastic-depth factor
     const long pbase = MODE != 1 ? (long)fidx * a.N + col0 : 0;
     auto kstep = [&](auto last_tag, int s) __attribute__((always_inline)) {
         constexpr bool LAST = decltype(last_tag)::value;
@@ -355,7 +414,14 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
 #pragma unroll
                 for (int i = 0; i < 9; ++i) ad[i] = *reinterpret_cast<const uint4*>(a.add + (row0 + 16 * i) * a.ldx + col0);
             }
-            if constexpr (MODE != 1) {
+            if constexpr (MODE == 3) {                  // mu / rs / ww hold bias / column scale / column shift here
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { mu[q] = 0.f; rs[q] = 1.f; ww[q] = 0.f; }
+                if (a.bias) load8(a.bias + col0, mu);
+                if (a.cs) { load8(a.cs + col0, rs); load8(a.ch + col0, ww); }
+                if (a.fscale) rsf = a.fscale[fidx / a.fdiv];
+            }
+            if constexpr (INBWD) {
                 const float4 m0 = *reinterpret_cast<const float4*>(a.mean + pbase), m1 = *reinterpret_cast<const float4*>(a.mean + pbase + 4);
                 const float4 r0 = *reinterpret_cast<const float4*>(a.rstd + pbase), r1 = *reinterpret_cast<const float4*>(a.rstd + pbase + 4);
                 const float4 w0 = *reinterpret_cast<const float4*>(a.w + col0), w1 = *reinterpret_cast<const float4*>(a.w + col0 + 4);
@@ -376,7 +442,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
         if constexpr (!LAST) {
             if (s + 2 < nk) { issue(sl2); wait_vm<PG>(); }
             else wait_vm<0>();
-        } else if constexpr (MODE != 1) {           // last step: the x rows land under its MFMAs (waited for before the barrier that ends them)
+        } else if constexpr (INBWD) {               // last step: the x rows land under its MFMAs (waited for before the barrier that ends them)
             xslot = GRP == 0 ? sl2 : (slot == PNSLOT - 1 ? 0 : slot + 1);
             const unsigned dst = __builtin_amdgcn_readfirstlane(ring + (unsigned)xslot * (unsigned)PSLOT_BYTES + (unsigned)w4 * 1024u);
 #pragma unroll
@@ -393,14 +459,14 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (LAST && MODE != 1 && GRP == 1) wait_vm<0>();           // this wave's x pieces: visible to the workgroup after the barrier below
+        if (LAST && INBWD && GRP == 1) wait_vm<0>();           // this wave's x pieces: visible to the workgroup after the barrier below
         __builtin_amdgcn_s_barrier();
         slot = slot == PNSLOT - 1 ? 0 : slot + 1;
     };
     for (int s = 0; s + 1 < nk; ++s) kstep(std::false_type{}, s);
     kstep(std::true_type{}, nk - 1);
     if constexpr (GRP == 0) {
-        if constexpr (MODE != 1) wait_vm<0>();                      // ... and likewise for waves 0-3
+        if constexpr (INBWD) wait_vm<0>();                          // ... and likewise for waves 0-3
         __builtin_amdgcn_s_barrier();                               // pairs with the extra barrier of waves 4-7: everybody's x pieces have landed
     }
 
@@ -442,6 +508,74 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
 #pragma unroll
                 for (int q = 0; q < 8; ++q) o2[q] = (bf16)((float)o[q] * m);
                 *reinterpret_cast<bf16x8*>(a.out2 + (row0 + 16 * i) * a.ldx + col0) = o2;
+            }
+        }
+    } else if constexpr (MODE == 3) {
+        // ---- the forward twin.  Stage A: the linear epilogue of the streaming kernels (same expressions: same bits), rows rounded and stored
+        const bool lo = li < 8;
+        const bool late_resid = a.n1.w && a.n1.resid && !a.add;      // the second norm's residual rows travel under stage A and the statistics
+        if (late_resid) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) ad[i] = *reinterpret_cast<const uint4*>(a.n1.resid + (row0 + 16 * i) * a.ldx + col0);
+        }
+        uint4 y[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            bf16x8 o;
+            if (a.add) {
+                const bf16x8 d8 = __builtin_bit_cast(bf16x8, ad[i]);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o[q] = (bf16)epi_lin_add(v[i][q], mu[q], rs[q], ww[q], rsf, a.cs != nullptr, (float)d8[q]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o[q] = (bf16)epi_lin(v[i][q], mu[q], rs[q], ww[q], rsf, a.cs != nullptr);
+            }
+            *reinterpret_cast<bf16x8*>(a.out + (row0 + 16 * i) * a.ldx + col0) = o;
+            y[i] = __builtin_bit_cast(uint4, o);
+        }
+        // ---- stage B: y = resid + g * InstanceNorm(out) over the frame (statistics of the rows as stored)
+        if (a.n1.w) {
+            float m1[8], r1[8], aa[8], ss[8];
+            load8(a.n1.w + col0, aa); load8(a.n1.b + col0, ss);
+            float gg[8];
+            if (a.n1.g) load8(a.n1.g + (long)(fidx / a.n1.gdiv) * a.N + col0, gg);
+            if (a.n1.resid && !late_resid) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) ad[i] = *reinterpret_cast<const uint4*>(a.n1.resid + (row0 + 16 * i) * a.ldx + col0);
+            }
+            frame_stats(y, lo, m1, r1);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float s0 = r1[q] * aa[q];
+                float t0 = fmaf(-m1[q], s0, ss[q]);
+                if (a.n1.g) { s0 *= gg[q]; t0 = fmaf(t0, gg[q], 0.f); }
+                aa[q] = s0; ss[q] = t0;
+            }
+            if (li == 0) { store8(a.n1.mean + pbase, m1); store8(a.n1.rstd + pbase, r1); store8(a.n1.sc + pbase, aa); store8(a.n1.sh + pbase, ss); }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const bf16x8 d8 = __builtin_bit_cast(bf16x8, ad[i]);
+                bf16x8 o;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o[q] = (bf16)(fmaf(bfq(y[i], q), aa[q], ss[q]) + (a.n1.resid ? (float)d8[q] : 0.f));
+                *reinterpret_cast<bf16x8*>(a.n1.out + (row0 + 16 * i) * a.ldx + col0) = o;
+                y[i] = __builtin_bit_cast(uint4, o);
+            }
+        }
+        // ---- stage C: the next stage's opening norm of the rows just stored
+        if (a.n2.w) {
+            float m2[8], r2[8], aa[8], ss[8];
+            load8(a.n2.w + col0, aa); load8(a.n2.b + col0, ss);
+            frame_stats(y, lo, m2, r2);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { aa[q] = r2[q] * aa[q]; ss[q] = fmaf(-m2[q], aa[q], ss[q]); }
+            if (li == 0) { store8(a.n2.mean + pbase, m2); store8(a.n2.rstd + pbase, r2); store8(a.n2.sc + pbase, aa); store8(a.n2.sh + pbase, ss); }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                bf16x8 o;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o[q] = (bf16)(fmaf(bfq(y[i], q), aa[q], ss[q]) + 0.f);
+                *reinterpret_cast<bf16x8*>(a.n2.out + (row0 + 16 * i) * a.ldx + col0) = o;
             }
         }
     } else {
@@ -578,7 +712,7 @@ __global__ void __launch_bounds__(512) gemm_pair_kernel(PairArgs a) {
     const int seq = xcd_remap(blockIdx.x, gridDim.x);       // the column blocks of a frame pair run back to back on one XCD: its rows come through one L2
     const int fp = seq / a.nt;
     const int m0 = fp * PM, n0 = (seq - fp * a.nt) * PN;
-    const int f0 = (MODE != 1 && a.whole) ? fp : 2 * fp;
+    const int f0 = ((MODE == 0 || MODE == 2) && a.whole) ? fp : 2 * fp;
     if (wave < 4) pair_body<MODE, 0>(a, smem, lane, wave, m0, n0, f0);
     else pair_body<MODE, 1>(a, smem, lane, wave - 4, m0, n0, f0);
 }
@@ -686,4 +820,41 @@ int bf_gemm_pair_scaled(int M, int N, int K, const bf_operand* A, const bf_opera
     if (a.out2 && ((uintptr_t)out2 & 15)) return 1;
     BfProfScope prof(st, a.add ? "gemm_pair<add>" : "gemm_pair<plain>", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * N * (a.add ? 2 : 1)));
     return launch_pair<1>(a, M, st);
+}
+
+// The forward twin of bf_gemm_inbwd_frames: out[M][N] = lin(A[M][K] @ Bt[K][N]) [+ add] on the frame-pair kernel (two 144-token frames x 128
+// columns per workgroup), followed -- in the same launch, from the registers that hold whole frame columns -- by up to two InstanceNorms of the
+// rows as stored: n1 (y = resid + g * IN(out): the MLP-branch norm behind fc2, layers/attention.py:312-317) and n2 (the NEXT stage's opening
+// norm of the last tensor written: statistics, sc / sh and the normalised operand, layers/attention.py:77,208).  Statistics are summed in
+// in_stats_kernel's order and the products in the streaming kernels': the results equal bf_gemm + bf_in_stats (+ apply) bit for bit.
+// Returns 0 when done, 1 when the shape is not covered (bf16, S = 144, an even number of frames, N % 128 = K % 64 = 0, K >= 128), < 0 on error.
+extern "C" int bf_gemm_fwd_frames(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* Bt, int64_t ldb, const float* bias,
+                                  const float* colscale, const float* colshift, const float* fscale, int fdiv, const void* add, void* out, int S,
+                                  const bf_frame_norm* n1, const bf_frame_norm* n2, bf_stream_t stream) {
+    static const bool off = bf_knob("BF_FUSE_FWD_NORM", 1) == 0;
+    if (off || dtype != BF_DTYPE_BF16 || S != FM || !pair_shape_ok(M, N, K, lda, ldb) || K < 2 * PK) return 1;
+    BF_REQUIRE(A && Bt && out, "bf_gemm_fwd_frames: null pointer");
+    BF_REQUIRE(!colscale == !colshift, "bf_gemm_fwd_frames: column scale and shift come together");
+    if (((uintptr_t)A | (uintptr_t)Bt | (uintptr_t)add | (uintptr_t)out | (uintptr_t)bias | (uintptr_t)colscale | (uintptr_t)colshift) & 15) return 1;
+    PairArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = (const bf16*)A; a.lda = lda; a.B = (const bf16*)Bt; a.ldb = ldb; a.N = N; a.nk = K / PK; a.nt = N / PN;
+    a.add = (const bf16*)add; a.out = (bf16*)out; a.ldx = N;
+    a.fscale = fscale; a.fdiv = fdiv > 0 ? fdiv : 1; a.cgdiv = 1;
+    a.bias = bias; a.cs = colscale; a.ch = colshift;
+    auto take = [&](const bf_frame_norm* n, FwdNorm& o, bool first) -> int {
+        if (!n) return 0;
+        BF_REQUIRE(n->w && n->b && n->mean && n->rstd && n->sc && n->sh && n->out, "bf_gemm_fwd_frames: incomplete norm record");
+        if (((uintptr_t)n->w | (uintptr_t)n->b | (uintptr_t)n->g | (uintptr_t)n->mean | (uintptr_t)n->rstd | (uintptr_t)n->sc | (uintptr_t)n->sh |
+             (uintptr_t)n->resid | (uintptr_t)n->out) & 15) return 1;
+        if (!first && (n->g || n->resid)) return 1;      // the chained norm is a plain one
+        o.w = n->w; o.b = n->b; o.g = n->g; o.gdiv = n->gdiv > 0 ? n->gdiv : 1; o.mean = n->mean; o.rstd = n->rstd; o.sc = n->sc; o.sh = n->sh;
+        o.resid = (const bf16*)n->resid; o.out = (bf16*)n->out;
+        return 0;
+    };
+    if (int rc = take(n1, a.n1, true)) return rc;
+    if (int rc = take(n2, a.n2, false)) return rc;
+    BfProfScope prof((hipStream_t)stream, n1 ? (n2 ? "gemm_pair<fwd,norm,chain>" : "gemm_pair<fwd,norm>") : (n2 ? "gemm_pair<fwd,chain>" : "gemm_pair<fwd>"),
+                     2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * N * (1 + (add ? 1 : 0) + (n1 ? (n1->resid ? 2 : 1) : 0) + (n2 ? 1 : 0))));
+    return launch_pair<3>(a, M, (hipStream_t)stream);
 }

@@ -247,15 +247,26 @@ __global__ void __launch_bounds__(512) stream_gemm_kernel(StreamArgs a) {
                     const u32x2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][2 * pp][r]), __float_as_uint(acc[i][2 * pp + 1][r]), false, false);
                     v[r] = __uint_as_float(sw[0]); v[4 + r] = __uint_as_float(sw[1]);
                 }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    v[q] += e_bias[pp][q];
-                    if constexpr (CS) v[q] = fmaf(v[q], e_cs[pp][q], e_ch[pp][q]) * (has_rs ? rsr[i] : 1.f);
-                }
-                if constexpr (AUX != BF_AUX_NONE) {
+                if constexpr (AUX == BF_AUX_ADD) {      // (gemm_common.h: epi_lin* -- the frame-pair forward kernel applies the same expressions)
                     const bf16x8 ax = __builtin_bit_cast(bf16x8, auxr[i][pp]);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = AUX == BF_AUX_ADD ? v[q] + (float)ax[q] : v[q] * dgelu_fast((float)ax[q]);
+                    for (int q = 0; q < 8; ++q) {
+                        float cs_ = 1.f, ch_ = 0.f;
+                        if constexpr (CS) { cs_ = e_cs[pp][q]; ch_ = e_ch[pp][q]; }
+                        v[q] = epi_lin_add(v[q], e_bias[pp][q], cs_, ch_, has_rs ? rsr[i] : 1.f, CS, (float)ax[q]);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        float cs_ = 1.f, ch_ = 0.f;
+                        if constexpr (CS) { cs_ = e_cs[pp][q]; ch_ = e_ch[pp][q]; }
+                        v[q] = epi_lin(v[q], e_bias[pp][q], cs_, ch_, has_rs ? rsr[i] : 1.f, CS);
+                    }
+                    if constexpr (AUX == BF_AUX_DGELU) {
+                        const bf16x8 ax = __builtin_bit_cast(bf16x8, auxr[i][pp]);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = v[q] * dgelu_fast((float)ax[q]);
+                    }
                 }
                 bf16x8 o;
 #pragma unroll
@@ -506,15 +517,26 @@ __global__ void __launch_bounds__(512) stream_pp_kernel(StreamArgs a) {
                     const u32x2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][2 * pp][r]), __float_as_uint(acc[i][2 * pp + 1][r]), false, false);
                     v[r] = __uint_as_float(sw[0]); v[4 + r] = __uint_as_float(sw[1]);
                 }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    v[q] += e_bias[pp][q];
-                    if constexpr (CS) v[q] = fmaf(v[q], e_cs[pp][q], e_ch[pp][q]) * (has_rs ? rsr[i] : 1.f);
-                }
-                if constexpr (AUX != BF_AUX_NONE) {
+                if constexpr (AUX == BF_AUX_ADD) {      // (gemm_common.h: epi_lin* -- the frame-pair forward kernel applies the same expressions)
                     const bf16x8 ax = __builtin_bit_cast(bf16x8, auxr[i][pp]);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = AUX == BF_AUX_ADD ? v[q] + (float)ax[q] : v[q] * dgelu_fast((float)ax[q]);
+                    for (int q = 0; q < 8; ++q) {
+                        float cs_ = 1.f, ch_ = 0.f;
+                        if constexpr (CS) { cs_ = e_cs[pp][q]; ch_ = e_ch[pp][q]; }
+                        v[q] = epi_lin_add(v[q], e_bias[pp][q], cs_, ch_, has_rs ? rsr[i] : 1.f, CS, (float)ax[q]);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        float cs_ = 1.f, ch_ = 0.f;
+                        if constexpr (CS) { cs_ = e_cs[pp][q]; ch_ = e_ch[pp][q]; }
+                        v[q] = epi_lin(v[q], e_bias[pp][q], cs_, ch_, has_rs ? rsr[i] : 1.f, CS);
+                    }
+                    if constexpr (AUX == BF_AUX_DGELU) {
+                        const bf16x8 ax = __builtin_bit_cast(bf16x8, auxr[i][pp]);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = v[q] * dgelu_fast((float)ax[q]);
+                    }
                 }
                 bf16x8 o;
 #pragma unroll

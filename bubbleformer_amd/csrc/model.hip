@@ -398,6 +398,7 @@ int wviews(const D& d, int cnt, const float* const* src, void* const* dst, const
 struct TemporalSaved {
     float *mean1, *rstd1, *sc1, *sh1, *mean2, *rstd2, *sc2, *sh2, *alpha, *beta, *mc;
     void *qkv, *o, *xn, *on, *win_c, *wout_c, *wout_s;      // wout_s = diag(alpha) W_out (data-gradient operand); xn / on: InstanceNorm'd block input / attention output (GEMM operands, fwd and dW)
+    void* wout_t;                                           // W_out^T [in][out]: the frame-pair forward kernel's operand (bf_gemm_fwd_frames)
     size_t bytes;
     TemporalSaved(const D& d, void* base) {
         Arena a(base);
@@ -412,6 +413,7 @@ struct TemporalSaved {
         win_c = a.take((size_t)3 * d.E * d.E * d.es);
         wout_c = a.take((size_t)d.E * d.E * d.es);
         wout_s = a.take((size_t)d.E * d.E * d.es);
+        wout_t = a.take((size_t)d.E * d.E * d.es);
         bytes = a.off;
     }
 };
@@ -682,16 +684,28 @@ extern "C" int bf_stage_chain_tail(const bf_spatial_params* prev_p, const void* 
     g_next_tail.p = prev_p; g_next_tail.saved = prev_saved; g_next_tail.drop = has_drop_mlp != 0;
     return 0;
 }
-extern "C" int bf_stage_chain_head(const bf_dims* dims, const bf_temporal_params* next_p, void* next_saved) {
+extern "C" int bf_stage_chain_next(const bf_dims* dims, int next_kind, const void* next_params, void* next_saved) {
     g_next_head.armed = false;
-    if (!dims || !next_p || !next_saved) return 0;          // disarm
+    if (!dims || !next_params || !next_saved) return 0;     // disarm
+    BF_REQUIRE(next_kind == 0 || next_kind == 1, "bf_stage_chain_next: kind must be 0 (temporal) or 1 (spatial)");
     D d; TRY(get_dims(dims, &d));
-    TemporalSaved sv(d, next_saved);
-    g_next_head.w = next_p->norm1_w; g_next_head.b = next_p->norm1_b;
-    g_next_head.mean = sv.mean1; g_next_head.rstd = sv.rstd1; g_next_head.sc = sv.sc1; g_next_head.sh = sv.sh1; g_next_head.xn = sv.xn;
+    if (next_kind == 0) {
+        const bf_temporal_params* np = (const bf_temporal_params*)next_params;
+        TemporalSaved sv(d, next_saved);
+        g_next_head.w = np->norm1_w; g_next_head.b = np->norm1_b;
+        g_next_head.mean = sv.mean1; g_next_head.rstd = sv.rstd1; g_next_head.sc = sv.sc1; g_next_head.sh = sv.sh1; g_next_head.xn = sv.xn;
+    } else {
+        const bf_spatial_params* np = (const bf_spatial_params*)next_params;
+        SpatialSaved sv(d, next_saved);
+        g_next_head.w = np->norm1_w; g_next_head.b = np->norm1_b;
+        g_next_head.mean = sv.mean1; g_next_head.rstd = sv.rstd1; g_next_head.sc = sv.sc1; g_next_head.sh = sv.sh1; g_next_head.xn = sv.xn;
+    }
     g_next_head.saved = next_saved;
     g_next_head.armed = true;
     return 0;
+}
+extern "C" int bf_stage_chain_head(const bf_dims* dims, const bf_temporal_params* next_p, void* next_saved) {
+    return bf_stage_chain_next(dims, 0, next_p, next_saved);
 }
 
 extern "C" int bf_temporal_fwd(const bf_dims* dims, const bf_temporal_params* p, const void* x, void* out, void* saved, void* scratch,
@@ -708,8 +722,9 @@ extern "C" int bf_temporal_fwd(const bf_dims* dims, const bf_temporal_params* p,
         void* dst[2] = {sv.win_c, sv.wout_c};
         const long n[2] = {3L * d.E * d.E, (long)d.E * d.E};
         const void* out[4];
+        const bool b16 = d.dtype == BF_DTYPE_BF16;
         const PrepArgs prep{p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr, sv.alpha, sv.beta, sv.mc, d.E, sv.wout_s, d.dtype,
-                            nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0};
+                            nullptr, nullptr, nullptr, 0, b16 ? p->output_head_w : nullptr, b16 ? sv.wout_t : nullptr, d.E, d.E};
         const bool ready = g_stage_prepared && d.dtype == BF_DTYPE_BF16;
         g_stage_prepared = false;
         if (ready) { out[0] = sv.win_c; out[1] = sv.wout_c; }
@@ -726,6 +741,16 @@ extern "C" int bf_temporal_fwd(const bf_dims* dims, const bf_temporal_params* p,
                     p->knorm_w, p->knorm_b, p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor : nullptr, 1.f, 0, st));
     TRY(bf_in_stats_apply(d.dtype, sv.o, (int)d.F, (int)d.S, d.E, p->norm2_w, p->norm2_b, nullptr, 1, nullptr, sv.mean2, sv.rstd2, sv.sc2, sv.sh2, sc.in_ws,
                           nullptr, sv.on, st));
+    if (g_next_head.armed) {      // the stage behind opens with InstanceNorm(out): it rides in the out-projection's launch (bf_stage_chain_next)
+        const NextHead h = g_next_head;
+        g_next_head.armed = false;
+        g_head_done_for = nullptr;
+        const bf_frame_norm n2{h.w, h.b, nullptr, 1, h.mean, h.rstd, h.sc, h.sh, nullptr, h.xn};
+        const int rc = bf_gemm_fwd_frames(d.dtype, (int)d.N, d.E, d.E, sv.on, d.E, sv.wout_t, d.E, nullptr, sv.alpha, sv.beta, drop, d.T, x, out, (int)d.S,
+                                          nullptr, &n2, s);
+        if (rc < 0) return rc;
+        if (rc == 0) { g_head_done_for = h.saved; return 0; }
+    }
     TRY(outproj_gemm(d, sv.on, wout_c, sv.alpha, sv.beta, x, out, drop, (long)d.T * d.S, st));   // mask per batch element
     return 0;
 }
@@ -820,7 +845,7 @@ extern "C" int bf_prep_stages(const bf_dims* dims, int n, const int32_t* kinds, 
                 for (int q = 0; q < 4; ++q) { j.src[q] = src[q < 2 ? q : 0]; j.dst[q] = (bf16*)dst[q < 2 ? q : 0]; j.n[q] = q < 2 ? cn[q] : 0; }
                 b.cnt[i] = 2;
                 b.a[i] = PrepArgs{p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr, sv.alpha, sv.beta, sv.mc, d.E, sv.wout_s, d.dtype,
-                                  nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0};
+                                  nullptr, nullptr, nullptr, 0, p->output_head_w, sv.wout_t, d.E, d.E};
             } else {
                 const bf_spatial_params* p = (const bf_spatial_params*)params[i0 + i];
                 SpatialSaved sv(d, saved[i0 + i]);
@@ -848,7 +873,8 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
                               const float* drop_att, const float* drop_mlp, bf_stream_t s) {
     D d; TRY(get_dims(dims, &d));
     BF_REQUIRE(p && x && out && saved && scratch, "bf_spatial_fwd: null pointer");
-    g_head_done_for = nullptr;         // (a chained head is consumed by the temporal stage called right after the spatial stage that made it)
+    const bool head_done = g_head_done_for == saved;      // the temporal stage in front left norm1's statistics and xn behind (bf_stage_chain_next)
+    g_head_done_for = nullptr;         // (a chained head is consumed by the stage called right after the stage that made it)
     hipStream_t st = (hipStream_t)s;
     TRY(side_join_pending(st));
     SpatialSaved sv(d, saved);
@@ -870,8 +896,9 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
         else TRY(wviews(d, 4, src, dst, n, out, st, &prep));
         win_c = out[0]; wout_c = out[1]; w1_c = out[2]; w2_c = out[3];
     }
-    TRY(bf_in_stats_apply(d.dtype, x, (int)d.F, (int)d.S, d.E, p->norm1_w, p->norm1_b, nullptr, 1, nullptr, sv.mean1, sv.rstd1, sv.sc1, sv.sh1, sc.in_ws,
-                          nullptr, sv.xn, st));
+    if (!head_done)
+        TRY(bf_in_stats_apply(d.dtype, x, (int)d.F, (int)d.S, d.E, p->norm1_w, p->norm1_b, nullptr, 1, nullptr, sv.mean1, sv.rstd1, sv.sc1, sv.sh1, sc.in_ws,
+                              nullptr, sv.xn, st));
     TRY(qkv_gemm(d, sv.xn, win_c, p->input_head_b, sv.qkv, st));
     // along w (one sequence per (frame, row): contiguous tokens), then along h (per (frame, column): stride w), averaged
     {   // ... and norm2 in the same launch where the one-launch form applies
@@ -896,13 +923,6 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
         e.gelu_out = sv.hid;
         TRY(bf_gemm(d.dtype, (int)d.N, 4 * d.E, d.E, &A, &Bo, &e, 1, st));
     }
-    {   // z = hid @ W2^T + b2
-        bf_operand A = op_plain(sv.hid, 4L * d.E, BF_LAY_KC);
-        bf_operand Bo = op_plain(w2_c, 4L * d.E, BF_LAY_KC);
-        bf_epilogue e = epi_store(sv.z, d.E);
-        e.bias = p->fc2_b;
-        TRY(bf_gemm(d.dtype, (int)d.N, d.E, 4 * d.E, &A, &Bo, &e, 1, st));
-    }
     // out = x1 + drop_mlp[f] * gamma_mlp * InstanceNorm(z): the per-(frame, channel) factor rides in the InstanceNorm affine
     const float* g3 = p->gamma_mlp;
     int g3div = (int)d.F;
@@ -912,6 +932,26 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
             BF_CHECK_LAUNCH();
         }
         g3 = sv.gtab; g3div = 1;
+    }
+    if (d.dtype == BF_DTYPE_BF16) {      // z = hid @ W2^T + b2, the MLP-branch norm + residual and (armed) the next stage's opening norm in ONE launch
+        const bf_frame_norm n1{p->mlp_norm_w, p->mlp_norm_b, g3, g3div, sv.mean3, sv.rstd3, sv.sc3, sv.sh3, sv.x1, out};
+        const NextHead h = g_next_head;
+        const bf_frame_norm n2{h.w, h.b, nullptr, 1, h.mean, h.rstd, h.sc, h.sh, nullptr, h.xn};
+        const int rc = bf_gemm_fwd_frames(d.dtype, (int)d.N, d.E, 4 * d.E, sv.hid, 4L * d.E, sv.w2t_c, d.E, p->fc2_b, nullptr, nullptr, nullptr, 1, nullptr, sv.z,
+                                          (int)d.S, &n1, h.armed ? &n2 : nullptr, s);
+        if (rc < 0) return rc;
+        if (rc == 0) {
+            g_next_head.armed = false;
+            g_head_done_for = h.armed ? h.saved : nullptr;
+            return 0;
+        }
+    }
+    {   // z = hid @ W2^T + b2
+        bf_operand A = op_plain(sv.hid, 4L * d.E, BF_LAY_KC);
+        bf_operand Bo = op_plain(w2_c, 4L * d.E, BF_LAY_KC);
+        bf_epilogue e = epi_store(sv.z, d.E);
+        e.bias = p->fc2_b;
+        TRY(bf_gemm(d.dtype, (int)d.N, d.E, 4 * d.E, &A, &Bo, &e, 1, st));
     }
     if (g_next_head.armed) {
         const NextHead h = g_next_head;

@@ -30,6 +30,8 @@ class SpaceTimeBlock(nn.Module):
     def forward_tokens(self, tok: torch.Tensor, drops=None, chain_to=None) -> torch.Tensor:
         """drops: optional (temporal [B], axial attention [B*T], MLP [B*T]) stochastic-depth factors drawn by the caller.
         chain_to: the temporal block that consumes this block's output (its opening InstanceNorm can ride in this block's last launch)."""
+        if tok.is_cuda:
+            ops.chain_next(self.spatial.stage_params(), "spatial")      # the axial block's opening norm rides in the temporal out-projection
         tok = self.temporal.forward_tokens(tok) if drops is None else self.temporal.forward_tokens(tok, drops[0])
         if chain_to is not None and tok.is_cuda:
             ops.chain_next(chain_to.stage_params())

@@ -201,11 +201,13 @@ _CHAIN = {"next": None}
 _LAST_SPATIAL = {"v": None}
 
 
-def chain_next(params) -> None:
-    """Announce the temporal stage that will consume the output of the spatial stage called next (its parameters in
-    ``_lib.TEMPORAL_FIELDS`` order): when both were prepared by `prepare_stages` for the same shape, that stage's opening InstanceNorm
-    is computed by the spatial stage's last launch (bf_stage_chain_head; bit-identical results, one launch and one read less)."""
-    _CHAIN["next"] = _stage_key("temporal", [_f32c(p) for p in params]) if _PREPARED and os.environ.get("BF_STAGE_CHAIN", "1") != "0" else None
+def chain_next(params, kind: str = "temporal") -> None:
+    """Announce the stage (`kind`, its parameters in ``_lib.TEMPORAL_FIELDS`` / ``SPATIAL_FIELDS`` order) that will consume the output of the
+    stage called next: when both were prepared by `prepare_stages` for the same shape, that stage's opening InstanceNorm is computed by the
+    last launch of the stage in front of it (bf_stage_chain_next: the temporal stage's out-projection, the spatial stage's fc2 + MLP-branch
+    norm; bit-identical results, one launch and one read of the activation less)."""
+    on = _PREPARED and os.environ.get("BF_STAGE_CHAIN", "1") != "0"
+    _CHAIN["next"] = _stage_key(kind, [_f32c(p) for p in params]) if on else None
 
 
 def _stage_key(kind: str, params) -> tuple:
@@ -421,10 +423,11 @@ class _BlockFn(torch.autograd.Function):
                                 (drop_b is not None and pre[2].data_ptr() != drop_b.data_ptr())):
             pre = None                                  # prepared for another shape or another stochastic-depth table: prepare here
         nxt, _CHAIN["next"] = _CHAIN["next"], None
-        if kind == "spatial" and nxt is not None:       # the next temporal stage's opening InstanceNorm rides in this stage's last launch
+        if nxt is not None and nxt[0] != kind:          # the next stage's opening InstanceNorm rides in this stage's last launch
             pn = _PREPARED.get(nxt)
-            if pn is not None and pn[0] == _dims_key(d):
-                L.check(lib.bf_stage_chain_head(C.byref(d), C.byref(pn[3]), _p(pn[1])), "bf_stage_chain_head")
+            if pn is not None and pn[0][:7] == _dims_key(d)[:7]:      # same dtype and token geometry (the stages' own switches may differ)
+                dn = L.Dims(*pn[0])
+                L.check(lib.bf_stage_chain_next(C.byref(dn), 0 if nxt[0] == "temporal" else 1, C.addressof(pn[3]), _p(pn[1])), "bf_stage_chain_next")
         if kind == "temporal":
             st = pre[3] if pre else L.TemporalParams(*[_p(p) for p in params])
             saved = pre[1] if pre else _saved(lib.bf_temporal_saved_bytes(C.byref(d)), x.device, "bf_temporal_saved_bytes")

@@ -116,6 +116,24 @@ int bf_gemm_inbwd_frames_chain(int dtype, int M, int N, int K, const void* A, in
                                const float* fscale, int fdiv, const void* cz, void* cdz, const float* cmean, const float* crstd,
                                const float* cw, const float* cg, int cgdiv, float* cws, bf_stream_t stream);
 
+/* The forward twin: out[M][N] = lin(A[M][K] @ Bt[K][N]) [+ add], lin(v) = ((v + bias) * colscale + colshift) * fscale[frame / fdiv], frames of
+ * S = 144 consecutive rows, followed IN THE SAME LAUNCH by up to two InstanceNorm2d over the frame (layers/attention.py:77,208 norm1;
+ * 312-317 the MLP-branch norm + layer scale + residual): n1 (optional): y = resid + g * IN(out), written to n1->out; n2 (optional): the NEXT
+ * stage's opening norm of the last tensor written, n2->out = IN(.) * w + b (no g, no resid).  Each leaves mean / rstd / sc / sh [frames][N]
+ * as bf_in_stats does.  Bt is the weight TRANSPOSED ([in][out], N contiguous).  Replaces bf_gemm + bf_in_stats (+ bf_affine_apply) -- one
+ * read of the activation and one launch per norm less -- with identical bits.  Returns 0 when done, 1 when the shape is not covered
+ * (bf16, S = 144, M % 288 = N % 128 = K % 64 = 0, K >= 128, 16-byte aligned operands), < 0 on error. */
+typedef struct bf_frame_norm {
+    const float *w, *b;             /* affine [N] */
+    const float* g; int32_t gdiv;   /* optional post scale [frames / gdiv][N] */
+    float *mean, *rstd, *sc, *sh;   /* [frames][N] */
+    const void* resid;              /* optional [M][N] */
+    void* out;                      /* [M][N] */
+} bf_frame_norm;
+int bf_gemm_fwd_frames(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* Bt, int64_t ldb, const float* bias,
+                       const float* colscale, const float* colshift, const float* fscale, int fdiv, const void* add, void* out, int S,
+                       const bf_frame_norm* n1, const bf_frame_norm* n2, bf_stream_t stream);
+
 /* Token-reduction GEMM (weight gradient of a 1x1 conv / Linear: autograd of layers/attention.py:78,121,210,299, linear_layers.py:18-25):
  *   out[Nout][Kin] = (accumulate ? out : 0) + sum_tok dy[tok][Nout] * x[tok][Kin],  colsum[Nout] likewise + sum_tok dy[tok][:]  (optional)
  * dy [M][ldy], x [M][ldx] token-major bf16.  Few long token slices, one 128 x 128 tile x slice per workgroup, partial tiles to fp32
@@ -379,6 +397,11 @@ int bf_trunk_eval_fwd(const bf_dims* dims, int n, const int32_t* kinds, const vo
  * NULL arguments disarm.  A spatial stage that cannot chain (fp32 frames longer than the register cache, ...) leaves the norm to the
  * temporal stage as usual. */
 int bf_stage_chain_head(const bf_dims* dims, const bf_temporal_params* next_p, void* next_saved);
+/* ... in either direction: next_kind 0 = a temporal stage follows (next_params: bf_temporal_params*), 1 = a spatial stage follows
+ * (bf_spatial_params*).  The stage forward called next folds that stage's opening InstanceNorm into its last GEMM's launch
+ * (bf_gemm_fwd_frames: the temporal stage's out-projection, the spatial stage's fc2 + MLP-branch norm) where the frame-pair kernel covers
+ * the shape, or into its last InstanceNorm launch; the stage on next_saved then skips its own norm1.  Bit-identical to the unchained calls. */
+int bf_stage_chain_next(const bf_dims* dims, int next_kind, const void* next_params, void* next_saved);
 /* The mirror image in the backward: the temporal stage's last kernel produces the output gradient of the spatial stage in front of it (prev_p,
  * prev_saved; has_drop_mlp: its MLP branch carried stochastic-depth factors), whose backward opens with its MLP-branch InstanceNorm -- armed
  * here, that norm's backward is applied by the temporal backward called next (bf_gemm_inbwd_frames_chain) and bf_spatial_bwd on prev_saved

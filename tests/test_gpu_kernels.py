@@ -497,6 +497,80 @@ def test_gemm_inbwd_frame_pairs_with_a_chained_second_norm(K, Fr, Kd, N, with_g)
                                           None, 1, _p(z), _p(dz), _p(mean3), _p(rstd3), _p(w3), _p(gt), 1, _p(cws), _stream()) == 1
 
 
+@pytest.mark.parametrize("Fr,Kd,N,kind", [(16, 384, 384, "outproj"), (16, 1536, 384, "fc2"), (16, 1536, 384, "fc2_chain"), (128, 384, 384, "outproj"),
+                                          (128, 1536, 384, "fc2_chain"), (16, 128, 256, "fc2_chain")])
+def test_gemm_fwd_frames_with_folded_norms_changes_no_bit(K, Fr, Kd, N, kind):
+    """bf_gemm_fwd_frames (the forward twin of the frame-pair kernel): projection + linear epilogue, then the InstanceNorm(s) of the rows as
+    stored folded into the same launch -- `outproj`: out = x + (alpha * (on @ W^T) + beta) * drop[f] and the NEXT stage's norm1 of it
+    (layers/attention.py:121-123 + :208); `fc2`: z = hid @ W2^T + b2, out = x1 + g * IN(z) (:312-317), `fc2_chain`: plus the next stage's norm1
+    of out (:77).  Against bf_gemm (streaming kernels) + bf_in_stats + bf_affine_apply on the same operands: every tensor bit for bit."""
+    from bubbleformer_amd import _lib as L
+    from bubbleformer_amd.ops import _p, _stream
+    import ctypes as C
+    lib = L.lib()
+    S, M = 144, Fr * 144
+    g = torch.Generator(device="cuda").manual_seed(71)
+    A = (torch.randn(M, Kd, device="cuda", generator=g) * 0.7).bfloat16()
+    W = (torch.randn(N, Kd, device="cuda", generator=g) / Kd ** 0.5).bfloat16()          # [out][in], as nn.Linear / Conv2d 1x1 store it
+    Wt = W.t().contiguous()
+    resid = (torch.randn(M, N, device="cuda", generator=g) * 1.3 + 0.2).bfloat16()
+    bias = torch.randn(N, device="cuda", generator=g)
+    alpha, beta = torch.randn(N, device="cuda", generator=g), torch.randn(N, device="cuda", generator=g)
+    drop = (torch.rand(Fr // 4, device="cuda", generator=g) > 0.3).float() / 0.7          # one factor per group of 4 frames
+    w1, b1 = torch.randn(N, device="cuda", generator=g), torch.randn(N, device="cuda", generator=g)
+    w2, b2 = torch.randn(N, device="cuda", generator=g), torch.randn(N, device="cuda", generator=g)
+    gt = 0.5 + torch.rand(Fr, N, device="cuda", generator=g)                             # per-(frame, channel) post scale (layer scale x drop)
+
+    def stats_apply(x, w, b, gpost=None, res=None):
+        mean, rstd, sc, sh = K.in_stats(x.view(Fr, S, N), Fr, S, N, w, b, g=gpost, gdiv=1)
+        out = torch.empty_like(x)
+        L.check(lib.bf_affine_apply(1, _p(x), _p(res), _p(sc), _p(sh), _p(out), M, S, N, _stream()), "bf_affine_apply")
+        return out, (mean, rstd, sc, sh)
+
+    def new_stats():
+        return [torch.full((Fr, N), float("nan"), device="cuda") for _ in range(4)]
+
+    def norm_rec(w, b, gpost, st, res, out):
+        return L.FrameNorm(_p(w), _p(b), _p(gpost), 1, _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), _p(res), _p(out))
+
+    nan = lambda: torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    if kind == "outproj":
+        ref = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        K.gemm(torch.bfloat16, M, N, Kd, K.operand(A, Kd), K.operand(W, Kd),
+               K.epilogue(ref, N, colscale=alpha, colshift=beta, aux_mode=L.BF_AUX_ADD, aux=resid, ld_aux=N, rowscale=drop, rows_per_group=4 * S))
+        ref_xn, ref_st = stats_apply(ref, w2, b2)
+        out, xn, st2 = nan(), nan(), new_stats()
+        n2 = norm_rec(w2, b2, None, st2, None, xn)
+        rc = lib.bf_gemm_fwd_frames(1, M, N, Kd, _p(A), Kd, _p(Wt), N, None, _p(alpha), _p(beta), _p(drop), 4, _p(resid), _p(out), S, None, C.byref(n2), _stream())
+        L.check(rc, "bf_gemm_fwd_frames")
+        assert torch.equal(out, ref) and torch.equal(xn, ref_xn)
+        assert all(torch.equal(a, b) for a, b in zip(st2, ref_st))
+    else:
+        z_ref = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        K.gemm(torch.bfloat16, M, N, Kd, K.operand(A, Kd), K.operand(W, Kd), K.epilogue(z_ref, N, bias=bias))
+        out_ref, st1_ref = stats_apply(z_ref, w1, b1, gpost=gt, res=resid)
+        z, out, xn, st1, st2 = nan(), nan(), nan(), new_stats(), new_stats()
+        n1 = norm_rec(w1, b1, gt, st1, resid, out)
+        n2 = norm_rec(w2, b2, None, st2, None, xn)
+        chain = kind == "fc2_chain"
+        rc = lib.bf_gemm_fwd_frames(1, M, N, Kd, _p(A), Kd, _p(Wt), N, _p(bias), None, None, None, 1, None, _p(z), S, C.byref(n1), C.byref(n2) if chain else None,
+                                    _stream())
+        L.check(rc, "bf_gemm_fwd_frames")
+        assert torch.equal(z, z_ref) and torch.equal(out, out_ref)
+        assert all(torch.equal(a, b) for a, b in zip(st1, st1_ref))
+        if chain:
+            xn_ref, st2_ref = stats_apply(out_ref, w2, b2)
+            assert torch.equal(xn, xn_ref) and all(torch.equal(a, b) for a, b in zip(st2, st2_ref))
+    # an fp64 check of the statistics themselves (the references above share the kernels' arithmetic)
+    last = (out if kind != "outproj" else out).double().view(Fr, S, N)
+    if kind != "fc2":
+        assert _rel(st2[0], last.mean(1)) < 1e-5 and _rel(st2[1], (last.var(1, unbiased=False) + 1e-5).rsqrt()) < 1e-5
+    # declined: fp32, an odd number of frames, 288-token frames
+    assert lib.bf_gemm_fwd_frames(0, M, N, Kd, _p(A), Kd, _p(Wt), N, None, None, None, None, 1, None, _p(nan()), S, None, None, _stream()) == 1
+    assert lib.bf_gemm_fwd_frames(1, M - 144, N, Kd, _p(A), Kd, _p(Wt), N, None, None, None, None, 1, None, _p(nan()), S, None, None, _stream()) == 1
+    assert lib.bf_gemm_fwd_frames(1, M, N, Kd, _p(A), Kd, _p(Wt), N, None, None, None, None, 1, None, _p(nan()), 288, None, None, _stream()) == 1
+
+
 def _attn_call(L_lib, qkv, dout, geo, heads, d, prm, generic):
     """Run attention fwd + bwd through the C ABI; returns (out, dqkv, param grads)."""
     import ctypes as C
