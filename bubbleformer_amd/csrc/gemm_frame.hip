@@ -344,6 +344,7 @@ __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
 template <int MODE, int GRP>
 __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem, int lane, int w4, int m0, int n0, int fidx0) {
     constexpr bool INBWD = MODE == 0 || MODE == 2;      // the InstanceNorm backward behind the product (x rows staged in LDS)
+    constexpr bool FWD = MODE == 3 || MODE == 4;        // the forward twin (4: with the MLP-branch norm n1 -- its own instantiation, so that profiles tell the two apart)
     constexpr int PG = GRP == 0 ? 7 : 6;            // DMA pieces per wave per K-step: A pieces {w, w+8, w+16, w+24} (+ 32 + w for waves 0-3), B pieces {w, w+8}
     const int wave = GRP * 4 + w4;
     const unsigned ring = lds_addr(smem);
@@ -414,7 +415,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
 #pragma unroll
                 for (int i = 0; i < 9; ++i) ad[i] = *reinterpret_cast<const uint4*>(a.add + (row0 + 16 * i) * a.ldx + col0);
             }
-            if constexpr (MODE == 3) {                  // mu / rs / ww hold bias / column scale / column shift here
+            if constexpr (FWD) {                        // mu / rs / ww hold bias / column scale / column shift here
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { mu[q] = 0.f; rs[q] = 1.f; ww[q] = 0.f; }
                 if (a.bias) load8(a.bias + col0, mu);
@@ -510,10 +511,10 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
                 *reinterpret_cast<bf16x8*>(a.out2 + (row0 + 16 * i) * a.ldx + col0) = o2;
             }
         }
-    } else if constexpr (MODE == 3) {
+    } else if constexpr (FWD) {
         // ---- the forward twin.  Stage A: the linear epilogue of the streaming kernels (same expressions: same bits), rows rounded and stored
         const bool lo = li < 8;
-        const bool late_resid = a.n1.w && a.n1.resid && !a.add;      // the second norm's residual rows travel under stage A and the statistics
+        const bool late_resid = MODE == 4 && a.n1.resid && !a.add;      // the second norm's residual rows travel under stage A and the statistics
         if (late_resid) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) ad[i] = *reinterpret_cast<const uint4*>(a.n1.resid + (row0 + 16 * i) * a.ldx + col0);
@@ -534,7 +535,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
             y[i] = __builtin_bit_cast(uint4, o);
         }
         // ---- stage B: y = resid + g * InstanceNorm(out) over the frame (statistics of the rows as stored)
-        if (a.n1.w) {
+        if constexpr (MODE == 4) {
             float m1[8], r1[8], aa[8], ss[8];
             load8(a.n1.w + col0, aa); load8(a.n1.b + col0, ss);
             float gg[8];
@@ -856,5 +857,5 @@ extern "C" int bf_gemm_fwd_frames(int dtype, int M, int N, int K, const void* A,
     if (int rc = take(n2, a.n2, false)) return rc;
     BfProfScope prof((hipStream_t)stream, n1 ? (n2 ? "gemm_pair<fwd,norm,chain>" : "gemm_pair<fwd,norm>") : (n2 ? "gemm_pair<fwd,chain>" : "gemm_pair<fwd>"),
                      2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * N * (1 + (add ? 1 : 0) + (n1 ? (n1->resid ? 2 : 1) : 0) + (n2 ? 1 : 0))));
-    return launch_pair<3>(a, M, (hipStream_t)stream);
+    return n1 ? launch_pair<4>(a, M, (hipStream_t)stream) : launch_pair<3>(a, M, (hipStream_t)stream);
 }
