@@ -125,7 +125,9 @@ SideStream* side_stream() {
     return s.st ? &s : nullptr;
 }
 // the previous stage's deferred tail (if any) is ordered before what `main` is given next
+int flush_pending_reduce(hipStream_t st);                    // (a spatial stage's parameter reductions waiting for the temporal stage behind it)
 int side_join_pending(hipStream_t main, int set = -1) {      // set: 0 / 1 = the work that reads that scratch set, -1 = everything
+    if (set < 0) { const int rc = flush_pending_reduce(main); if (rc) return rc; }
     SideStream* s = side_stream();
     if (!s) return 0;
     for (int i = 0; i < 2; ++i)
@@ -448,7 +450,7 @@ struct SpatialSaved {
 
 // transient scratch (backward is the larger user)
 struct Scratch {
-    float *G, *csum, *zeros, *ones, *wg, *attn_ws, *attn_ws2, *in_ws, *in_ws2, *in_ws3;   // wg: prepared-layout weight gradient scratch
+    float *G, *csum, *zeros, *ones, *wg, *attn_ws, *attn_ws2, *in_ws, *in_ws2, *in_ws3, *in_ws4, *in_ws5;   // wg: prepared-layout weight gradient scratch; in_ws4 / 5: the chained tails' partials (bf_stage_chain_tail), alternating
     float* tokred_ws; int64_t tokred_floats;      // slabs of the token-reduction (weight-gradient) GEMM
     static constexpr long ATTN_WS_FLOATS = 1024L * (4 * 128 + 32 * 16 + 16);
     void *t1, *t3, *t4, *t1b; int64_t t1b_floats;
@@ -476,7 +478,7 @@ struct Scratch {
             in_ws = a.f32((size_t)n);
             // one partials region per InstanceNorm of a block: their reductions run together at the end of the stage
             const size_t nt = (size_t)bf_in_ws_floats(d.dtype, (int)d.F, (int)d.S, d.E);
-            in_ws2 = a.f32(nt); in_ws3 = a.f32(nt);
+            in_ws2 = a.f32(nt); in_ws3 = a.f32(nt); in_ws4 = a.f32(nt); in_ws5 = a.f32(nt);
         }
         // activation-sized transients; embed/debed stages work at up to (patch/2)^2 * N pixels of E/4 (or cin/cout) channels
         size_t tok = (size_t)d.N * d.E;
@@ -499,7 +501,7 @@ struct Scratch {
 // ------------------------------------------------------------------------------------------------ stage-end parameter reductions
 // All InstanceNorm / attention parameter-gradient reductions of one stage backward in ONE launch (grid z = job): nothing on the
 // critical path reads them, and eight dependent ~5 us launches per block are worth ~3 % of the step.
-struct ReduceJobs { int n_in = 0, n_attn = 0; InReduceJob in[3]; AttnReduceJob at[2]; };
+struct ReduceJobs { int n_in = 0, n_attn = 0; InReduceJob in[6]; AttnReduceJob at[4]; };      // room for a spatial + a temporal stage (see g_pending_reduce)
 __global__ void __launch_bounds__(256) stage_param_reduce_kernel(ReduceJobs J) {
     __shared__ float red[5][4][64];
     const int z = blockIdx.z;
@@ -523,6 +525,25 @@ int launch_reduce_jobs(ReduceJobs& J, hipStream_t st) {
     hipLaunchKernelGGL(stage_param_reduce_kernel, dim3(gx, gy, J.n_in + J.n_attn), dim3(256), 0, st, J);
     BF_CHECK_LAUNCH();
     return 0;
+}
+// Deferred mode (bf_side_defer): the spatial stage's reductions wait for the temporal stage's backward that follows it and ride in ITS launch
+// (one launch per block pair instead of two: 12 launches less on the caller's queue per step).  The two stages use different scratch sets, so
+// the spatial stage's partial sums are intact until the next spatial stage, which flushes a leftover first -- as does every full join.
+ReduceJobs g_pending_reduce;
+bool g_pending_reduce_on = false;
+int flush_pending_reduce(hipStream_t st) {
+    if (!g_pending_reduce_on) return 0;
+    g_pending_reduce_on = false;
+    return launch_reduce_jobs(g_pending_reduce, st);
+}
+int launch_with_pending(ReduceJobs& J, hipStream_t st) {
+    if (g_pending_reduce_on) {
+        g_pending_reduce_on = false;
+        const ReduceJobs& P = g_pending_reduce;
+        for (int i = 0; i < P.n_in && J.n_in < 6; ++i) J.in[J.n_in++] = P.in[i];
+        for (int i = 0; i < P.n_attn && J.n_attn < 4; ++i) J.at[J.n_attn++] = P.at[i];
+    }
+    return launch_reduce_jobs(J, st);
 }
 
 
@@ -678,6 +699,10 @@ const void* g_head_done_for = nullptr;
 namespace {
 struct NextTail { bool armed = false; const bf_spatial_params* p = nullptr; const void* saved = nullptr; bool drop = false; } g_next_tail;
 const void* g_tail_done_for = nullptr;
+// where the chained tail left the norm's partial sums.  Two regions, alternating: the spatial stage's reduction of them waits for the temporal
+// stage behind it (g_pending_reduce), whose own chained tail -- for the NEXT spatial stage, same scratch set -- must not overwrite them
+float* g_tail_ws = nullptr;
+bool g_tail_ws_flip = false;
 }  // namespace
 extern "C" int bf_stage_chain_tail(const bf_spatial_params* prev_p, const void* prev_saved, int has_drop_mlp) {
     g_next_tail.armed = prev_p && prev_saved;
@@ -805,7 +830,9 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
             TRY(side_join_pending(st, oset));
             Scratch so(d, (char*)scratch + (size_t)oset * Scratch(d, nullptr).bytes);
             SpatialSaved ps(d, const_cast<void*>(h.saved));
-            tn = TailNorm{ps.z, so.t1, ps.mean3, ps.rstd3, h.p->mlp_norm_w, h.drop ? ps.gtab : h.p->gamma_mlp, h.drop ? 1 : (int)d.F, so.in_ws3, &tail_done};
+            tn = TailNorm{ps.z, so.t1, ps.mean3, ps.rstd3, h.p->mlp_norm_w, h.drop ? ps.gtab : h.p->gamma_mlp, h.drop ? 1 : (int)d.F, g_tail_ws_flip ? so.in_ws5 : so.in_ws4, &tail_done};
+            g_tail_ws = tn.ws;
+            g_tail_ws_flip = !g_tail_ws_flip;
             fu1.tail = &tn;
         }
         g_tail_done_for = nullptr;
@@ -814,7 +841,7 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
     } else
     TRY(linear_bwd(d, sc, dqkv, 3 * d.E, sv.xn, d.E, BF_PRO_NONE, nullptr, nullptr, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk, &fu1, true));
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws, (int)d.F, d.E, p->norm1_w, p->norm1_b, nullptr, 1, g->norm1_w, g->norm1_b, nullptr, nullptr, nullptr, nullptr};
-    TRY(launch_reduce_jobs(jobs, st));
+    TRY(launch_with_pending(jobs, st));      // ... with the reductions the spatial stage behind (in the forward) left pending
     return fk.join();
 }
 
@@ -980,6 +1007,7 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     const void* w2_c = f32 ? (const void*)p->fc2_w : sv.w2_c;
     // weight-gradient GEMMs go to the side stream and are joined at the end; every buffer they read (dz = t1, dpre = t4,
     // dx1 = t1b, dbr = e5, dqkv = t3, s1) is written once per call, so the critical path below never recycles one under them.
+    TRY(flush_pending_reduce(st));      // (a spatial stage that no temporal stage followed: its partial sums live in the set this stage is about to use)
     Fork fk(st, true, g_scratch_parity);
     if (fk.deferred) TRY(side_join_pending(st, fk.set));      // the stage before the previous one used this scratch set
     // out = x1 + gamma_mlp * IN(z)
@@ -990,13 +1018,13 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     if (drop_mlp) {   // gtab[f][c] = drop_mlp[f] * gamma_mlp[c] was the scale: d gamma_mlp = sum_f drop_mlp[f] * (w s2 + b s1), folded in the reduction
         if (!tail_done)
             TRY(bf_in_bwd_partials(d.dtype, dout, sv.z, nullptr, dz, (int)d.F, (int)d.S, d.E, sv.mean3, sv.rstd3, p->mlp_norm_w, p->mlp_norm_b, sv.gtab, 1, 0, sc.in_ws3, st));
-        jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws3, (int)d.F, d.E, p->mlp_norm_w, p->mlp_norm_b, sv.gtab, 1, g->mlp_norm_w, g->mlp_norm_b, nullptr, nullptr,
+        jobs.in[jobs.n_in++] = InReduceJob{tail_done ? g_tail_ws : sc.in_ws3, (int)d.F, d.E, p->mlp_norm_w, p->mlp_norm_b, sv.gtab, 1, g->mlp_norm_w, g->mlp_norm_b, nullptr, nullptr,
                                            drop_mlp, g->gamma_mlp};
     } else {
         if (!tail_done)
             TRY(bf_in_bwd_partials(d.dtype, dout, sv.z, nullptr, dz, (int)d.F, (int)d.S, d.E, sv.mean3, sv.rstd3, p->mlp_norm_w, p->mlp_norm_b, p->gamma_mlp,
                                    (int)d.F, 0, sc.in_ws3, st));
-        jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws3, (int)d.F, d.E, p->mlp_norm_w, p->mlp_norm_b, p->gamma_mlp, (int)d.F, g->mlp_norm_w, g->mlp_norm_b,
+        jobs.in[jobs.n_in++] = InReduceJob{tail_done ? g_tail_ws : sc.in_ws3, (int)d.F, d.E, p->mlp_norm_w, p->mlp_norm_b, p->gamma_mlp, (int)d.F, g->mlp_norm_w, g->mlp_norm_b,
                                            g->gamma_mlp, nullptr, nullptr, nullptr};
     }
     // fc2: z = gelu(pre) @ W2^T + b2 ; dpre = (dz @ W2) * gelu'(pre)
@@ -1051,7 +1079,9 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     const InFuse fu1{x, dx1, dx, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, sc.in_ws};              // dqkv @ W_in, then norm1's backward + residual
     TRY(linear_bwd(d, sc, dqkv, 3 * d.E, sv.xn, d.E, BF_PRO_NONE, nullptr, nullptr, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk, &fu1, true));
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws, (int)d.F, d.E, p->norm1_w, p->norm1_b, nullptr, 1, g->norm1_w, g->norm1_b, nullptr, nullptr, nullptr, nullptr};
-    TRY(launch_reduce_jobs(jobs, st));
+    static const bool merge_on = bf_knob("BF_REDUCE_MERGE", 1) != 0;
+    if (fk.deferred && merge_on) { g_pending_reduce = jobs; g_pending_reduce_on = true; }      // rides in the next temporal stage's launch (or the next join)
+    else TRY(launch_reduce_jobs(jobs, st));
     return fk.join();
 }
 
