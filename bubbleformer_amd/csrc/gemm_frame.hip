@@ -282,6 +282,9 @@ struct PairArgs {
     // n2 (optional: the NEXT stage's opening norm of the last tensor written, xn = IN(y) -- statistics, sc / sh and the normalised copy)
     const float *bias, *cs, *ch;
     FwdNorm n1, n2;
+    // MODE 0 / 2, optional: a second copy of `out` scaled per frame group, out_s = out * fscale_s[frame / fdiv_s] -- the stochastic-depth factor the
+    // NEXT stage's backward applies to this gradient before anything else reads it (one elementwise launch and a read of `out` less)
+    bf16* out_s; const float* fscale_s; int fdiv_s;
 };
 
 // LDS-DMA with a wave-uniform 64-bit base in SGPRs and a per-lane 32-bit byte offset: one offset register serves every piece of a wave
@@ -343,7 +346,7 @@ __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
 
 template <int MODE, int GRP>
 __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem, int lane, int w4, int m0, int n0, int fidx0) {
-    constexpr bool INBWD = MODE == 0 || MODE == 2;      // the InstanceNorm backward behind the product (x rows staged in LDS)
+    constexpr bool INBWD = MODE == 0 || MODE == 2 || MODE == 5;      // the InstanceNorm backward behind the product (x rows staged in LDS); 5 = 0 + the scaled second copy
     constexpr bool FWD = MODE == 3 || MODE == 4;        // the forward twin (4: with the MLP-branch norm n1 -- its own instantiation, so that profiles tell the two apart)
     constexpr int PG = GRP == 0 ? 7 : 6;            // DMA pieces per wave per K-step: A pieces {w, w+8, w+16, w+24} (+ 32 + w for waves 0-3), B pieces {w, w+8}
     const int wave = GRP * 4 + w4;
@@ -411,7 +414,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
         const bf16* cA = reinterpret_cast<const bf16*>(smem + (size_t)slot * PSLOT_BYTES);
         const bf16* cB = reinterpret_cast<const bf16*>(smem + (size_t)slot * PSLOT_BYTES + PA_BYTES);
         if constexpr (LAST) {
-            if (MODE != 2 && a.add) {
+            if (MODE != 2 && MODE != 5 && a.add) {
 #pragma unroll
                 for (int i = 0; i < 9; ++i) ad[i] = *reinterpret_cast<const uint4*>(a.add + (row0 + 16 * i) * a.ldx + col0);
             }
@@ -472,7 +475,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
     }
 
     constexpr bool chain = MODE == 2;      // its own instantiation: the code below costs the unchained kernel 13 spilled registers and 1.5 us per launch
-    if constexpr (chain) {                 // the chained form has no registers for the residual-gradient rows during the last K-step (they spilled, beside
+    if constexpr (chain || MODE == 5) {    // the chained form has no registers for the residual-gradient rows during the last K-step (they spilled, beside
         // hand-counted vmcnt): it asks for them here, and they travel under the column-sum pass below instead of under the MFMAs
         if (a.add) {
 #pragma unroll
@@ -641,6 +644,13 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, unsigned char* smem
                 o[q] = (bf16)t;
             }
             *reinterpret_cast<bf16x8*>(a.out + (row0 + 16 * i) * a.ldx + col0) = o;
+            if constexpr (MODE == 5) {               // the scaled copy is the scaled ROUNDED value: what a separate pass over `out` would write
+                const float m2 = a.fscale_s[fidx / a.fdiv_s];
+                bf16x8 o2;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o2[q] = (bf16)((float)o[q] * m2);
+                *reinterpret_cast<bf16x8*>(a.out_s + (row0 + 16 * i) * a.ldx + col0) = o2;
+            }
         }
         if constexpr (chain) {      // the next InstanceNorm backward in line, on the rows just stored (144-token frames: whole frame columns sit in this wave)
             // its rows are requested only now: before this point the kernel has no registers to park them in (248 of 256 in use), and a
@@ -713,7 +723,7 @@ __global__ void __launch_bounds__(512) gemm_pair_kernel(PairArgs a) {
     const int seq = xcd_remap(blockIdx.x, gridDim.x);       // the column blocks of a frame pair run back to back on one XCD: its rows come through one L2
     const int fp = seq / a.nt;
     const int m0 = fp * PM, n0 = (seq - fp * a.nt) * PN;
-    const int f0 = ((MODE == 0 || MODE == 2) && a.whole) ? fp : 2 * fp;
+    const int f0 = ((MODE == 0 || MODE == 2 || MODE == 5) && a.whole) ? fp : 2 * fp;
     if (wave < 4) pair_body<MODE, 0>(a, smem, lane, wave, m0, n0, f0);
     else pair_body<MODE, 1>(a, smem, lane, wave - 4, m0, n0, f0);
 }
@@ -740,6 +750,10 @@ bool pair_shape_ok(int M, int N, int K, int64_t lda, int64_t ldb) {
 }  // namespace
 
 struct InbwdChain { const void* z; void* dz; const float *mean, *rstd, *w, *g; int gdiv; float* ws; };
+struct InbwdScaled { void* out_s; const float* f; int fdiv; };
+static int inbwd_frames_impl2(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, const void* x,
+                              const void* add, void* out, int S, const float* mean, const float* rstd, const float* w, float* ws,
+                              const float* fscale, int fdiv, const InbwdChain* ch, const InbwdScaled* sc2, bf_stream_t stream);
 static int inbwd_frames_impl(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, const void* x,
                              const void* add, void* out, int S, const float* mean, const float* rstd, const float* w, float* ws,
                              const float* fscale, int fdiv, const InbwdChain* ch, bf_stream_t stream);
@@ -762,6 +776,20 @@ extern "C" int bf_gemm_inbwd_frames_chain(int dtype, int M, int N, int K, const 
 static int inbwd_frames_impl(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, const void* x,
                              const void* add, void* out, int S, const float* mean, const float* rstd, const float* w, float* ws,
                              const float* fscale, int fdiv, const InbwdChain* ch, bf_stream_t stream) {
+    return inbwd_frames_impl2(dtype, M, N, K, A, lda, B, ldb, x, add, out, S, mean, rstd, w, ws, fscale, fdiv, ch, nullptr, stream);
+}
+// library-internal (model.hip): bf_gemm_inbwd_frames with a second, per-frame-group scaled copy of `out` (out_s = out * f[frame / fdiv]); returns 1
+// (nothing launched) where the frame-pair kernel does not take the shape -- the caller then runs the plain entry point and scales separately
+int bf_gemm_inbwd_frames_scaled(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, const void* x,
+                                const void* add, void* out, int S, const float* mean, const float* rstd, const float* w, float* ws,
+                                const float* fscale, int fdiv, void* out_s, const float* f_s, int fdiv_s, hipStream_t stream) {
+    if (!out_s || !f_s || (((uintptr_t)out_s) & 15)) return 1;
+    const InbwdScaled sc2{out_s, f_s, fdiv_s > 0 ? fdiv_s : 1};
+    return inbwd_frames_impl2(dtype, M, N, K, A, lda, B, ldb, x, add, out, S, mean, rstd, w, ws, fscale, fdiv, nullptr, &sc2, (bf_stream_t)stream);
+}
+static int inbwd_frames_impl2(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, const void* x,
+                              const void* add, void* out, int S, const float* mean, const float* rstd, const float* w, float* ws,
+                              const float* fscale, int fdiv, const InbwdChain* ch, const InbwdScaled* sc2, bf_stream_t stream) {
     BF_REQUIRE(A && B && x && out && mean && rstd && w, "bf_gemm_inbwd_frames: null pointer");
     static const bool off = bf_knob("BF_FUSE_INBWD", 1) == 0;
     if (off || dtype != BF_DTYPE_BF16 || (S != FM && S != PM) || M <= 0 || M % S || N <= 0 || N % FN || K < FK || K % FK || lda % 8 || ldb % 8) return 1;
@@ -772,15 +800,19 @@ static int inbwd_frames_impl(int dtype, int M, int N, int K, const void* A, int6
         a.x = (const bf16*)x; a.add = (const bf16*)add; a.out = (bf16*)out; a.ldx = N;
         a.mean = mean; a.rstd = rstd; a.w = w; a.ws = ws; a.fscale = fscale; a.fdiv = fdiv > 0 ? fdiv : 1; a.out2 = nullptr;
         a.cz = nullptr; a.cdz = nullptr; a.cmean = a.crstd = a.cw = a.cg = nullptr; a.cgdiv = 1; a.cws = nullptr;
+        a.bias = a.cs = a.ch = nullptr; memset(&a.n1, 0, sizeof(a.n1)); memset(&a.n2, 0, sizeof(a.n2));
+        a.out_s = nullptr; a.fscale_s = nullptr; a.fdiv_s = 1;
+        if (sc2) { a.out_s = (bf16*)sc2->out_s; a.fscale_s = sc2->f; a.fdiv_s = sc2->fdiv; }
         if (ch) {
             if (a.whole || (((uintptr_t)ch->z | (uintptr_t)ch->dz) & 15)) return 1;
             a.cz = (const bf16*)ch->z; a.cdz = (bf16*)ch->dz; a.cmean = ch->mean; a.crstd = ch->rstd; a.cw = ch->w; a.cg = ch->g; a.cgdiv = ch->gdiv; a.cws = ch->ws;
         }
-        BfProfScope prof((hipStream_t)stream, ch ? "gemm_pair<inbwd,chain>" : "gemm_pair<inbwd>", 2.0 * M * N * K,
-                         2.0 * ((double)M * K + (double)N * K + (double)M * N * ((add ? 3 : 2) + (ch ? 2 : 0))));
+        BfProfScope prof((hipStream_t)stream, ch ? "gemm_pair<inbwd,chain>" : sc2 ? "gemm_pair<inbwd,scaled>" : "gemm_pair<inbwd>", 2.0 * M * N * K,
+                         2.0 * ((double)M * K + (double)N * K + (double)M * N * ((add ? 3 : 2) + (ch ? 2 : 0) + (sc2 ? 1 : 0))));
+        if (sc2) { if (ch) return 1; return launch_pair<5>(a, M, (hipStream_t)stream); }
         return ch ? launch_pair<2>(a, M, (hipStream_t)stream) : launch_pair<0>(a, M, (hipStream_t)stream);
     }
-    if (ch) return 1;
+    if (ch || sc2) return 1;
     if (S != FM) return 1;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_inbwd_frames_kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -818,6 +850,8 @@ int bf_gemm_pair_scaled(int M, int N, int K, const bf_operand* A, const bf_opera
     a.mean = nullptr; a.rstd = nullptr; a.w = nullptr; a.ws = nullptr; a.fscale = rowfac; a.fdiv = rows_per_group > 0 ? rows_per_group : 1;
     a.out2 = rowfac ? (bf16*)out2 : nullptr; a.whole = 0;
     a.cz = nullptr; a.cdz = nullptr; a.cmean = a.crstd = a.cw = a.cg = nullptr; a.cgdiv = 1; a.cws = nullptr;
+    a.bias = a.cs = a.ch = nullptr; memset(&a.n1, 0, sizeof(a.n1)); memset(&a.n2, 0, sizeof(a.n2));
+    a.out_s = nullptr; a.fscale_s = nullptr; a.fdiv_s = 1;
     if (a.out2 && ((uintptr_t)out2 & 15)) return 1;
     BfProfScope prof(st, a.add ? "gemm_pair<add>" : "gemm_pair<plain>", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * N * (a.add ? 2 : 1)));
     return launch_pair<1>(a, M, st);

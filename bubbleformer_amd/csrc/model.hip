@@ -19,6 +19,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+int bf_gemm_inbwd_frames_scaled(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, const void* x,
+                                const void* add, void* out, int S, const float* mean, const float* rstd, const float* w, float* ws,
+                                const float* fscale, int fdiv, void* out_s, const float* f_s, int fdiv_s, hipStream_t stream);
+
 namespace {
 
 struct D {
@@ -580,7 +584,8 @@ void* bwd_scratch(const D& d, void* scratch) {
 struct TailNorm { const void* z; void* dz; const float *mean, *rstd, *w, *g; int gdiv; float* ws; bool* done; };
 struct InFuse { const void* x; const void* add; void* dx; const float* mean; const float* rstd; const float* w; const float* b; float* ws;
                 const float* fscale = nullptr; int fdiv = 1;         // fscale: optional per-frame-group factor on dy (stochastic depth)
-                const TailNorm* tail = nullptr; };
+                const TailNorm* tail = nullptr;
+                void* scaled_out = nullptr; const float* scaled_f = nullptr; int scaled_fdiv = 1; bool* scaled_done = nullptr; };      // optional second copy dx * scaled_f[frame / fdiv]
 int dgrad_inbwd(const D& d, const void* dy, int Kdim, const void* w_xc, int Nout, void* tmp, const InFuse& f, hipStream_t st) {
     if (f.tail) {
         const TailNorm& t = *f.tail;
@@ -588,6 +593,12 @@ int dgrad_inbwd(const D& d, const void* dy, int Kdim, const void* w_xc, int Nout
                                                    f.fscale, f.fdiv, t.z, t.dz, t.mean, t.rstd, t.w, t.g, t.gdiv, t.ws, st);
         if (crc < 0) return crc;
         if (crc == 0) { *t.done = true; return 0; }
+    }
+    if (f.scaled_out) {
+        const int src = bf_gemm_inbwd_frames_scaled(d.dtype, (int)d.N, Nout, Kdim, dy, Kdim, w_xc, Nout, f.x, f.add, f.dx, (int)d.S, f.mean, f.rstd, f.w, f.ws,
+                                                    f.fscale, f.fdiv, f.scaled_out, f.scaled_f, f.scaled_fdiv, st);
+        if (src < 0) return src;
+        if (src == 0) { *f.scaled_done = true; return 0; }
     }
     const int rc = bf_gemm_inbwd_frames(d.dtype, (int)d.N, Nout, Kdim, dy, Kdim, w_xc, Nout, f.x, f.add, f.dx, (int)d.S, f.mean, f.rstd, f.w, f.ws,
                                         f.fscale, f.fdiv, st);
@@ -678,7 +689,9 @@ int linear_bwd(const D& d, const Scratch& sc, const void* dy, int Nout, const vo
 extern "C" int64_t bf_temporal_saved_bytes(const bf_dims* s) { D d; if (get_dims(s, &d)) return -1; return (int64_t)TemporalSaved(d, nullptr).bytes; }
 extern "C" int64_t bf_spatial_saved_bytes(const bf_dims* s) { D d; if (get_dims(s, &d)) return -1; return (int64_t)SpatialSaved(d, nullptr).bytes; }
 // two scratch sets: consecutive trunk backward stages alternate between them in deferred mode (see SideStream)
-extern "C" int64_t bf_scratch_bytes(const bf_dims* s) { D d; if (get_dims(s, &d)) return -1; return 2 * (int64_t)Scratch(d, nullptr).bytes; }
+// ... and, behind them, two [N][E] buffers for the pre-scaled gradient a spatial stage leaves for the temporal stage behind it (bf_stage_next_scale)
+size_t dbr_bytes(const D& d) { return (((size_t)d.N * d.E * d.es) + 255) & ~(size_t)255; }
+extern "C" int64_t bf_scratch_bytes(const bf_dims* s) { D d; if (get_dims(s, &d)) return -1; return 2 * (int64_t)Scratch(d, nullptr).bytes + 2 * (int64_t)dbr_bytes(d); }
 
 // Deferred weight-gradient tails (see SideStream): opt-in for callers that join explicitly before they consume parameter gradients
 extern "C" void bf_side_defer(int on) { g_side_defer = on != 0; }
@@ -707,6 +720,20 @@ bool g_tail_ws_flip = false;
 extern "C" int bf_stage_chain_tail(const bf_spatial_params* prev_p, const void* prev_saved, int has_drop_mlp) {
     g_next_tail.armed = prev_p && prev_saved;
     g_next_tail.p = prev_p; g_next_tail.saved = prev_saved; g_next_tail.drop = has_drop_mlp != 0;
+    return 0;
+}
+// Stochastic depth in the backward: a temporal stage multiplies its incoming gradient by its per-sample factors before anything else reads it.
+// That gradient is produced by the last kernel of the spatial stage in front of it (QKV data gradient + norm1 backward): told the factors
+// (bf_stage_next_scale, armed by the caller just before that spatial stage's backward), the kernel writes the scaled copy as well and the
+// temporal backward finds it in place (one elementwise launch and one read of the gradient less per block).  Two buffers, alternating: the
+// temporal stage's side-stream work may still read its copy while the next spatial stage writes the next one.
+namespace {
+struct NextScale { const float* f = nullptr; int fdiv = 1; } g_next_scale;
+struct DbrReady { const void* dx = nullptr; const float* f = nullptr; void* buf = nullptr; } g_dbr_ready;
+bool g_dbr_flip = false;
+}  // namespace
+extern "C" int bf_stage_next_scale(const float* factors, int fdiv) {
+    g_next_scale.f = factors; g_next_scale.fdiv = fdiv > 0 ? fdiv : 1;
     return 0;
 }
 extern "C" int bf_stage_chain_next(const bf_dims* dims, int next_kind, const void* next_params, void* next_saved) {
@@ -797,9 +824,13 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
     // stream instead was measured twice and lost: EXPERIMENTS.md)
     const void* dbr = dout;
     if (drop) {
-        TRY(bf_frame_scale(d.dtype, dout, drop, d.T, sc.t4, d.N, (int)d.S, d.E, st));
-        dbr = sc.t4;
+        if (g_dbr_ready.dx == dout && g_dbr_ready.f == drop && g_dbr_ready.buf) dbr = g_dbr_ready.buf;      // the stage in front left the scaled copy behind
+        else {
+            TRY(bf_frame_scale(d.dtype, dout, drop, d.T, sc.t4, d.N, (int)d.S, d.E, st));
+            dbr = sc.t4;
+        }
     }
+    g_dbr_ready = DbrReady{};
     const InFuse fu2{sv.o, nullptr, dO, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, sc.in_ws2};      // don @ ... then norm2's backward -> dO
     TRY(outproj_bwd(d, sc, dbr, sv.on, sv.wout_s, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr,
                     sv.alpha, sv.mc, g->output_head_w, g->output_head_b, nullptr, g->gamma, nullptr, nullptr, don, st, fk, &fu2));
@@ -1076,8 +1107,18 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
                                                d.attn_scale ? g->attn_scale_factor_y : nullptr};
     }
     void* dxn = sc.e6;      // don is dead (it was only read on this stream)
-    const InFuse fu1{x, dx1, dx, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, sc.in_ws};              // dqkv @ W_in, then norm1's backward + residual
+    InFuse fu1{x, dx1, dx, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, sc.in_ws};              // dqkv @ W_in, then norm1's backward + residual
+    bool scaled_done = false;
+    const NextScale ns = g_next_scale;
+    g_next_scale = NextScale{};
+    g_dbr_ready = DbrReady{};
+    static const bool scaled_on = bf_knob("BF_BWD_SCALED_COPY", 1) != 0;
+    if (ns.f && scaled_on && fk.deferred && d.dtype == BF_DTYPE_BF16) {
+        fu1.scaled_out = (char*)scratch + 2 * Scratch(d, nullptr).bytes + (g_dbr_flip ? dbr_bytes(d) : 0);
+        fu1.scaled_f = ns.f; fu1.scaled_fdiv = ns.fdiv; fu1.scaled_done = &scaled_done;
+    }
     TRY(linear_bwd(d, sc, dqkv, 3 * d.E, sv.xn, d.E, BF_PRO_NONE, nullptr, nullptr, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk, &fu1, true));
+    if (scaled_done) { g_dbr_ready = DbrReady{dx, ns.f, fu1.scaled_out}; g_dbr_flip = !g_dbr_flip; }
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws, (int)d.F, d.E, p->norm1_w, p->norm1_b, nullptr, 1, g->norm1_w, g->norm1_b, nullptr, nullptr, nullptr, nullptr};
     static const bool merge_on = bf_knob("BF_REDUCE_MERGE", 1) != 0;
     if (fk.deferred && merge_on) { g_pending_reduce = jobs; g_pending_reduce_on = true; }      // rides in the next temporal stage's launch (or the next join)

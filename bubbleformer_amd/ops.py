@@ -199,6 +199,7 @@ _PREPARED: dict = {}      # (kind, pointer of the stage's first parameter) -> (d
 
 _CHAIN = {"next": None}
 _LAST_SPATIAL = {"v": None}
+_LAST_TEMPORAL = {"v": None}      # (output pointer, stochastic-depth factors, T) of the temporal stage just run: the spatial stage behind it remembers them
 
 
 def chain_next(params, kind: str = "temporal") -> None:
@@ -446,7 +447,13 @@ class _BlockFn(torch.autograd.Function):
         # Backward chain (bf_stage_chain_tail): a temporal stage fed by a spatial stage's output remembers that stage -- its backward's last
         # kernel produces that stage's output gradient and can open that stage's backward (the MLP-branch InstanceNorm) in the same launch
         last, _LAST_SPATIAL["v"] = _LAST_SPATIAL["v"], None
+        lastt, _LAST_TEMPORAL["v"] = _LAST_TEMPORAL["v"], None
         ctx.prev_spatial = None
+        ctx.next_scale = None
+        if kind == "temporal" and drop_a is not None and x.dtype == torch.bfloat16:
+            _LAST_TEMPORAL["v"] = (out.data_ptr(), drop_a, T)
+        if kind == "spatial" and lastt is not None and lastt[0] == x.data_ptr():
+            ctx.next_scale = (lastt[1], lastt[2])      # the backward of the temporal stage in front scales this stage's dx by these factors (bf_stage_next_scale)
         if kind == "spatial":
             if x.dtype == torch.bfloat16 and os.environ.get("BF_STAGE_CHAIN", "1") != "0":
                 _LAST_SPATIAL["v"] = (out.data_ptr(), (tuple(x.shape), x.dtype), st, saved, drop_b is not None, params)
@@ -482,8 +489,12 @@ class _BlockFn(torch.autograd.Function):
             rc = bwd(C.byref(d), C.byref(st), C.byref(gs), _p(x), _p(dout), _p(dx), _p(saved), _p(scratch_for(d, x.device)), _p(drop_a), _stream())
             lib.bf_stage_chain_tail(None, None, 0)
         else:
+            ns = getattr(ctx, "next_scale", None)
+            if ns is not None and direct:
+                lib.bf_stage_next_scale(_p(ns[0]), ns[1])
             rc = bwd(C.byref(d), C.byref(st), C.byref(gs), _p(x), _p(dout), _p(dx), _p(saved), _p(scratch_for(d, x.device)), _p(drop_a),
                      _p(drop_b), _stream())
+            lib.bf_stage_next_scale(None, 0)
         L.check(rc, f"bf_{ctx.kind}_bwd")
         if _DEFER["on"]:
             _DEFER["keep"].append((saved, dout, x))

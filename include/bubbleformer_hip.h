@@ -407,6 +407,11 @@ int bf_stage_chain_next(const bf_dims* dims, int next_kind, const void* next_par
  * here, that norm's backward is applied by the temporal backward called next (bf_gemm_inbwd_frames_chain) and bf_spatial_bwd on prev_saved
  * skips it.  bf16, 144-token frames, an even number of frames; otherwise nothing changes.  NULL arguments disarm. */
 int bf_stage_chain_tail(const bf_spatial_params* prev_p, const void* prev_saved, int has_drop_mlp);
+/* Stochastic depth in the backward (optional, deferred-side-work mode): `factors` [frames / fdiv] are what the NEXT stage backward to be called
+ * (a temporal stage) multiplies its incoming gradient by -- the gradient the spatial stage backward called next produces.  Armed, that stage's
+ * last kernel also writes the scaled copy and the temporal backward, given the same dout and drop pointers, uses it instead of scaling in a
+ * launch of its own.  The flag is consumed by the next bf_spatial_bwd; NULL disarms. */
+int bf_stage_next_scale(const float* factors, int fdiv);
 /* Stochastic depth (timm DropPath at layers/attention.py:123,309,317): `drop*` are the per-sample factors (0 or 1/keep) the
  * caller drew -- [B] for the temporal block (dim 0 = batch), [B*T] each for the two branches of the axial block -- or NULL. */
 int bf_temporal_fwd(const bf_dims* d, const bf_temporal_params* p, const void* x, void* out, void* saved, void* scratch,
