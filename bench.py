@@ -196,7 +196,7 @@ def cpu_baseline(w, threads):
     return out
 
 
-def eager_gpu_baseline(w, dev, autocast):
+def eager_gpu_baseline(w, dev, autocast, nsteps=5, nwarm=2):
     """the same restatement run eagerly on the MI355X through stock PyTorch-ROCm kernels -- the
     un-accelerated GPU comparator (the bench shape, AdamW; fp32 or bf16 autocast).  Checker code, timed, never shipped."""
     import torch
@@ -212,16 +212,16 @@ def eager_gpu_baseline(w, dev, autocast):
         loss = R.lp_loss(pred.float(), y)
         loss.backward()
         opt.step()
-    for _ in range(2):
+    for _ in range(nwarm):
         step()
     torch.cuda.synchronize()
-    n, t0 = 5, time.perf_counter()
+    n, t0 = nsteps, time.perf_counter()
     for _ in range(n):
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"value": w["batch"] * n / dt, "unit": "samples/s", "ms_per_step": dt / n * 1e3, "dtype": "bf16 autocast" if autocast else "f32",
-            "kind": "oracle restatement, eager PyTorch-ROCm on the same GPU", "sample": f"batch {w['batch']}, 2 warm-up + {n} timed steps"}
+            "kind": "oracle restatement, eager PyTorch-ROCm on the same GPU", "sample": f"batch {w['batch']}, {nwarm} warm-up + {n} timed steps"}
 
 
 def host_threads():
@@ -341,7 +341,7 @@ def sample_trajectory(w, dev):
     return traj.repeat(1, 1, ry, rx)[..., :w["H"], :w["W"]].contiguous().to(dev)
 
 
-def run_rollout(args, w, dev, dtype):
+def run_rollout(args, w, dev, dtype, profile=True):
     import torch
     from bubbleformer_amd import _lib
     from bubbleformer_amd.models import get_model
@@ -373,7 +373,7 @@ def run_rollout(args, w, dev, dtype):
             cur = preds[s].unsqueeze(0)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        prof = prof_steps(lambda: model(x0, cond))
+        prof = prof_steps(lambda: model(x0, cond)) if profile else {}
         # the record: per fed-back step, relative L2 against the sample-derived target (utils/losses.py:17-94 as inference.py:230 uses it),
         # Eikonal residual of the predicted signed-distance field (utils/losses.py:5-15), heater heat flux of the last frame of the step
         # (utils/heatflux.py:17-38 geometry scaled to this grid: 16-wide domain, dx = 16 / W, FC-72 constants)
@@ -390,6 +390,64 @@ def run_rollout(args, w, dev, dtype):
     return dt, prof, rec
 
 
+def other_config_legs(dev, cdt, dtype_name):
+    """Bounded legs of the default one-GPU run (a few seconds together), so that the driver's own record carries the other BASELINE
+    configurations and the un-accelerated GPU comparator beside the headline: configs3 (5 timed training steps at 32x384x192, batch 4),
+    configs4 (50 HIP-graph replays of the batch-1 rollout step) and the oracle restatement run eagerly on this GPU (bf16 autocast, 3 steps)."""
+    import types
+    import torch
+    from bubbleformer_amd import ops
+    from bubbleformer_amd.models import get_model
+    from bubbleformer_amd.trainer import TrainStep
+    legs = {}
+
+    def roof(w, per_s, kind):
+        pb = BYTES_PER_STEP_PARAMS / w["batch"] if kind == "train" else 0.058e9
+        return {"hbm_frac": per_s * (w["bytes"] + pb) / (PEAK_HBM_GBS * 1e9), "mfma_frac": per_s * w["flops"] / (PEAK_MFMA_TFLOPS[dtype_name] * 1e12)}
+
+    def guarded(name, fn):
+        t0 = time.perf_counter()
+        try:
+            legs[name] = fn()
+        except Exception as e:      # a leg must never cost the headline line
+            legs[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        legs[name]["leg_wall_s"] = round(time.perf_counter() - t0, 2)
+        torch.cuda.synchronize()
+        ops.clear_scratch()
+        torch.cuda.empty_cache()
+
+    def configs3():
+        w = WORKLOADS["configs3"]
+        torch.manual_seed(42)
+        model = get_model("filmavit", time_window=w["T"], drop_path=DROP_PATH, compute_dtype=cdt, **CFG).to(dev).train()
+        step = TrainStep(model, lr=2.5e-4, weight_decay=1e-2)
+        x, cond, y = synthetic_batch(w, 42, dev)
+        for _ in range(2):
+            step(x, cond, y)
+        torch.cuda.synchronize()
+        n, t0 = 5, time.perf_counter()
+        for _ in range(n):
+            loss = step(x, cond, y)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        v = w["batch"] * n / dt
+        return {"metric": w["metric"], "value": v, "unit": "samples/s", "ms_per_step": dt / n * 1e3, "steps": n, "warmup": 2, "loss": float(loss),
+                "step_roofline": roof(w, v, "train"), "what": w["what"]}
+
+    def configs4():
+        w = WORKLOADS["configs4"]
+        a = types.SimpleNamespace(steps=50, warmup=3)
+        dt, _prof, rec = run_rollout(a, w, dev, cdt, profile=False)
+        v = a.steps / dt
+        return {"metric": w["metric"], "value": v, "unit": "steps/s", "ms_per_step": dt / a.steps * 1e3, "steps": a.steps, "warmup": a.warmup,
+                "rel_l2_last": rec[-1]["rel_l2"], "step_roofline": roof(w, v, "rollout"), "what": w["what"] + " (random-init weights: plumbing, not physics)"}
+
+    guarded("configs3", configs3)
+    guarded("configs4", configs4)
+    guarded("eager_gpu_baseline_bf16", lambda: eager_gpu_baseline(WORKLOADS["configs1"], dev, True, nsteps=3, nwarm=1))
+    return legs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -402,6 +460,8 @@ def main():
                     help="device-store: every timed step draws its batch from a DeviceClipStore (HBM-resident trajectories, bf_clip_gather)")
     ap.add_argument("--record", default=None, help="configs4: write the per-step rollout record (relative L2, Eikonal, heat flux) to this file")
     ap.add_argument("--eager-gpu-baseline", action="store_true", help="also time the oracle eagerly on the GPU (fp32 and bf16 autocast)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the bounded configs3 / configs4 / eager-GPU legs the default one-GPU configs1 run adds as `other_configs`")
     args = ap.parse_args()
     w = WORKLOADS[args.config]
 
@@ -550,11 +610,20 @@ def main():
         out["clip_supply"] = clip_supply
         if args.data == "device-store":
             out["data"] = "device-store: batches gathered per step from HBM-resident trajectories (the reference's sample files tiled to 192 x 192, std-normalised; DeviceClipStore.gather = bf_clip_gather)"
+    if world == 1 and args.config == "configs1" and args.dtype == "bf16" and not args.no_other_configs and not force_dist:
+        log("bounded legs: configs3, configs4, eager GPU comparator")
+        del step, model, x, cond, y
+        from bubbleformer_amd import ops as _ops
+        torch.cuda.synchronize()
+        _ops.clear_scratch()
+        torch.cuda.empty_cache()
+        out["other_configs"] = other_config_legs(dev, cdt, args.dtype)
+        step = model = None
     if world == 1 and not args.no_cpu_baseline:
         log("timing the CPU baseline (oracle) on", host_threads(), "threads")
         out["cpu_baseline"] = cpu_baseline(w, host_threads())
     if world == 1 and args.eager_gpu_baseline and w["kind"] == "train":
-        del step, model
+        step = model = None
         torch.cuda.empty_cache()
         out["eager_gpu_baseline"] = [eager_gpu_baseline(w, dev, True), eager_gpu_baseline(w, dev, False)]
     sys.stdout.flush()
