@@ -18,6 +18,7 @@ BF_PRO_NONE, BF_PRO_AFFINE, BF_PRO_AFFINE_GELU, BF_PRO_GELU = 0, 1, 2, 3
 BF_AUX_NONE, BF_AUX_ADD, BF_AUX_DGELU = 0, 1, 2
 BF_OUT_STORE, BF_OUT_STORE_F32, BF_OUT_ATOMIC_F32 = 0, 1, 2
 BF_MAX_STAGES = 5
+BF_LOSS_LIMBS = 5          # int64 limbs per relative-L2 partial sum (include/bubbleformer_hip.h)
 
 vp, fp, i32, i64, f32 = C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float
 

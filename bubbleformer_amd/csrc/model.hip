@@ -1311,7 +1311,7 @@ struct DebedSaved {
     size_t bytes;
     DebedSaved(const D& d, void* base) {
         Arena a(base);
-        lossbuf = a.f32((size_t)d.F * d.cout * 4); coef = a.f32((size_t)d.F * d.cout);
+        lossbuf = a.f32((size_t)d.F * d.cout * 2 * 2 * BF_LOSS_LIMBS); coef = a.f32((size_t)d.F * d.cout);      // [F][Co][2][limbs] int64
         Np = roundup(4 * d.cout, 8);
         for (int i = 0; i < d.nst; ++i) {
             Cin[i] = i == 0 ? d.E : d.E / 4;
@@ -1604,7 +1604,7 @@ extern "C" int bf_debed_fwd(const bf_dims* dims, const bf_debed_params* p, const
             TRY(bf_in_stats(d.dtype, sv.y[i], (int)d.F, S4, co, p->in_w[i], p->in_b[i], nullptr, 1, nullptr, sv.mean[i],
                             sv.rstd[i], sv.sc[i], sv.sh[i], sc.in_ws, st));
         } else {
-            if (target) ZERO(sv.lossbuf, (size_t)d.F * d.cout * 2 * 8);
+            if (target) ZERO(sv.lossbuf, (size_t)d.F * d.cout * 2 * BF_LOSS_LIMBS * 8);
             // InstanceNorm affine + GELU + the 2x2 transposed convolution + NCHW store + loss partials in one streaming pass where it applies
             const int rc = i > 0 ? bf_debed_last(d.dtype, sv.y[i - 1], sv.sc[i - 1], sv.sh[i - 1], sv.wc[i], pred, target, sv.lossbuf, (int)d.F, cin, co,
                                                  sv.gh[i], sv.gw[i], sv.Np, st) : 1;

@@ -65,23 +65,40 @@ __global__ void __launch_bounds__(NT) col2im_kernel(const T* __restrict__ g, flo
 // The relative-L2 sums of a (frame, channel) come from dozens of workgroups.  Added as floats they depend on arrival order, and that
 // last-bit noise reaches coef = 1 / (F sqrt(num) sqrt(den)), i.e. EVERY element of the loss gradient: in bf16 mode a few rounding flips
 // there cascade through the K = 384 contractions of the backward until ~12 % of a gradient tensor's elements differ by an ulp between
-// two runs on identical inputs (1.3 % in d(clip); measured).  So the partial sums are added as 64-bit fixed-point integers (2^-32
-// resolution: exact, associative); lossbuf is [frames][Co][2] int64.  A non-finite partial poisons the sum (finalize returns NaN).
-constexpr double LOSS_FX = 4294967296.0;                 // 2^32
-constexpr long long LOSS_POISON = 1LL << 61;
+// two runs on identical inputs (1.3 % in d(clip); measured).  So the partial sums are added as INTEGERS (exact, associative): a sum is
+// LOSS_LIMBS 64-bit limbs holding base-2^48 digits of the value in units of 2^-112; a partial (an fp32 number: 24 significant bits) is cut
+// into its digits exactly and each non-zero digit is one 64-bit integer atomic.  Covers every partial in [2^-112, 2^127) -- the whole
+// useful fp32 range: un-normalised fields (norm="none" is the dataset default, bubbleformer/data/dataset.py:25) sum to 1e15 and beyond, a
+// nearly converged numerator to 1e-12 and below; the reference's float sums (utils/losses.py:79-89) reach both, and a single 2^-32 limb
+// (rounds 1-3) returned NaN above 2.7e8 and flushed below 2.3e-10.  lossbuf is [frames][Co][2][LOSS_LIMBS] int64, zeroed by the caller.
+// A non-finite, negative or >= 2^127 partial poisons the sum (finalize returns NaN, as the float sum would give inf / NaN).
+constexpr int LOSS_LIMBS = BF_LOSS_LIMBS;
+constexpr long long LOSS_POISON = 1LL << 62;
 __device__ __forceinline__ void loss_accum(float* lossbuf, long slot, float v) {
-    const double d = (double)v * LOSS_FX;
-    const long long q = (d == d && fabs(d) < 4.0e18) ? __double2ll_rn(d) : LOSS_POISON;
-    atomicAdd(reinterpret_cast<unsigned long long*>(lossbuf) + slot, (unsigned long long)q);
+    unsigned long long* limb = reinterpret_cast<unsigned long long*>(lossbuf) + slot * LOSS_LIMBS;
+    if (!(v >= 0.f) || !(v < 1.7014118346046923e38f)) { atomicAdd(limb + LOSS_LIMBS - 1, (unsigned long long)LOSS_POISON); return; }      // NaN, negative, >= 2^127
+    double x = (double)v;                                  // exact; every step below is exact too (x has 24 significant bits)
+#pragma unroll
+    for (int k = LOSS_LIMBS - 1; k >= 1; --k) {
+        const double unit = __builtin_ldexp(1.0, 48 * k - 112);
+        const long long dgt = __double2ll_rd(x / unit);    // < 2^48
+        if (dgt != 0) { atomicAdd(limb + k, (unsigned long long)dgt); x -= (double)dgt * unit; }
+    }
+    const long long d0 = __double2ll_rn(x * __builtin_ldexp(1.0, 112));      // what is left below 2^-64 (rounded to the 2^-112 grid)
+    if (d0 != 0) atomicAdd(limb, (unsigned long long)d0);
 }
 __device__ __forceinline__ float loss_read(const float* lossbuf, long slot) {
-    const long long q = reinterpret_cast<const long long*>(lossbuf)[slot];
-    return (q >= LOSS_POISON / 2 || q < 0) ? __builtin_nanf("") : (float)((double)q / LOSS_FX);
+    const long long* limb = reinterpret_cast<const long long*>(lossbuf) + slot * LOSS_LIMBS;
+    if (limb[LOSS_LIMBS - 1] >= LOSS_POISON / 2 || limb[LOSS_LIMBS - 1] < 0) return __builtin_nanf("");
+    double t = 0.0;
+#pragma unroll
+    for (int k = LOSS_LIMBS - 1; k >= 0; --k) t += (double)limb[k] * __builtin_ldexp(1.0, 48 * k - 112);      // same integers in -> same bits out
+    return (float)t;
 }
 
 // ---------------------------------------------------------------------------- pm2nchw + loss partials
 // pm: [P][Np] fp32, n = co*4 + ky*2 + kx; pred: [F][Co][H][W]; grid (blocks over h*w pixels, F)
-// lossbuf[f][co][0] += sum (pred - y)^2, [1] += sum y^2   (int64 fixed point, see loss_accum)
+// lossbuf[f][co][0] += sum (pred - y)^2, [1] += sum y^2   (integer limbs, see loss_accum)
 __global__ void __launch_bounds__(NT) pm2nchw_kernel(const float* __restrict__ pm, float* __restrict__ pred, const float* __restrict__ y,
                                                     float* __restrict__ lossbuf, int Co, int h, int w, int Np) {
     __shared__ float red[NT / 64][2];

@@ -224,8 +224,11 @@ void bf_debug_force_generic_attn(int on);
 
 int bf_im2col_nchw(int dtype, const float* x, void* out, int frames, int C, int H, int W, int Kp, bf_stream_t stream);
 int bf_col2im_nchw(int dtype, const void* g, float* dx, int frames, int C, int H, int W, int Kp, bf_stream_t stream);
-/* lossbuf (here, in bf_debed_last and bf_lploss_finalize): [frames][Co][2] 64-bit fixed-point sums (2^-32 units) of (pred - y)^2 and y^2,
- * zeroed by the caller: integer adds are order independent, so the loss and its gradient are bit-reproducible run to run. */
+/* lossbuf (here, in bf_debed_last and bf_lploss_finalize): [frames][Co][2][BF_LOSS_LIMBS] int64, zeroed by the caller: the sums of (pred - y)^2
+ * and of y^2 as integers -- base-2^48 digits in units of 2^-112, one 64-bit integer atomic per non-zero digit of a partial.  Integer adds are
+ * order independent, so the loss and its gradient are bit-reproducible run to run; the limbs cover partial sums in [2^-112, 2^127), i.e. the
+ * range of the reference's float sums (utils/losses.py:79-89): un-normalised fields and nearly converged numerators included. */
+#define BF_LOSS_LIMBS 5
 int bf_pm2nchw(const float* pm, float* pred, const float* y, float* lossbuf, int frames, int Co, int h, int w, int Np,
                bf_stream_t stream);
 /* Last HMLPDebed stage in one pass (layers/patching.py:92-104: InstanceNorm affine + GELU on the input rows, ConvTranspose2d(k=2,s=2)

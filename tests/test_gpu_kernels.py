@@ -5,6 +5,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+def _loss_limbs_value(lossbuf):
+    """[..., limbs] int64 -> float64 value of each sum (bf_debed_last / bf_pm2nchw: base-2^48 digits in units of 2^-112)."""
+    out = torch.zeros(lossbuf.shape[:-1], dtype=torch.float64, device=lossbuf.device)
+    for k in range(lossbuf.shape[-1]):
+        out += lossbuf[..., k].double() * 2.0 ** (48 * k - 112)
+    return out
+
+
 def _rel(a, b):
     a, b = a.double().flatten(), b.double().flatten()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
@@ -792,7 +800,7 @@ def test_debed_last_stage_one_pass(Ci, Co, h, w):
     wc = wc.bfloat16()
     y = torch.randn(Fr, Co, 2 * h, 2 * w, device="cuda", generator=g)
     pred = torch.full((Fr, Co, 2 * h, 2 * w), float("nan"), device="cuda")
-    lossbuf = torch.zeros(Fr, Co, 2, device="cuda", dtype=torch.int64)      # 64-bit fixed-point sums, 2^-32 units
+    lossbuf = torch.zeros(Fr, Co, 2, L.BF_LOSS_LIMBS, device="cuda", dtype=torch.int64)      # integer limbs: base-2^48 digits in units of 2^-112
     L.check(lib.bf_debed_last(1, _p(act), _p(sc), _p(sh), _p(wc), _p(pred), _p(y), _p(lossbuf), Fr, Ci, Co, h, w, 16, _stream()), "debed_last")
     a = torch.nn.functional.gelu(act.float().view(Fr, h * w, Ci) * sc[:, None] + sh[:, None]).bfloat16().float()
     a = a.view(Fr, h, w, Ci).permute(0, 3, 1, 2)
@@ -801,7 +809,7 @@ def test_debed_last_stage_one_pass(Ci, Co, h, w):
     assert _rel(pred, ref) < 2e-3
     num = (pred.double() - y.double()).pow(2).sum(dim=(-1, -2))
     den = y.double().pow(2).sum(dim=(-1, -2))
-    lossbuf = lossbuf.double() / 2.0 ** 32
+    lossbuf = _loss_limbs_value(lossbuf)
     assert _rel(lossbuf[..., 0], num) < 1e-5 and _rel(lossbuf[..., 1], den) < 1e-5
     # without a target: prediction only
     pred2 = torch.zeros_like(pred)
@@ -903,6 +911,50 @@ def test_debed_last_stage_backward_with_the_norm_in_front(Ci, Co, h, w, fused_lo
     assert b"workspace" in lib.bf_last_error()
     with pytest.raises(L.BubbleformerHipError, match="declined"):
         L.check(1, "debed_last_bwd_norm")
+
+
+@pytest.mark.parametrize("scale,err", [(1.0, 1e-1), (3.0e5, 1e-1), (1.0e-7, 1e-1), (1.0, 1.0e-7), (40.0, 1.0e-6), (1.0e15, 1e-2)])
+def test_lploss_sums_cover_the_float_range(scale, err):
+    """The fused relative-L2 sums (utils/losses.py:79-89: ||pred - y||_2 / ||y||_2 per (frame, channel), float sums in the reference) on
+    un-normalised large-magnitude fields (norm="none" is the dataset default: sums of 1e15 and more), on tiny ones, and with a nearly
+    converged numerator (pred - y ~ 1e-7 * y): the integer limbs must neither overflow into NaN nor flush to zero.  Against fp64; the
+    result must also be bit-identical run to run (integer adds)."""
+    from bubbleformer_amd import _lib as L
+    from bubbleformer_amd.ops import _p, _stream
+    lib = L.lib()
+    Fr, Co, h, w = 3, 4, 48, 40
+    g = torch.Generator(device="cuda").manual_seed(5)
+    y = (torch.randn(Fr, Co, 2 * h, 2 * w, device="cuda", generator=g) + 0.3) * scale
+    pred_ref = y * (1.0 + err * torch.randn(y.shape, device="cuda", generator=g))
+    # patch-major prediction rows [P][16]: n = co * 4 + ky * 2 + kx
+    pm = pred_ref.view(Fr, Co, h, 2, w, 2).permute(0, 2, 4, 1, 3, 5).reshape(Fr * h * w, Co * 4).contiguous()
+
+    def run():
+        pred = torch.empty_like(y)
+        lossbuf = torch.zeros(Fr, Co, 2, L.BF_LOSS_LIMBS, device="cuda", dtype=torch.int64)
+        loss, coef = torch.zeros(1, device="cuda"), torch.zeros(Fr, Co, device="cuda")
+        L.check(lib.bf_pm2nchw(_p(pm), _p(pred), _p(y), _p(lossbuf), Fr, Co, h, w, 16, _stream()), "bf_pm2nchw")
+        L.check(lib.bf_lploss_finalize(_p(lossbuf), Fr, Co, _p(loss), _p(coef), _stream()), "bf_lploss_finalize")
+        return pred, lossbuf, loss, coef
+
+    pred, lossbuf, loss, coef = run()
+    assert torch.equal(pred, pred_ref)
+    num = ((pred_ref.double() - y.double()) ** 2).sum((2, 3))
+    den = (y.double() ** 2).sum((2, 3))
+    v = _loss_limbs_value(lossbuf)
+    assert _rel(v[..., 0], num) < 1e-5 and _rel(v[..., 1], den) < 1e-5           # (the kernel squares and pre-sums in fp32)
+    ref_loss = (num.sqrt() / den.sqrt()).sum() / Fr
+    assert torch.isfinite(loss).all() and abs(float(loss) - float(ref_loss)) < 1e-5 * float(ref_loss)
+    ref_coef = 1.0 / (Fr * num.sqrt() * den.sqrt())
+    assert torch.isfinite(coef).all() and _rel(coef, ref_coef) < 1e-5
+    _, lossbuf2, loss2, coef2 = run()
+    assert torch.equal(lossbuf, lossbuf2) and torch.equal(loss, loss2) and torch.equal(coef, coef2)
+    # a non-finite prediction poisons the sum instead of wrapping around
+    pm_bad = pm.clone(); pm_bad[7, 3] = float("inf")
+    lb = torch.zeros(Fr, Co, 2, L.BF_LOSS_LIMBS, device="cuda", dtype=torch.int64)
+    L.check(lib.bf_pm2nchw(_p(pm_bad), _p(torch.empty_like(y)), _p(y), _p(lb), Fr, Co, h, w, 16, _stream()), "bf_pm2nchw")
+    L.check(lib.bf_lploss_finalize(_p(lb), Fr, Co, _p(loss), _p(coef), _stream()), "bf_lploss_finalize")
+    assert not torch.isfinite(loss).all()
 
 
 @pytest.mark.parametrize("cin,h2,w2", [(4, 96, 96), (3, 40, 32), (4, 33, 16)])
