@@ -1381,7 +1381,13 @@ extern "C" int bf_embed_fwd(const bf_dims* dims, const bf_embed_params* p, const
             // lean: the stage-0 map is W0 . patch -- when every consumer of this call's saved record can rebuild its rows (the streaming
             // stage-1 kernels, the one-pass backward tail) it is not stored at all; g_embed_lean remembers the decision for the backward
             static const bool lean_on = bf_knob("BF_EMBED_LEAN", 1) != 0;
-            const bool lean = lean_on && part_ok && d.dtype == BF_DTYPE_BF16 && sv.Kp == 16 && d.cin <= 4 && sv.C[0] == 96 && sv.C[1] == 96 && (W / 2) % 16 == 0 &&
+            // ... and only when the BACKWARD kernels that rebuild the rows will take this frame count with the workspaces this call's scratch holds
+            // (the one-pass tail's partials live in the token-reduction workspace, the rebuilt-rows weight gradient's slabs in t1b: a batch of
+            // 23+ clips of 16 frames at 192 x 192 exceeds the first): otherwise the map is stored and the generic chain runs, as before
+            const int64_t tail_need = n > 1 ? bf_embed_tail_ws_floats((int)d.F, sv.gh[1], sv.gw[1], sv.C[0], sv.Kp) : 0;
+            const bool bwd_fits = tail_need > 0 && tail_need + (int64_t)sv.C[0] * sv.Kp <= sc.tokred_floats && d.F <= 512 &&
+                                  (int64_t)d.F * (4 * 96 * 96) <= sc.t1b_floats;
+            const bool lean = lean_on && part_ok && bwd_fits && d.dtype == BF_DTYPE_BF16 && sv.Kp == 16 && d.cin <= 4 && sv.C[0] == 96 && sv.C[1] == 96 && (W / 2) % 16 == 0 &&
                               sv.gw[1] % 16 == 0 && ((long)sv.gh[1] * sv.gw[1]) % 128 == 0 && S0 >= 1024;
             const int rc = bf_embed_first(d.dtype, x, wc, sv.patches, lean ? nullptr : sv.y[0], (int)d.F, sv.C[0], d.cin, H / 2, W / 2, sv.Kp,
                                           part_ok ? sc.in_ws + (size_t)2 * d.F * sv.C[0] : nullptr, st);

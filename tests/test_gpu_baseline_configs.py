@@ -669,3 +669,32 @@ def test_config1_batch8_backward_matches_the_single_sample_fixture():
         _against_reference("config1_16x192x192", prod, dtype)
         del m, x8, loss, pred, dx
         torch.cuda.empty_cache()
+
+
+def test_training_step_at_384_frames_takes_the_stored_map_path():
+    """A per-GPU batch of 24 clips of 16 frames at 192 x 192 (F = 384): the one-pass embed backward tail's partials no longer fit the
+    token-reduction workspace (F <= 367 at this geometry), so the forward must NOT drop the stage-0 map (the "lean" embed) -- before the
+    backward's limits were part of that decision such a step failed in bf_embed_bwd.  A 2-block bf16 model without an input gradient
+    (the training case); the embed's gradients against the same step at F = 96 frames four times over (same clips, batch-mean loss)."""
+    from bubbleformer_amd.models import get_model
+    T, H, W, seed = 16, 192, 192, 12
+    cfg = dict(SMALL, processor_blocks=2)
+    x, y, c = (t.cuda() for t in _inputs(6, T, H, W, seed))
+
+    def run(rep):
+        torch.manual_seed(0)
+        m = get_model("filmavit", time_window=T, drop_path=0.0, compute_dtype=torch.bfloat16, **cfg)
+        m.load_state_dict(_weights(seed, cfg))
+        m = m.cuda()
+        loss, _ = m.forward_loss(x.repeat(rep, 1, 1, 1, 1), c.repeat(rep, 1), y.repeat(rep, 1, 1, 1, 1))
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+    l4, g4 = run(4)          # 24 clips: F = 384
+    l1, g1 = run(1)          # 6 clips: F = 96 (the lean path)
+    assert abs(l4 - l1) < 2e-3 * abs(l1)
+    for k in g1:
+        if k.startswith("embed.") and not structurally_zero(k):
+            assert torch.isfinite(g4[k]).all(), k
+            assert rel_l2(g4[k], g1[k]) < 6e-2, (k, rel_l2(g4[k], g1[k]))
