@@ -312,8 +312,8 @@ def clip_store_batches(w, dev, rank, world):
     fluid = [{"inv_reynolds": 0.0042 * (1 + 0.1 * i), "cpgas": 0.83, "mugas": 0.023, "rhogas": 0.0083, "thcogas": 0.25, "stefan": 0.5298,
               "prandtl": 8.4, "heater": {"nucWaitTime": 0.4, "wallTemp": 1.0 + 0.05 * i}} for i in range(len(trajs))]
     ds = BubbleForecast.from_arrays(trajs, fluid, norm="std", time_window=w["T"], start_time=0)
-    ds.normalize()
     store = ds.device_store(dev)
+    store.normalize()          # mean / std of every field by one reduction launch over the resident trajectories (bf_field_stats)
     import torch
     g = torch.Generator(device=dev).manual_seed(7)
     order = torch.cat([torch.randperm(len(ds), device=dev, generator=g) for _ in range(64)])     # device-resident shuffles: no host work per step

@@ -79,6 +79,8 @@ SIGNATURES = {
     "bf_side_defer": (None, [C.c_int]),
     "bf_prep_stages": (C.c_int, [C.POINTER(Dims), C.c_int, C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]),
     "bf_stage_prepared": (None, [C.c_int]),
+    "bf_field_stats_ws_doubles": (i64, [C.c_int]),
+    "bf_field_stats": (C.c_int, [fp, vp, vp, C.c_int, vp, vp, vp]),
     "bf_stage_chain_next": (C.c_int, [C.POINTER(Dims), C.c_int, vp, vp]),
     "bf_stage_next_scale": (C.c_int, [fp, C.c_int]),
     "bf_gemm_fwd_frames": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, fp, fp, fp, fp, C.c_int, vp, vp, C.c_int,

@@ -932,6 +932,57 @@ extern "C" int bf_heatflux_rows(const float* dfun, const float* temp, int64_t fr
     return 0;
 }
 
+// ---------------------------------------------------------------------------- field statistics of device-resident trajectories
+// The normalisation constants of the dataset (bubbleformer/data/dataset.py:74-117: mean / std / min / max of every full field of every file,
+// which the reference reads through h5py and reduces on the host) from the trajectories ALREADY resident in HBM: one launch over all
+// (field, file) segments.  Pass 1: every workgroup sweeps a contiguous share of one segment (16-byte loads) and leaves {sum, sum of squares,
+// min, max} in fp64; pass 2: one wave per segment adds the workgroup rows in row order (bit-reproducible; no atomics).
+constexpr int FS_ROWS = 64;      // workgroups per segment
+__global__ void __launch_bounds__(NT) field_stats_kernel(const float* __restrict__ src, const long* __restrict__ seg_begin, const long* __restrict__ seg_len,
+                                                        double* __restrict__ part) {
+    __shared__ double red[NT / 64][4];
+    const int seg = blockIdx.y;
+    const float* p = src + seg_begin[seg];
+    const long n = seg_len[seg];
+    const long per = ((n + FS_ROWS - 1) / FS_ROWS + 3) & ~3L;                      // a multiple of 4 floats: whole 16-byte groups when the segment is aligned
+    const long lo = (long)blockIdx.x * per, hi = min(n, lo + per);
+    double s1 = 0.0, s2 = 0.0, mn = 1.0 / 0.0, mx = -1.0 / 0.0;
+    auto take = [&](float v) { const double d = (double)v; s1 += d; s2 += d * d; mn = fmin(mn, d); mx = fmax(mx, d); };
+    const bool vec = (((uintptr_t)p) & 15) == 0;
+    long i = lo + 4L * threadIdx.x;
+    if (vec)
+        for (; i + 3 < hi; i += 4L * NT) { const float4 v = *reinterpret_cast<const float4*>(p + i); take(v.x); take(v.y); take(v.z); take(v.w); }
+    else
+        for (; i + 3 < hi; i += 4L * NT) { take(p[i]); take(p[i + 1]); take(p[i + 2]); take(p[i + 3]); }
+    for (long j = i; j < hi && j < i + 4; ++j) take(p[j]);                            // the share's ragged end (at most one thread has one)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); mn = fmin(mn, __shfl_xor(mn, o, 64)); mx = fmax(mx, __shfl_xor(mx, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { double* r = red[threadIdx.x >> 6]; r[0] = s1; r[1] = s2; r[2] = mn; r[3] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0, c = 1.0 / 0.0, e = -1.0 / 0.0;
+        for (int w = 0; w < NT / 64; ++w) { a += red[w][0]; b += red[w][1]; c = fmin(c, red[w][2]); e = fmax(e, red[w][3]); }
+        double* o = part + ((long)seg * FS_ROWS + blockIdx.x) * 4;
+        o[0] = a; o[1] = b; o[2] = c; o[3] = e;
+    }
+}
+__global__ void __launch_bounds__(64) field_stats_finish_kernel(const double* __restrict__ part, double* __restrict__ out) {
+    const int seg = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    double a = 0.0, b = 0.0, c = 1.0 / 0.0, e = -1.0 / 0.0;
+    for (int r = 0; r < FS_ROWS; ++r) { const double* q = part + ((long)seg * FS_ROWS + r) * 4; a += q[0]; b += q[1]; c = fmin(c, q[2]); e = fmax(e, q[3]); }
+    out[seg * 4] = a; out[seg * 4 + 1] = b; out[seg * 4 + 2] = c; out[seg * 4 + 3] = e;
+}
+extern "C" int64_t bf_field_stats_ws_doubles(int nseg) { return nseg > 0 ? (int64_t)nseg * FS_ROWS * 4 : 0; }
+extern "C" int bf_field_stats(const float* src, const int64_t* seg_begin, const int64_t* seg_len, int nseg, double* out, double* ws, bf_stream_t stream) {
+    BF_REQUIRE(src && seg_begin && seg_len && out && ws && nseg > 0 && nseg <= 65535, "bf_field_stats: bad arguments");
+    hipLaunchKernelGGL(field_stats_kernel, dim3(FS_ROWS, (unsigned)nseg), dim3(NT), 0, (hipStream_t)stream, src, (const long*)seg_begin, (const long*)seg_len, ws);
+    BF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(field_stats_finish_kernel, dim3((unsigned)nseg), dim3(64), 0, (hipStream_t)stream, (const double*)ws, out);
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------- clip gather (device-resident trajectories -> batch)
 // out[b][t][c][yo][xo] = (src[field[c]][first[b] + t0 + t][ys(yo)][xs(xo)] - diff[c]) / div[c]
 // ys / xs: identity, or torch's F.interpolate(mode="nearest") source index floor(dst * float(in / out)) clamped to in - 1

@@ -22,6 +22,30 @@ def _fluid_vector(fp: dict) -> List[float]:
     return [fp[k] for k in FLUID_PARAM_KEYS] + [fp["heater"]["nucWaitTime"], fp["heater"]["wallTemp"]]
 
 
+# (offset, scale) of one file's field from its {mean, std, min, max}; the dataset's constants are the means of these over the files
+_NORMS = {
+    "none": lambda st: (0.0, 1.0),
+    "std": lambda st: (st["mean"], st["std"]),
+    "minmax": lambda st: (st["min"], st["max"] - st["min"]),
+    "tanh": lambda st: ((st["max"] + st["min"]) / 2.0, (st["max"] - st["min"]) / 2.0),
+}
+
+
+def _host_constants(x: Optional[np.ndarray], norm: str) -> Tuple[float, float]:
+    if norm not in _NORMS:
+        raise ValueError(f"Unknown normalization type: {norm}")
+    if x is None:
+        return _NORMS[norm]({})
+    need = {"std": ("mean", "std"), "minmax": ("min", "max"), "tanh": ("min", "max")}[norm]
+    return _NORMS[norm]({k: getattr(x, k)() for k in need})      # numpy's own reductions in the array's dtype, as the reference's h5py arrays give
+
+
+def _combine_constants(per_file: Dict[str, List[Tuple[float, float]]]) -> Tuple[Dict, Dict]:
+    diff = {f: np.mean([c[0] for c in cs]).item() for f, cs in per_file.items()}
+    div = {f: np.mean([c[1] for c in cs]).item() + 1e-8 for f, cs in per_file.items()}
+    return diff, div
+
+
 class BubbleForecast(Dataset):
     """Dataset class for time series forecasting on the BubbleML dataset (reference: bubbleformer/data/dataset.py:17)."""
 
@@ -74,30 +98,14 @@ class BubbleForecast(Dataset):
         return sum(self._per_traj())
 
     def normalize(self, diff_terms: Optional[Dict] = None, div_terms: Optional[Dict] = None) -> Tuple[Dict, Dict]:
-        """Channel-wise normalisation constants: mean over files of the per-file statistic (dataset.py:73-117)."""
+        """Channel-wise normalisation constants (the reference's contract, dataset.py:73-117): per field, the mean over files of that file's
+        (offset, scale) under ``self.norm``, with 1e-8 added to the scale; or the constants handed in (a validation set takes the training
+        set's).  This is the HOST path (numpy over the whole field of every file, as the reference computes them): what a CPU-only caller and
+        ``norm="none"`` use.  With the trajectories resident in HBM, ``device_store(...).normalize()`` gets the same constants from one
+        reduction launch instead of a host pass over every file."""
         if diff_terms is None and div_terms is None:
-            diff_terms = {k: [] for k in self.fields}
-            div_terms = {k: [] for k in self.fields}
-            for field in self.fields:
-                for h5_file in self.data:
-                    if self.norm == "none":
-                        diff_terms[field].append(0.0)
-                        div_terms[field].append(1.0)
-                        continue
-                    x = h5_file[field][...]
-                    if self.norm == "std":
-                        diff_terms[field].append(x.mean())
-                        div_terms[field].append(x.std())
-                    elif self.norm == "minmax":
-                        diff_terms[field].append(x.min())
-                        div_terms[field].append(x.max() - x.min())
-                    elif self.norm == "tanh":
-                        diff_terms[field].append((x.max() + x.min()) / 2.0)
-                        div_terms[field].append((x.max() - x.min()) / 2.0)
-                    else:
-                        raise ValueError(f"Unknown normalization type: {self.norm}")
-                diff_terms[field] = np.mean(diff_terms[field]).item()
-                div_terms[field] = np.mean(div_terms[field]).item() + 1e-8
+            per_file = {f: [_host_constants(None if self.norm == "none" else h5[f][...], self.norm) for h5 in self.data] for f in self.fields}
+            diff_terms, div_terms = _combine_constants(per_file)
         self.diff_terms = diff_terms
         self.div_terms = div_terms
         return self.diff_terms, self.div_terms
@@ -139,7 +147,7 @@ class DeviceClipStore:
 
     def __init__(self, ds: BubbleForecast, device):
         self.ds = ds
-        self.device = torch.device(device)
+        self.device = torch.empty(0, device=device).device      # indexed ("cuda" -> "cuda:0"): gather() compares index tensors' devices with it
         shapes = {tuple(f[ds.fields[0]].shape[1:]) for f in ds.data}
         if len(shapes) != 1:
             raise ValueError(f"device store needs one spatial resolution per dataset, got {sorted(shapes)}")
@@ -156,6 +164,40 @@ class DeviceClipStore:
         if ds.return_fluid_params:
             self.fluid = torch.tensor([_fluid_vector(fp) for fp in ds.fluid_params], dtype=torch.float32, device=self.device)
         self._tables()
+
+    def normalize(self) -> Tuple[Dict, Dict]:
+        """``BubbleForecast.normalize()`` from the trajectories in HBM: {sum, sum of squares, min, max} of every (field, file) segment by ONE
+        reduction launch (bf_field_stats, fp64 accumulation in a fixed order) instead of a host pass over every file, then the reference's
+        rule per file and the mean over files (dataset.py:84-117).  Sets the dataset's constants and this store's tables; returns them.
+        Against the host path the constants agree to fp32 rounding of the host's own float32 reductions (~1e-7 relative)."""
+        from .. import _lib as L
+        from ..ops import _p, _stream
+        ds = self.ds
+        if ds.norm == "none" or self.device.type != "cuda":
+            out = ds.normalize()
+            self._tables()
+            return out
+        if ds.norm not in _NORMS:
+            raise ValueError(f"Unknown normalization type: {ds.norm}")
+        nfile, px = len(ds.traj_lens), self.H * self.W
+        total = int(self.frame0[-1])
+        begin = [(ci * total + int(self.frame0[fi])) * px for ci in range(len(self.fields)) for fi in range(nfile)]
+        length = [int(ds.traj_lens[fi]) * px for _ in self.fields for fi in range(nfile)]
+        nseg = len(begin)
+        seg_b = torch.tensor(begin, dtype=torch.int64, device=self.device)
+        seg_n = torch.tensor(length, dtype=torch.int64, device=self.device)
+        out = torch.empty(nseg, 4, dtype=torch.float64, device=self.device)
+        ws = torch.empty(L.lib().bf_field_stats_ws_doubles(nseg), dtype=torch.float64, device=self.device)
+        L.check(L.lib().bf_field_stats(_p(self.frames), _p(seg_b), _p(seg_n), nseg, _p(out), _p(ws), _stream()), "bf_field_stats")
+        st = out.cpu().view(len(self.fields), nfile, 4).numpy()
+        n = np.asarray(length, dtype=np.float64).reshape(len(self.fields), nfile)
+        mean = st[..., 0] / n
+        var = np.maximum(st[..., 1] / n - mean * mean, 0.0)
+        per_file = {name: [_NORMS[ds.norm]({"mean": mean[ci, fi], "std": float(np.sqrt(var[ci, fi])), "min": st[ci, fi, 2], "max": st[ci, fi, 3]})
+                           for fi in range(nfile)] for ci, name in enumerate(self.fields)}
+        ds.diff_terms, ds.div_terms = _combine_constants(per_file)
+        self._tables()
+        return ds.diff_terms, ds.div_terms
 
     def _tables(self):
         """Per-output-channel field index and normalisation constants; call again after ``ds.normalize()`` changed them."""

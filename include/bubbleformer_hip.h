@@ -316,6 +316,11 @@ int bf_adamw(float* p, const float* g, float* m, float* v, int64_t n, int step, 
  * (yo, xo) when Ho x Wo < H x W (F.interpolate(mode="nearest") index rule), identity otherwise.  out is (B, T, C, Ho, Wo) fp32. */
 int bf_clip_gather(const float* src, int64_t field_stride, const int32_t* field, const int64_t* first, int t0, const float* diff,
                    const float* div, float* out, int B, int T, int C, int H, int W, int Ho, int Wo, bf_stream_t stream);
+/* Normalisation statistics of device-resident trajectories (BubbleForecast.normalize, bubbleformer/data/dataset.py:74-117: mean / std / min /
+ * max of every full field of every file): segment i = seg_len[i] floats at src + seg_begin[i] (both arrays on the DEVICE);
+ * out[i] = {sum, sum of squares, min, max} in fp64, summed in a fixed order (bit-reproducible).  ws: bf_field_stats_ws_doubles(nseg) doubles. */
+int64_t bf_field_stats_ws_doubles(int nseg);
+int bf_field_stats(const float* src, const int64_t* seg_begin, const int64_t* seg_len, int nseg, double* out, double* ws, bf_stream_t stream);
 /* Rollout physics metrics (scripts/inference.py; utils/losses.py:5-15, utils/heatflux.py:17-38).
  * bf_eikonal_sum: *out (fp64, caller zeroes) += sum over frames x H x W of (|grad phi| - 1)^2, gradients as torch.gradient(spacing=dx).
  * bf_heatflux_rows: flux[t] = mean over the W bottom-row cells of [|x_c| <= 5 and dfun < 0] * (heater_temp - temp) * 0.054 / (dx * lc),

@@ -154,6 +154,38 @@ def test_device_gather_is_bit_identical_to_host_collate(tmp_path, norm, ds):
         store.gather([n])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("norm", ["std", "minmax", "tanh", "none"])
+def test_device_store_normalize_matches_the_host_pass(norm):
+    """DeviceClipStore.normalize(): mean / std / min / max of every (field, file) by one reduction launch over the HBM-resident trajectories
+    (bf_field_stats) against BubbleForecast.normalize() -- the reference's host pass over every full field of every file
+    (bubbleformer/data/dataset.py:84-117) -- and against fp64 statistics of the same arrays; the gathered batch then uses them."""
+    from bubbleformer_amd.data import BubbleForecast
+    fields = ["dfun", "temperature", "velx", "vely"]
+    host = BubbleForecast(FILES, fields, ["temperature", "vely"], norm=norm, time_window=6, start_time=4)
+    hdiff, hdiv = host.normalize()
+    d = BubbleForecast(FILES, fields, ["temperature", "vely"], norm=norm, time_window=6, start_time=4)
+    store = d.device_store("cuda")
+    diff, div = store.normalize()
+    assert d.diff_terms is diff and d.div_terms is div
+    arrays = _arrays()
+    for k in fields:
+        # min / max are exact; mean / std differ from numpy's float32 reductions by fp32 rounding only
+        assert diff[k] == pytest.approx(hdiff[k], rel=2e-6, abs=1e-7) and div[k] == pytest.approx(hdiv[k], rel=2e-6)
+        if norm == "std":
+            xs = [np.asarray(a[k], dtype=np.float64) for a in arrays]
+            assert diff[k] == pytest.approx(np.mean([x.mean() for x in xs]), rel=1e-12, abs=1e-14)
+            assert div[k] == pytest.approx(np.mean([x.std() for x in xs]) + 1e-8, rel=1e-9)
+        if norm == "minmax":
+            assert diff[k] == pytest.approx(np.mean([float(a[k].min()) for a in arrays]), rel=1e-15)      # minima are exact
+    again = store.normalize()
+    assert again[0] == diff and again[1] == div                     # fixed summation order: the same bits every time
+    inp, out = store.gather([0, 5])
+    href = BubbleForecast(FILES, fields, ["temperature", "vely"], norm=norm, time_window=6, start_time=4)
+    href.normalize(diff, div)
+    assert torch.equal(inp.cpu(), torch.stack([href[0][0], href[5][0]])) and torch.equal(out.cpu(), torch.stack([href[0][1], href[5][1]]))
+
+
 def test_dataset_over_in_memory_trajectories_equals_the_file_backed_one(tmp_path):
     """BubbleForecast.from_arrays (bench.py's clip-supply leg tiles the sample trajectories in memory): same length, same samples as
     the dataset over the files the arrays were read from."""
