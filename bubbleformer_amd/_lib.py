@@ -69,6 +69,7 @@ class DebedParams(C.Structure):
     _fields_ = [("conv_w", fp * BF_MAX_STAGES), ("in_w", fp * BF_MAX_STAGES), ("in_b", fp * BF_MAX_STAGES)]
 
 
+STAGE_DONE_FN = C.CFUNCTYPE(None, C.c_int, C.c_void_p)      # bf_stage_done_fn
 P = C.POINTER
 # name -> (restype, argtypes); mirrors include/bubbleformer_hip.h one to one
 SIGNATURES = {
@@ -79,6 +80,10 @@ SIGNATURES = {
     "bf_side_defer": (None, [C.c_int]),
     "bf_prep_stages": (C.c_int, [C.POINTER(Dims), C.c_int, C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]),
     "bf_stage_prepared": (None, [C.c_int]),
+    "bf_trunk_train_fwd": (C.c_int, [C.POINTER(Dims), C.c_int, C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp,
+                                     C.POINTER(vp), vp, vp]),
+    "bf_trunk_train_bwd": (C.c_int, [C.POINTER(Dims), C.c_int, C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                     C.POINTER(vp), vp, C.POINTER(vp), vp, C.POINTER(vp), vp, vp, vp, vp, vp]),
     "bf_field_stats_ws_doubles": (i64, [C.c_int]),
     "bf_field_stats": (C.c_int, [fp, vp, vp, C.c_int, vp, vp, vp]),
     "bf_stage_chain_next": (C.c_int, [C.POINTER(Dims), C.c_int, vp, vp]),

@@ -1126,6 +1126,79 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     return fk.join();
 }
 
+// ================================================================================================= the training trunk in one call per direction
+// The n trunk stages of a training step (SpaceTimeBlock x 12: temporal, spatial, temporal, ...; models/axial_vit.py:58-63, 234-235) enqueued
+// by ONE native call each way instead of one Python -> ctypes round trip per stage: the stage forwards / backwards above, called in a
+// loop with the chain hints between them (bf_stage_chain_next, bf_stage_chain_tail, bf_stage_next_scale) set here, where the whole sequence
+// is known.  Everything is caller-owned: saved[i] = stage i's record (bf_temporal_saved_bytes / bf_spatial_saved_bytes), acts[i] = stage
+// i's output [N][E] (the last one is the trunk's output), three [N][E] gradient buffers that rotate between consecutive backward stages
+// (a stage's side-stream work may read its incoming gradient until the stage after the next one starts).
+extern "C" int bf_trunk_train_fwd(const bf_dims* dims, int n, const int32_t* kinds, const void* const* params, void* const* saved,
+                                  const float* const* drop_a, const float* const* drop_b, const void* x, void* const* acts, void* scratch,
+                                  bf_stream_t s) {
+    D d; TRY(get_dims(dims, &d));
+    BF_REQUIRE(n >= 1 && kinds && params && saved && x && acts && scratch, "bf_trunk_train_fwd: bad arguments");
+    for (int i = 0; i < n; ++i)
+        BF_REQUIRE(params[i] && saved[i] && acts[i] && (kinds[i] == 0 || kinds[i] == 1), "bf_trunk_train_fwd: bad stage entry");
+    const bool b16 = d.dtype == BF_DTYPE_BF16;
+    if (b16) {
+        const int rc = bf_prep_stages(dims, n, kinds, params, saved, drop_b, s);
+        if (rc < 0) return rc;
+    }
+    for (int i = 0; i < n; ++i) {
+        const void* in = i ? acts[i - 1] : x;
+        // the next stage's opening InstanceNorm rides in this stage's last GEMM launch where the kinds alternate (bf16)
+        if (b16 && i + 1 < n && kinds[i + 1] != kinds[i]) TRY(bf_stage_chain_next(dims, kinds[i + 1], params[i + 1], saved[i + 1]));
+        else TRY(bf_stage_chain_next(nullptr, 0, nullptr, nullptr));
+        bf_stage_prepared(b16 ? 1 : 0);
+        const int rc = kinds[i] == 0
+            ? bf_temporal_fwd(dims, (const bf_temporal_params*)params[i], in, acts[i], saved[i], scratch, drop_a ? drop_a[i] : nullptr, s)
+            : bf_spatial_fwd(dims, (const bf_spatial_params*)params[i], in, acts[i], saved[i], scratch, drop_a ? drop_a[i] : nullptr,
+                             drop_b ? drop_b[i] : nullptr, s);
+        if (rc) { (void)bf_stage_chain_next(nullptr, 0, nullptr, nullptr); return rc; }
+    }
+    return 0;
+}
+
+// grads[i]: the gradient struct of stage i (same type as params[i]); gradients ACCUMULATE.  dout: gradient of acts[n - 1]; dx: gradient of x.
+// stage_done (optional) is called on the host right after stage i's backward has been enqueued (its last weight-gradient GEMM possibly still
+// deferred, see bf_side_defer): the data-parallel bucket reducer's hook.
+extern "C" int bf_trunk_train_bwd(const bf_dims* dims, int n, const int32_t* kinds, const void* const* params, const void* const* grads,
+                                  void* const* saved, const float* const* drop_a, const float* const* drop_b, const void* x, void* const* acts,
+                                  const void* dout, void* const* gbuf3, void* dx, void* scratch, bf_stage_done_fn stage_done, void* user,
+                                  bf_stream_t s) {
+    D d; TRY(get_dims(dims, &d));
+    BF_REQUIRE(n >= 1 && kinds && params && grads && saved && x && acts && dout && gbuf3 && dx && scratch, "bf_trunk_train_bwd: bad arguments");
+    BF_REQUIRE(gbuf3[0] && gbuf3[1] && gbuf3[2], "bf_trunk_train_bwd: three gradient buffers are needed");
+    const void* cur = dout;
+    int rot = 0;
+    for (int i = n - 1; i >= 0; --i) {
+        BF_REQUIRE(params[i] && grads[i] && saved[i] && (kinds[i] == 0 || kinds[i] == 1), "bf_trunk_train_bwd: bad stage entry");
+        const void* in = i ? acts[i - 1] : x;
+        void* gout = i ? gbuf3[rot] : dx;
+        rot = (rot + 1) % 3;
+        int rc;
+        if (kinds[i] == 0) {
+            // the spatial stage in front (in the forward) opens its backward with its MLP-branch norm: applied by this stage's last kernel
+            if (i > 0 && kinds[i - 1] == 1)
+                TRY(bf_stage_chain_tail((const bf_spatial_params*)params[i - 1], saved[i - 1], drop_b && drop_b[i - 1] ? 1 : 0));
+            rc = bf_temporal_bwd(dims, (const bf_temporal_params*)params[i], (const bf_temporal_params*)grads[i], in, cur, gout, saved[i], scratch,
+                                 drop_a ? drop_a[i] : nullptr, s);
+            (void)bf_stage_chain_tail(nullptr, nullptr, 0);
+        } else {
+            // the temporal stage in front scales this stage's input gradient by its stochastic-depth factors: written here as a second copy
+            if (i > 0 && kinds[i - 1] == 0 && drop_a && drop_a[i - 1]) TRY(bf_stage_next_scale(drop_a[i - 1], d.T));
+            rc = bf_spatial_bwd(dims, (const bf_spatial_params*)params[i], (const bf_spatial_params*)grads[i], in, cur, gout, saved[i], scratch,
+                                drop_a ? drop_a[i] : nullptr, drop_b ? drop_b[i] : nullptr, s);
+            (void)bf_stage_next_scale(nullptr, 0);
+        }
+        if (rc) return rc;
+        if (stage_done) stage_done(i, user);
+        cur = gout;
+    }
+    return 0;
+}
+
 // ================================================================================================= inference forward of the trunk
 // Eval forward of n trunk stages in one call (scripts/inference.py:239-252: FiLMConditionedAViT.forward under torch.no_grad, one clip at a
 // time): nothing is saved for a backward, the InstanceNorms ride inside the whole-frame projection kernels (frame_fwd.hip) and the bf16

@@ -92,6 +92,16 @@ class _AxialBase(nn.Module):
             for i in range(len(self.blocks)):
                 if rates[i] > 0.0:
                     drops[i] = (table[i, :B], table[i, B:B + F], table[i, B + F:])
+        if tok.is_cuda and self.blocks:      # all stages in one native call per direction (ops.trunk_train)
+            b0 = self.blocks[0]
+            seq = []
+            for i, blk in enumerate(self.blocks):
+                dr = drops[i]
+                seq.append(("temporal", blk.temporal.stage_params(), None if dr is None else (dr[0],)))
+                seq.append(("spatial", blk.spatial.stage_params(), None if dr is None else (dr[1], dr[2])))
+            out = ops.trunk_train(tok, b0.temporal.num_heads, b0.temporal.attn_scale, b0.spatial.feat_scale, seq)
+            if out is not None:
+                return out
         if tok.is_cuda and self.blocks:      # every stage's parameter preparation in one launch per 12 stages (a no-op outside bf16)
             b0 = self.blocks[0]
             stages = []

@@ -502,6 +502,120 @@ class _BlockFn(torch.autograd.Function):
         return (dx, None, None, None, None, None, None, *ret)
 
 
+# ------------------------------------------------------------------------------------------------ the training trunk in one call per direction
+class _TrunkFn(torch.autograd.Function):
+    """All trunk stages of a training step through bf_trunk_train_fwd / bf_trunk_train_bwd: one native call per direction instead of one
+    Python -> ctypes round trip (and one autograd node) per stage.  Same kernels, same chain hints, same saved records as the per-stage
+    Functions; the per-stage gradient-ready notifications of the data-parallel reducer come through a host callback."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, kinds, masks, drops, *flat):
+        _require_gpu(x)
+        heads, attn_scale, feat_scale = cfg
+        x = x.contiguous()
+        B, T, h, w, E = x.shape
+        d = make_dims(x.dtype, B, T, h, w, E, heads, attn_scale, feat_scale)
+        lib = L.lib()
+        n = len(kinds)
+        it = iter(flat)
+        plist = [[_f32c(next(it)) if m else None for m in mask] for mask in masks]
+        for kind, ps in zip(kinds, plist):
+            _check_stage_params(kind, ps, E, heads, x.device)
+        structs = [(L.TemporalParams if kind == "temporal" else L.SpatialParams)(*[_p(p) for p in ps]) for kind, ps in zip(kinds, plist)]
+        kinds_c = (C.c_int32 * n)(*[0 if k == "temporal" else 1 for k in kinds])
+        pp = (C.c_void_p * n)(*[C.addressof(s) for s in structs])
+        nb = {"temporal": lib.bf_temporal_saved_bytes(C.byref(d)), "spatial": lib.bf_spatial_saved_bytes(C.byref(d))}
+        if min(nb.values()) < 0:
+            L.check(-1, "bf_*_saved_bytes")
+        offs, total = [], 0
+        for k in kinds:
+            offs.append(total)
+            total += (nb[k] + 255) // 256 * 256
+        arena = torch.empty(total, dtype=torch.uint8, device=x.device)
+        sp = (C.c_void_p * n)(*[arena.data_ptr() + o for o in offs])
+        acts = torch.empty((max(n - 1, 1),) + tuple(x.shape), dtype=x.dtype, device=x.device)      # the outputs of stages 0 .. n - 2 (inputs of 1 .. n - 1)
+        out = torch.empty_like(x)
+        ap = (C.c_void_p * n)(*([acts[i].data_ptr() for i in range(n - 1)] + [out.data_ptr()]))
+        da = [None if dr is None or dr[0] is None else dr[0].contiguous().float() for dr in drops]
+        db = [None if dr is None or len(dr) < 2 or dr[1] is None else dr[1].contiguous().float() for dr in drops]
+        dap = (C.c_void_p * n)(*[_p(t) for t in da])
+        dbp = (C.c_void_p * n)(*[_p(t) for t in db])
+        L.check(lib.bf_trunk_train_fwd(C.byref(d), n, kinds_c, pp, sp, dap, dbp, _p(x), ap, _p(scratch_for(d, x.device)), _stream()), "bf_trunk_train_fwd")
+        ctx.cfg, ctx.kinds, ctx.masks, ctx.offs = cfg, kinds, masks, offs
+        ctx.drops = (da, db)
+        ctx.save_for_backward(x, arena, acts, *flat)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, arena, acts, *flat = ctx.saved_tensors
+        heads, attn_scale, feat_scale = ctx.cfg
+        kinds, masks = ctx.kinds, ctx.masks
+        B, T, h, w, E = x.shape
+        d = make_dims(x.dtype, B, T, h, w, E, heads, attn_scale, feat_scale)
+        lib = L.lib()
+        n = len(kinds)
+        it = iter(flat)
+        plist = [[next(it) if m else None for m in mask] for mask in masks]
+        pstructs, gstructs, rets, directs = [], [], [], []
+        for kind, ps in zip(kinds, plist):
+            gviews, ret, direct = _stage_grads(ps)
+            cls = L.TemporalParams if kind == "temporal" else L.SpatialParams
+            pstructs.append(cls(*[_p(p) for p in ps]))
+            gstructs.append(cls(*[_p(g) for g in gviews]))
+            rets.append(ret)
+            directs.append(direct)
+        kinds_c = (C.c_int32 * n)(*[0 if k == "temporal" else 1 for k in kinds])
+        pp = (C.c_void_p * n)(*[C.addressof(s) for s in pstructs])
+        gp = (C.c_void_p * n)(*[C.addressof(s) for s in gstructs])
+        sp = (C.c_void_p * n)(*[arena.data_ptr() + o for o in ctx.offs])
+        ap = (C.c_void_p * n)(*([acts[i].data_ptr() for i in range(n - 1)] + [None]))
+        da, db = ctx.drops
+        dap = (C.c_void_p * n)(*[_p(t) for t in da])
+        dbp = (C.c_void_p * n)(*[_p(t) for t in db])
+        dout = dout.contiguous()
+        gbuf = torch.empty((3,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        g3 = (C.c_void_p * 3)(*[gbuf[i].data_ptr() for i in range(3)])
+        dx = torch.empty_like(x)
+        on_ready = _DIRECT["on_ready"]
+        errs = []
+
+        def done(i, _user):          # host callback from inside the native call: stage i's backward is enqueued
+            try:
+                if directs[i] and on_ready is not None:
+                    on_ready([p.data_ptr() for p in plist[i] if p is not None])
+            except BaseException as e:      # an exception must not unwind through the C frames
+                errs.append(e)
+
+        cb = L.STAGE_DONE_FN(done)
+        rc = lib.bf_trunk_train_bwd(C.byref(d), n, kinds_c, pp, gp, sp, dap, dbp, _p(x), ap, _p(dout), g3, _p(dx), _p(scratch_for(d, x.device)),
+                                    C.cast(cb, C.c_void_p), None, _stream())
+        L.check(rc, "bf_trunk_train_bwd")
+        if errs:
+            raise errs[0]
+        if not all(directs):             # gradients go back through autograd on this stream: nothing may still be in flight on the side stream
+            L.check(lib.bf_side_join(_stream()), "bf_side_join")
+        if _DEFER["on"]:
+            _DEFER["keep"].append((arena, acts, dout, x, gbuf))
+        flat_ret = [g for ret, mask in zip(rets, masks) for g, m in zip(ret, mask) if m]
+        return (dx, None, None, None, None, *flat_ret)
+
+
+def trunk_train(tok: torch.Tensor, heads: int, attn_scale: bool, feat_scale: bool, stages) -> Optional[torch.Tensor]:
+    """Training forward of all trunk stages in ONE native call (and their backward in one more).  stages: [(kind, params, drops)] in call
+    order, drops = None, (drop,) for a temporal stage, (drop_att, drop_mlp) for a spatial one.  Returns None when the per-stage path is
+    asked for (BF_TRUNK_NATIVE=0, or BF_STAGE_CHAIN=0: the native call always chains the stage heads) -- the caller then runs the stages."""
+    if not tok.is_cuda or not stages or os.environ.get("BF_TRUNK_NATIVE", "1") == "0" or os.environ.get("BF_STAGE_CHAIN", "1") == "0":
+        return None
+    if tok.dim() != 5:
+        raise L.BubbleformerHipError("trunk_train: tokens must be (B, T, h, w, E)")
+    kinds = tuple(k for k, _, _ in stages)
+    masks = tuple(tuple(p is not None for p in ps) for _, ps, _ in stages)
+    flat = [p for _, ps, _ in stages for p in ps if p is not None]
+    drops = [dr for _, _, dr in stages]
+    return _TrunkFn.apply(tok, (heads, bool(attn_scale), bool(feat_scale)), kinds, masks, drops, *flat)
+
+
 def temporal_block(x: torch.Tensor, heads: int, attn_scale: bool, params: List[Optional[torch.Tensor]], drop=None) -> torch.Tensor:
     """x: (B, T, h, w, E) tokens.  params in ``_lib.TEMPORAL_FIELDS`` order (None where the reference has no parameter).
     drop: optional [B] stochastic-depth factors (0 or 1/keep) for the attention branch."""

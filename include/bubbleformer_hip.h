@@ -398,6 +398,19 @@ int64_t bf_trunk_eval_weights_bytes(const bf_dims* dims, int n, const int32_t* k
 int bf_trunk_eval_prepare(const bf_dims* dims, int n, const int32_t* kinds, const void* const* params, void* weights, bf_stream_t stream);
 int bf_trunk_eval_fwd(const bf_dims* dims, int n, const int32_t* kinds, const void* const* params, const void* weights, const void* x,
                       void* out, void* scratch, bf_stream_t stream);
+/* The n trunk stages of a TRAINING step in one native call per direction (the reference runs them as a Python loop over SpaceTimeBlock,
+ * models/axial_vit.py:234-235 -> :58-63): kinds / params as bf_prep_stages; saved[i]: stage i's record (bf_temporal_saved_bytes /
+ * bf_spatial_saved_bytes); acts[i]: stage i's output [N][E] (acts[n - 1] is the trunk's output; the backward reads acts[0 .. n - 2] as stage
+ * inputs); drop_a[i] / drop_b[i]: the stage's stochastic-depth factors or NULL (the arrays themselves may be NULL).  The forward prepares
+ * the weights (bf_prep_stages) and chains every stage's opening InstanceNorm into the launch in front of it.  Backward: grads[i] mirrors
+ * params[i] (gradients accumulate); dout = d(acts[n - 1]), dx = d(x); gbuf3: three [N][E] buffers for the gradients between stages;
+ * stage_done(i, user) (optional) is called on the host after stage i's backward has been enqueued. */
+typedef void (*bf_stage_done_fn)(int stage, void* user);
+int bf_trunk_train_fwd(const bf_dims* dims, int n, const int32_t* kinds, const void* const* params, void* const* saved,
+                       const float* const* drop_a, const float* const* drop_b, const void* x, void* const* acts, void* scratch, bf_stream_t stream);
+int bf_trunk_train_bwd(const bf_dims* dims, int n, const int32_t* kinds, const void* const* params, const void* const* grads, void* const* saved,
+                       const float* const* drop_a, const float* const* drop_b, const void* x, void* const* acts, const void* dout,
+                       void* const* gbuf3, void* dx, void* scratch, bf_stage_done_fn stage_done, void* user, bf_stream_t stream);
 /* x, out, dout, dx: [N][E] activations.  Gradients ACCUMULATE into `g` (zero it first). */
 /* Chained stage heads (optional, forward only): arm the NEXT temporal stage's opening InstanceNorm (norm1 of next_p, written into next_saved)
  * to be computed by the tail of the spatial stage called next, whose output it normalises -- one launch and one read of the activation
