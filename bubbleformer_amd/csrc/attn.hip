@@ -369,6 +369,8 @@ int bf_attn_axial_fwd_mfma(const void* qkv, void* out, int frames, int h, int w,
                            const float* kb, const float* emb, const float* hscale_x, const float* hscale_y, const float* nw, const float* nb,
                            void* out_n, float* mean, float* rstd, float* sc, float* sh, hipStream_t st);
 static bool use_mfma(int dtype, int d) { return !g_force_generic && dtype == BF_DTYPE_BF16 && d % 32 == 0 && d <= 128; }
+// library-internal: whether bf_attn_bwd takes the raw-gradient modes (accumulate 2 / 5: the LayerNorm backward once for two passes)
+bool bf_attn_raw_modes(int dtype, int d) { return use_mfma(dtype, d); }
 
 extern "C" void bf_debug_force_generic_attn(int on) { g_force_generic = on != 0; }
 
@@ -441,6 +443,8 @@ static int attn_bwd_impl(int dtype, const void* qkv, const void* dout, void* dqk
     if (rows_out) *rows_out = 0;
     BF_REQUIRE(qkv && dout && dqkv && qw && qb && kw && kb && nseq > 0 && inner > 0, "bf_attn_bwd: bad arguments");
     if (int rc = check_geo("bf_attn_bwd", dtype, heads, d, L)) return rc;
+    BF_REQUIRE(accumulate == 0 || accumulate == 1 || ((accumulate == 2 || accumulate == 5) && use_mfma(dtype, d)),
+               "bf_attn_bwd: accumulate must be 0 / 1 (or 2 / 5, the raw-gradient pair of passes, on the bf16 MFMA path)");
     if (use_mfma(dtype, d)) {
         BfProfScope prof((hipStream_t)stream, "attn_bwd", 10.0 * nseq * heads * L * L * d, (double)nseq * heads * L * d * 2.0 * (accumulate ? 10.0 : 7.0));
         return bf_attn_bwd_mfma(qkv, dout, dqkv, nseq, L, inner, outer_stride, inner_stride, tok_stride, heads, d, qw, qb, kw, kb, emb, hscale, dqw,

@@ -639,6 +639,12 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
     const float scale = rsqrtf((float)D);
     const long nprob = g.nseq * heads;
     const int gq = lane >> 4, i16 = lane & 15;
+    // accumulate: bit 0 = add what dqkv holds; bit 1 ("raw out") = leave the q / k gradients BEFORE the LayerNorm backward (the gradient with
+    // respect to the LayerNorm outputs) and skip that backward and its parameter sums; bit 2 ("raw in", with bit 0) = the q / k values dqkv holds
+    // are such raw gradients: they are added in front of the LayerNorm backward.  The LayerNorm backward is linear in its incoming gradient, so
+    // the two axial passes over the same tokens (layers/attention.py:218-277) run it ONCE, on the sum: pass W with 2, pass H with 1 | 4.
+    const bool raw_out = accumulate & 2, raw_in = accumulate & 4;
+    accumulate &= 1;
 
     // q/k LayerNorm parameter gradients: value v = ((2 * part + {dw: 0, db: 1}) * KS + ks) * 8 + j of channel group gq.  Each
     // problem's 16-row totals (DPP row reduction, VALU only) are deposited in lane (v & 15) of the row, slot v >> 4: 2 * KS
@@ -667,6 +673,9 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
     float mk[NB][NB][4], mneg[NB][NB][4];
     int eidx[NB][NB][4];
     lane_masks<NB>(L, lane, mk, mneg, eidx);
+    if (NB == 1) {      // k-slots 16..31 of the natural-order operands must read zeros: columns 16..31 of the two small tiles, which nothing else writes
+        for (int c = lane; c < 16 * 16; c += 64) { at_t[(c >> 4) * LDP + 16 + (c & 15)] = (bf16)0.f; ds_t[(c >> 4) * LDP + 16 + (c & 15)] = (bf16)0.f; }
+    }
     for (; pr < nprob; pr += pstep) {
         const int head = at.head;
         const long tok0 = at.tok0;
@@ -766,9 +775,6 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
             dhs = wave_sum(dhs);
             if (lane == 0) atomicAdd(&s_dhs[head], dhs);
         }
-        if (NB == 1) {      // k-slots 16..31 of the natural-order operands must read zeros
-            for (int c = lane; c < 16 * 16; c += 64) { at_t[(c >> 4) * LDP + 16 + (c & 15)] = (bf16)0.f; ds_t[(c >> 4) * LDP + 16 + (c & 15)] = (bf16)0.f; }
-        }
         wsync();
         // ---- dV^T[e][j] = sum_i dO[i][e] A[i][j]   and   dKn^T[e][j] = sum_i Qn[i][e] dS[i][j]      (k = query i, natural order)
         // ---- dQn^T[e][i] = sum_j Kn[j][e] dS[i][j]                                                (k-slots in key order)
@@ -809,6 +815,27 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
             }
         }
         wsync();   // all transposed reads of the tiles are done: the tiles become the fp32 re-layout buffer
+        if (raw_out) {      // the first of two passes over these tokens: the gradients with respect to the LayerNorm outputs, as they stand (8-byte stores)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int row = 16 * b + i16;
+                if (row < L) {
+                    bf16* dst = dqkv + (tok0 + row * g.tok_stride) * 3L * E + head * 3 * D + 4 * gq;
+#pragma unroll
+                    for (int t = 0; t < NT16; ++t) {
+                        float vq[4] = {dq[b][t][0], dq[b][t][1], dq[b][t][2], dq[b][t][3]}, vk[4] = {dk[b][t][0], dk[b][t][1], dk[b][t][2], dk[b][t][3]};
+                        if (accumulate) {
+                            const bf16x4 oq = *reinterpret_cast<const bf16x4*>(dst + 16 * t), ok = *reinterpret_cast<const bf16x4*>(dst + D + 16 * t);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { vq[r] += (float)oq[r]; vk[r] += (float)ok[r]; }
+                        }
+                        const bf16x4 a4 = {(bf16)vq[0], (bf16)vq[1], (bf16)vq[2], (bf16)vq[3]}, b4 = {(bf16)vk[0], (bf16)vk[1], (bf16)vk[2], (bf16)vk[3]};
+                        *reinterpret_cast<bf16x4*>(dst + 16 * t) = a4;
+                        *reinterpret_cast<bf16x4*>(dst + D + 16 * t) = b4;
+                    }
+                }
+            }
+        } else
         // ---- LayerNorm backward in the operand layout, q then k
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
@@ -840,7 +867,8 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float xh = part == 0 ? xq[b][ks][j] : xk[b][ks][j];
-                        const float d0 = row < L ? raw[j] : 0.f;
+                        float d0 = row < L ? raw[j] : 0.f;
+                        if (raw_in) d0 += row < L ? (float)(part == 0 ? old.q[b][ks][j] : old.k[b][ks][j]) : 0.f;      // the other pass's raw gradient
                         pw[ks][j] += d0 * xh;
                         pb[ks][j] += d0;
                         const float gg = d0 * w[32 * ks + 8 * gq + j];
@@ -860,7 +888,7 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
                         for (int j = 0; j < 8; ++j) {
                             const float xh = part == 0 ? xq[b][ks][j] : xk[b][ks][j];
                             float v = rs * (dn[ks][j] - m1 - xh * m2);
-                            if (accumulate) v += (float)(part == 0 ? old.q[b][ks][j] : old.k[b][ks][j]);
+                            if (accumulate && !raw_in) v += (float)(part == 0 ? old.q[b][ks][j] : old.k[b][ks][j]);
                             o[j] = (bf16)v;
                         }
                         *reinterpret_cast<bf16x8*>(dst + 32 * ks) = o;

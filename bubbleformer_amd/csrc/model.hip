@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+bool bf_attn_raw_modes(int dtype, int d);
 int bf_gemm_inbwd_frames_scaled(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, const void* x,
                                 const void* add, void* out, int S, const float* mean, const float* rstd, const float* w, float* ws,
                                 const float* fscale, int fdiv, void* out_s, const float* f_s, int fdiv_s, hipStream_t stream);
@@ -1095,14 +1096,18 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     void* dqkv = sc.t3;
     {
         int rows = 0;
+        // the two passes share their tokens' q / k LayerNorms, whose backward is linear in the incoming gradient: the W pass leaves its raw
+        // gradients, the H pass adds its own and runs that backward (and the LayerNorm parameter sums) once (bf16 MFMA path)
+        static const bool raw_on = bf_knob("BF_ATTN_RAW", 1) != 0;
+        const bool rawm = raw_on && bf_attn_raw_modes(d.dtype, d.d);
         TRY(bf_attn_bwd_partials(d.dtype, sv.qkv, dO, dqkv, d.F * d.h, d.w, 1, d.w, 0, 1, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
                                  p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_x : nullptr, g->qnorm_w, g->qnorm_b, g->knorm_w, g->knorm_b,
-                                 g->rel_pos_emb, d.attn_scale ? g->attn_scale_factor_x : nullptr, 0.5f, 0, sc.attn_ws, Scratch::ATTN_WS_FLOATS, &rows, st));
+                                 g->rel_pos_emb, d.attn_scale ? g->attn_scale_factor_x : nullptr, 0.5f, rawm ? 2 : 0, sc.attn_ws, Scratch::ATTN_WS_FLOATS, &rows, st));
         jobs.at[jobs.n_attn++] = AttnReduceJob{sc.attn_ws, rows, d.d, d.heads, g->qnorm_w, g->qnorm_b, g->knorm_w, g->knorm_b, g->rel_pos_emb,
                                                d.attn_scale ? g->attn_scale_factor_x : nullptr};
         TRY(bf_attn_bwd_partials(d.dtype, sv.qkv, dO, dqkv, d.F * d.w, d.h, d.w, d.S, 1, d.w, d.heads, d.d, p->qnorm_w, p->qnorm_b, p->knorm_w, p->knorm_b,
                                  p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor_y : nullptr, g->qnorm_w, g->qnorm_b, g->knorm_w, g->knorm_b,
-                                 g->rel_pos_emb, d.attn_scale ? g->attn_scale_factor_y : nullptr, 0.5f, 1, sc.attn_ws2, Scratch::ATTN_WS_FLOATS, &rows, st));
+                                 g->rel_pos_emb, d.attn_scale ? g->attn_scale_factor_y : nullptr, 0.5f, rawm ? 5 : 1, sc.attn_ws2, Scratch::ATTN_WS_FLOATS, &rows, st));
         jobs.at[jobs.n_attn++] = AttnReduceJob{sc.attn_ws2, rows, d.d, d.heads, g->qnorm_w, g->qnorm_b, g->knorm_w, g->knorm_b, g->rel_pos_emb,
                                                d.attn_scale ? g->attn_scale_factor_y : nullptr};
     }

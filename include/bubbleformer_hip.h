@@ -206,6 +206,10 @@ int bf_attn_axial_norm_fwd(int dtype, const void* qkv, void* out, void* out_n, i
                            const float* qw, const float* qb, const float* kw, const float* kb, const float* emb, const float* hscale_x,
                            const float* hscale_y, const float* norm_w, const float* norm_b, float* mean, float* rstd, float* sc,
                            float* sh, bf_stream_t stream);
+/* Backward of bf_attn_fwd.  accumulate: 0 = dqkv is written, 1 = added to.  Two passes over the SAME tokens (the axial block's W and H
+ * attention, layers/attention.py:218-277, share one q / k LayerNorm) may run that LayerNorm's backward -- linear in its incoming gradient --
+ * once: first pass accumulate = 2 (q / k columns of dqkv receive the raw gradient with respect to the LayerNorm outputs; no LayerNorm
+ * parameter sums), second pass accumulate = 5 (adds the raw values in front of its LayerNorm backward, v as with 1).  bf16 MFMA path only. */
 int bf_attn_bwd(int dtype, const void* qkv, const void* dout, void* dqkv, int64_t nseq, int L, int64_t inner,
                 int64_t outer_stride, int64_t inner_stride, int64_t tok_stride, int heads, int d, const float* qw,
                 const float* qb, const float* kw, const float* kb, const float* emb, const float* hscale, float* dqw,

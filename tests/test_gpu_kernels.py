@@ -638,6 +638,56 @@ def test_attention_mfma_matches_generic_and_fp32(L, d, heads, axis):
             assert float((a - b).norm()) / float(b.norm()) < (1e-1 if name == "dhscale" else 5e-2), (name, float((a - b).norm()) / float(b.norm()))
 
 
+@pytest.mark.parametrize("h,w,d,heads", [(12, 12, 64, 6), (6, 10, 64, 2), (16, 12, 32, 3), (24, 12, 64, 2)])
+def test_axial_attention_backward_raw_pair_of_passes(h, w, d, heads):
+    """bf_attn_bwd's raw-gradient modes (accumulate 2, then 5): the W and H passes of the axial block share one q / k LayerNorm
+    (layers/attention.py:213-214), whose backward is linear in its incoming gradient -- the W pass leaves the gradients with respect to the
+    LayerNorm outputs, the H pass adds its own and runs the LayerNorm backward and the parameter sums once.  Against the two plain passes
+    (accumulate 0, then 1), which run them twice: data gradients and every parameter gradient equal to bf16 rounding of the intermediate."""
+    from bubbleformer_amd import _lib as L
+    from bubbleformer_amd.ops import _p, _stream
+    lib = L.lib()
+    g = torch.Generator(device="cuda").manual_seed(7 + h + w)
+    Fr, E = 5, heads * d
+    N = Fr * h * w
+    qkv = (torch.randn(N, 3 * E, device="cuda", generator=g) * 1.5).bfloat16()
+    dout = torch.randn(N, E, device="cuda", generator=g).bfloat16()
+    prm = [1 + 0.2 * torch.randn(d, device="cuda", generator=g), 0.2 * torch.randn(d, device="cuda", generator=g),
+           1 + 0.2 * torch.randn(d, device="cuda", generator=g), 0.2 * torch.randn(d, device="cuda", generator=g),
+           0.5 * torch.randn(32, heads, device="cuda", generator=g), 1 + 0.3 * torch.randn(heads, device="cuda", generator=g)]
+    geoW = (Fr * h, w, 1, w, 0, 1)
+    geoH = (Fr * w, h, w, h * w, 1, w)
+
+    def run(a1, a2):
+        dqkv = torch.full_like(qkv, float("nan"))
+        grads = [torch.zeros_like(t) for t in prm]
+        for geo, acc in ((geoW, a1), (geoH, a2)):
+            L.check(lib.bf_attn_bwd(1, _p(qkv), _p(dout), _p(dqkv), *geo, heads, d, *[_p(t) for t in prm], *[_p(t) for t in grads], 0.5, acc, None, 0,
+                                    _stream()), "bf_attn_bwd")
+        torch.cuda.synchronize()
+        return dqkv, grads
+
+    ref, gref = run(0, 1)
+    raw, graw = run(2, 5)
+    assert torch.isfinite(raw.float()).all()
+    parts = lambda t: t.float().view(N, heads, 3, d)
+    for pi, pn in enumerate("qkv"):
+        e = _rel(parts(raw)[:, :, pi], parts(ref)[:, :, pi])
+        assert e < (1e-6 if pn == "v" else 8e-3), (pn, e)          # v: the same arithmetic; q, k: one bf16 rounding placed differently
+    assert torch.equal(parts(raw)[:, :, 2], parts(ref)[:, :, 2])
+    for a, b, name in zip(graw, gref, ("dqw", "dqb", "dkw", "dkb", "demb", "dhscale")):
+        if name == "dkb":     # structurally zero: absolute bound
+            assert float((a - b).norm()) < 1e-2 * float(gref[0].norm()), name
+        else:
+            assert float((a - b).norm()) / float(b.norm()) < 5e-3, (name, float((a - b).norm()) / float(b.norm()))
+    # the raw modes exist on the bf16 MFMA path only
+    lib.bf_debug_force_generic_attn(1)
+    try:
+        assert lib.bf_attn_bwd(1, _p(qkv), _p(dout), _p(raw), *geoW, heads, d, *[_p(t) for t in prm], *[_p(t) for t in graw], 0.5, 2, None, 0, _stream()) < 0
+    finally:
+        lib.bf_debug_force_generic_attn(0)
+
+
 @pytest.mark.parametrize("path", ["mfma_bf16", "generic_f32"])
 @pytest.mark.parametrize("L", [4, 6, 8, 12, 16, 24, 32])
 def test_attention_t5_buckets_bit_exact_on_device(K, path, L):

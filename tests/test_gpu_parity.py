@@ -430,6 +430,9 @@ def test_bias_type_none_equals_a_zero_table(dtype):
             outs.append((out.detach(), tok.grad.detach(), {k: p.grad.detach().clone() for k, p in blk.named_parameters() if "rel_pos_bias" not in k}))
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
         for k, g in outs[0][2].items():
+            if k.endswith("knorm.bias"):      # structurally zero (softmax is shift invariant): rounding noise around 0, summed by float atomics in arrival order
+                assert float((outs[1][2][k] - g).abs().max()) < 1e-3 * float(outs[0][2][k.replace("knorm.bias", "knorm.weight")].abs().max()), k
+                continue
             assert rel_l2(outs[1][2][k], g) < 1e-5 or float(g.abs().max()) < 1e-9, k
 
 
