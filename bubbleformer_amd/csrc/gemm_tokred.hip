@@ -187,15 +187,53 @@ __device__ __forceinline__ void tokred_pp_body(const bf16* __restrict__ A, long 
     }
 }
 
+// The slab sum of the PREVIOUS token-reduction GEMM, carried by extra workgroups of this launch (bf_gemm_tokred_deferred): the slabs were
+// complete when this launch started (stream order), so no hand-off protocol is needed; the sum runs in slice order exactly as
+// tokred_pp_reduce_kernel's (same bits) while the other workgroups multiply, instead of in a launch of its own between two GEMMs.
+struct FoldRed { const float* slab; const float* cslab; int nslice, ntiles, tiles_k, Nout, Kin; float* out; float* colsum; int accumulate; int nwg; };
+template <int NI>
+__device__ __forceinline__ void fold_reduce(const FoldRed& r, int b) {
+    using Gm = PPGeom<NI>;
+    constexpr int T4 = Gm::TILE_FLOATS / 4;
+    const long total = (long)r.ntiles * T4;
+    const size_t sstride = (size_t)r.ntiles * Gm::TILE_FLOATS;
+    for (long e = (long)b * 512 + threadIdx.x; e < total; e += (long)r.nwg * 512) {
+        const int tile = (int)(e / T4), q = (int)(e - (long)tile * T4);
+        const int lane = q & 63, t = q >> 6, wave = t / Gm::TILES, ij = t - wave * Gm::TILES, i = ij / 6, j = ij - i * 6;
+        const int wm = wave & 3, wn = wave >> 2;
+        const int nout = (tile / r.tiles_k) * Gm::TM + 16 * (wm + 4 * i) + (lane & 15);
+        const int kin = (tile % r.tiles_k) * PTN + 16 * (wn + 2 * j) + 4 * (lane >> 4);
+        const float* src = r.slab + (size_t)tile * Gm::TILE_FLOATS + (size_t)q * 4;
+        float4* dst = reinterpret_cast<float4*>(r.out + (size_t)nout * r.Kin + kin);
+        float4 a = r.accumulate ? *dst : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s0 = 0; s0 < r.nslice; s0 += 8) {          // eight slices in flight (a load-then-add loop pays a memory round trip per slice)
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = s0 + u < r.nslice ? *reinterpret_cast<const float4*>(src + (size_t)(s0 + u) * sstride) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < r.nslice) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+        }
+        *dst = a;
+    }
+    if (r.colsum)
+        for (long m = (long)b * 512 + threadIdx.x; m < r.Nout; m += (long)r.nwg * 512) {
+            float a = r.accumulate ? r.colsum[m] : 0.f;
+            for (int s2 = 0; s2 < r.nslice; ++s2) a += r.cslab[(size_t)s2 * r.Nout + m];
+            r.colsum[m] = a;
+        }
+}
+
 template <int NI>
 __global__ void __launch_bounds__(512) tokred_pp_kernel(const bf16* __restrict__ A, long lda, const bf16* __restrict__ B, long ldb,
                                                       float* __restrict__ slab, float* __restrict__ cslab, int Nout, int halves_total,
-                                                      int halves_per, int tiles_k, int ntiles) {
+                                                      int halves_per, int tiles_k, int ntiles, int main_wgs, FoldRed red) {
     using Gm = PPGeom<NI>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x >= main_wgs) { fold_reduce<NI>(red, (int)blockIdx.x - main_wgs); return; }
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // contiguous runs of the (slice, tile) sequence per XCD: the tiles of a slice read the same token rows through one L2
-    const int seq = xcd_remap(blockIdx.x, gridDim.x);
+    const int seq = xcd_remap(blockIdx.x, main_wgs);
     const int slice = seq / ntiles, tile = seq - slice * ntiles;
     const int n0 = (tile / tiles_k) * Gm::TM, c0 = (tile % tiles_k) * PTN;
     const int h_beg = slice * halves_per;
@@ -499,8 +537,51 @@ extern "C" int64_t bf_gemm_tokred_ws_floats(int Nout, int Kin, int64_t M) {
 }
 
 // Returns 0 when done, 1 when the shape is not covered (the caller then runs bf_gemm's token-reduction form), < 0 on error.
+// ---- deferred slab sums (library-internal, model.hip): bf_gemm_tokred_deferred leaves its slab sum PENDING -- the next deferred call on the
+// same stream carries it in extra workgroups of its own launch (FoldRed), bf_gemm_tokred_flush runs what is left as a launch of its own.
+// The caller alternates nothing: the two halves of `ws` are used in turn, so a pending sum's slabs are never the next launch's target.
+namespace {
+struct PendingRed { bool on = false; FoldRed r{}; int NI = 0; };
+PendingRed g_pending[64];
+bool g_half[64];
+PendingRed& pending_slot() { int dev = 0; (void)hipGetDevice(&dev); return g_pending[(dev >= 0 && dev < 64) ? dev : 0]; }
+bool& half_slot() { int dev = 0; (void)hipGetDevice(&dev); return g_half[(dev >= 0 && dev < 64) ? dev : 0]; }
+constexpr int FOLD_WGS = 40;      // extra workgroups that carry a pending sum (they hold a CU's LDS like the others: 128 + 40 of 256)
+}  // namespace
+static int tokred_impl(int dtype, int Nout, int Kin, int64_t M, const void* dy, int64_t ldy, const void* x, int64_t ldx, float* out,
+                       int accumulate, float* colsum, float* ws, int64_t ws_floats, bool defer, bf_stream_t stream);
+int bf_gemm_tokred_flush(hipStream_t st) {
+    PendingRed& p = pending_slot();
+    if (!p.on) return 0;
+    p.on = false;
+    const FoldRed& r = p.r;
+    const long n = (long)r.Nout * r.Kin;
+    const unsigned rblocks = (unsigned)bf_cdiv(std::max<long>(n / 4, r.Nout), 256);
+    BfProfScope prof(st, "tokred_reduce_kernel", 0.0, (double)(r.nslice + 1 + (r.accumulate ? 1 : 0)) * n * 4.0);
+    if (p.NI == 6) {
+        if (r.nslice <= 8) hipLaunchKernelGGL((tokred_pp_reduce_kernel<6, 8>), dim3(rblocks), dim3(256), 0, st, r.slab, r.cslab, r.nslice, r.ntiles, r.tiles_k, r.Nout, r.Kin, r.out, r.colsum, r.accumulate);
+        else hipLaunchKernelGGL((tokred_pp_reduce_kernel<6, MAX_SLICES>), dim3(rblocks), dim3(256), 0, st, r.slab, r.cslab, r.nslice, r.ntiles, r.tiles_k, r.Nout, r.Kin, r.out, r.colsum, r.accumulate);
+    } else {
+        if (r.nslice <= 8) hipLaunchKernelGGL((tokred_pp_reduce_kernel<3, 8>), dim3(rblocks), dim3(256), 0, st, r.slab, r.cslab, r.nslice, r.ntiles, r.tiles_k, r.Nout, r.Kin, r.out, r.colsum, r.accumulate);
+        else hipLaunchKernelGGL((tokred_pp_reduce_kernel<3, MAX_SLICES>), dim3(rblocks), dim3(256), 0, st, r.slab, r.cslab, r.nslice, r.ntiles, r.tiles_k, r.Nout, r.Kin, r.out, r.colsum, r.accumulate);
+    }
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+bool bf_gemm_tokred_pending() { return pending_slot().on; }
+const float* bf_gemm_tokred_pending_out() { const PendingRed& p = pending_slot(); return p.on ? p.r.out : nullptr; }      // whose sum is pending
+// as bf_gemm_tokred, but the slab sum may stay pending (see above); returns 0 / 1 / < 0 likewise.  A shape outside the ping-pong tiling, or a
+// workspace too small for two regions, is summed at once (after whatever was pending).
+int bf_gemm_tokred_deferred(int dtype, int Nout, int Kin, int64_t M, const void* dy, int64_t ldy, const void* x, int64_t ldx, float* out,
+                            int accumulate, float* colsum, float* ws, int64_t ws_floats, hipStream_t stream) {
+    return tokred_impl(dtype, Nout, Kin, M, dy, ldy, x, ldx, out, accumulate, colsum, ws, ws_floats, true, (bf_stream_t)stream);
+}
 extern "C" int bf_gemm_tokred(int dtype, int Nout, int Kin, int64_t M, const void* dy, int64_t ldy, const void* x, int64_t ldx, float* out,
                               int accumulate, float* colsum, float* ws, int64_t ws_floats, bf_stream_t stream) {
+    return tokred_impl(dtype, Nout, Kin, M, dy, ldy, x, ldx, out, accumulate, colsum, ws, ws_floats, false, stream);
+}
+static int tokred_impl(int dtype, int Nout, int Kin, int64_t M, const void* dy, int64_t ldy, const void* x, int64_t ldx, float* out,
+                       int accumulate, float* colsum, float* ws, int64_t ws_floats, bool defer, bf_stream_t stream) {
     if (dtype != BF_DTYPE_BF16) return 1;
     static const int skip_env = bf_knob("BF_TOKRED_SKIP", 0);      // timing experiment (results wrong): the step without its weight-gradient GEMMs
     if (skip_env) return 0;
@@ -536,9 +617,23 @@ extern "C" int bf_gemm_tokred(int dtype, int Nout, int Kin, int64_t M, const voi
         const int ns = bf_cdiv(halves, halves_per);                // slices that actually have tokens
         BF_REQUIRE(ws_floats >= (int64_t)ns * (n + Nout), "bf_gemm_tokred: workspace too small (bf_gemm_tokred_ws_floats)");
         const int tiles_k = Kin / PTN, ntiles = (Nout / tm) * tiles_k;
-        float* slab = ws;
-        float* cslab = colsum ? ws + (size_t)ns * n : nullptr;
+        // deferred form: this launch's slabs go to one half of the workspace while a pending sum reads the other
+        static const bool fold_on = bf_knob("BF_TOKRED_FOLD", 1) != 0;
+        const int64_t half_floats = (ws_floats / 2) & ~(int64_t)3;
+        const bool fold = defer && fold_on && (int64_t)ns * (n + Nout) <= half_floats;
+        PendingRed& pend = pending_slot();
+        if (!fold && pend.on) { const int frc = bf_gemm_tokred_flush(st); if (frc) return frc; }      // (also: the immediate form may be about to overwrite its slabs)
+        if (fold && pend.on && pend.NI != (big ? 6 : 3)) { const int frc = bf_gemm_tokred_flush(st); if (frc) return frc; }
+        bool& hf = half_slot();
+        float* region = ws;
+        if (fold) { region = ws + (hf ? half_floats : 0); hf = !hf; }
+        float* slab = region;
+        float* cslab = colsum ? region + (size_t)ns * n : nullptr;
         const unsigned rblocks = (unsigned)bf_cdiv(std::max<long>(n / 4, Nout), 256);
+        FoldRed red{};
+        static const int fold_wgs = bf_knob("BF_TOKRED_FOLD_WGS", FOLD_WGS);
+        if (fold && pend.on) { red = pend.r; red.nwg = fold_wgs; }
+        const unsigned extra = red.nwg > 0 ? (unsigned)red.nwg : 0u;
 #define BF_PP_GO(NIV)                                                                                                                     \
         do {                                                                                                                              \
             {                                                                                                                             \
@@ -551,9 +646,14 @@ extern "C" int bf_gemm_tokred(int dtype, int Nout, int Kin, int64_t M, const voi
                     if (e_ != hipSuccess) return bf_fail(e_, __FILE__, __LINE__);                                                         \
                     attr_done = true;                                                                                                     \
                 }                                                                                                                         \
-                hipLaunchKernelGGL(tokred_pp_kernel<NIV>, dim3((unsigned)(ns * ntiles)), dim3(512), lds_bytes, st, (const bf16*)dy, (long)ldy, \
-                                   (const bf16*)x, (long)ldx, slab, cslab, Nout, (int)halves, halves_per, tiles_k, ntiles);               \
+                hipLaunchKernelGGL(tokred_pp_kernel<NIV>, dim3((unsigned)(ns * ntiles) + extra), dim3(512), lds_bytes, st, (const bf16*)dy, (long)ldy, \
+                                   (const bf16*)x, (long)ldx, slab, cslab, Nout, (int)halves, halves_per, tiles_k, ntiles, ns * ntiles, red); \
                 BF_CHECK_LAUNCH();                                                                                                        \
+            }                                                                                                                             \
+            if (fold) {                                                                                                                   \
+                pend.on = true; pend.NI = NIV;                                                                                            \
+                pend.r = FoldRed{slab, cslab, ns, ntiles, tiles_k, Nout, Kin, out, colsum, accumulate, 0};                                \
+                break;                                                                                                                    \
             }                                                                                                                             \
             BfProfScope prof(st, "tokred_reduce_kernel", 0.0, (double)(ns + 1 + (accumulate ? 1 : 0)) * n * 4.0);                         \
             if (ns <= 8) hipLaunchKernelGGL((tokred_pp_reduce_kernel<NIV, 8>), dim3(rblocks), dim3(256), 0, st, slab, cslab, ns, ntiles, tiles_k, Nout, Kin, out, colsum, accumulate); \
@@ -564,6 +664,7 @@ extern "C" int bf_gemm_tokred(int dtype, int Nout, int Kin, int64_t M, const voi
 #undef BF_PP_GO
         return 0;
     }
+    { const int frc = bf_gemm_tokred_flush(st); if (frc) return frc; }      // (a pending sum's slabs live in the workspace this form is about to use)
     const long steps = M / BK;
     int nslice = slices_env > 0 ? slices_env : 8;
     nslice = (int)std::max<long>(1, std::min<long>({(long)nslice, (long)MAX_SLICES, steps}));

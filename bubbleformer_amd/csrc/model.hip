@@ -20,6 +20,11 @@
 #include <string.h>
 
 bool bf_attn_raw_modes(int dtype, int d);
+int bf_gemm_tokred_deferred(int dtype, int Nout, int Kin, int64_t M, const void* dy, int64_t ldy, const void* x, int64_t ldx, float* out,
+                            int accumulate, float* colsum, float* ws, int64_t ws_floats, hipStream_t stream);
+int bf_gemm_tokred_flush(hipStream_t st);
+bool bf_gemm_tokred_pending();
+const float* bf_gemm_tokred_pending_out();
 int bf_gemm_inbwd_frames_scaled(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, const void* x,
                                 const void* add, void* out, int S, const float* mean, const float* rstd, const float* w, float* ws,
                                 const float* fscale, int fdiv, void* out_s, const float* f_s, int fdiv_s, hipStream_t stream);
@@ -134,6 +139,12 @@ int flush_pending_reduce(hipStream_t st);                    // (a spatial stage
 int side_join_pending(hipStream_t main, int set = -1) {      // set: 0 / 1 = the work that reads that scratch set, -1 = everything
     if (set < 0) { const int rc = flush_pending_reduce(main); if (rc) return rc; }
     SideStream* s = side_stream();
+    if (set < 0 && bf_gemm_tokred_pending()) {               // the last weight-gradient GEMM's slab sum is still pending (bf_gemm_tokred_deferred): run it now
+        hipStream_t ws_st = s ? s->st : main;
+        const int rc = bf_gemm_tokred_flush(ws_st);
+        if (rc) return rc;
+        if (s) { HIP_TRY(hipEventRecord(s->join, s->st)); HIP_TRY(hipStreamWaitEvent(main, s->join, 0)); }
+    }
     if (!s) return 0;
     for (int i = 0; i < 2; ++i)
         if ((set < 0 || set == i) && s->pending[i]) {
@@ -145,6 +156,8 @@ int side_join_pending(hipStream_t main, int set = -1) {      // set: 0 / 1 = the
 struct Fork {
     hipStream_t main; SideStream* s; bool used = false; bool deferred; int set;
     std::vector<std::function<int(hipStream_t)>> jobs;          // deferred mode: the stage's side work, launched by flush()
+    std::vector<std::function<int(hipStream_t)>> late;          // ... and what must follow the stage's LAST weight-gradient launch (see run_late)
+    hipStream_t last_side = nullptr;
     explicit Fork(hipStream_t m, bool may_defer = false, int scratch_set = 0) : main(m), s(side_stream()), set(scratch_set) {
         deferred = may_defer && g_side_defer && s != nullptr;
     }
@@ -162,7 +175,18 @@ struct Fork {
     template <class F> int run(F&& job) {
         hipStream_t ss;
         const int rc = begin(&ss);
+        last_side = ss;
         return rc ? rc : job(ss);
+    }
+    // work that reads the result of a token-reduction GEMM whose slab sum rides in the NEXT such launch (bf_gemm_tokred_deferred): queued here,
+    // it runs on the side stream after the stage's remaining weight-gradient launches (join() / flush())
+    template <class F> void run_late(F&& job) { late.push_back(job); }
+    int drain_late() {
+        if (late.empty()) return 0;
+        hipStream_t ss = last_side ? last_side : main;
+        for (auto& j : late) { const int rc = j(ss); if (rc) return rc; }
+        late.clear();
+        return 0;
     }
     // deferred mode: one fork for everything collected so far
     int flush() {
@@ -177,10 +201,16 @@ struct Fork {
     // everything forked so far is ordered before what `main` is given next (deferred mode: before the next stage's fork point)
     int join() {
         if (deferred) {
-            const int rc = flush();
+            int rc = flush();
             if (rc) return rc;
+            if ((rc = drain_late())) return rc;
             if (used) { HIP_TRY(hipEventRecord(s->tail[set], s->st)); s->pending[set] = true; used = false; }
             return 0;
+        }
+        {   // plain stream-ordered semantics: nothing of the stage may stay pending
+            int rc = drain_late();
+            if (rc) return rc;
+            if (bf_gemm_tokred_pending() && (rc = bf_gemm_tokred_flush(last_side ? last_side : main))) return rc;
         }
         if (!s || !used) return 0;
         HIP_TRY(hipEventRecord(s->join, s->st));
@@ -619,7 +649,7 @@ int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on,
     TRY(fk.run([=](hipStream_t ss) -> int {           // parameter-gradient side: G GEMM, finalize
         const void* dsrc = dout;
         // G[n][k] = sum_m dout[m][n] * on[m][k]; `on` is the normalised operand the forward saved; dbeta = colsum(dout) from the same pass
-        const int trc = bf_gemm_tokred(d.dtype, d.E, d.E, d.N, dsrc, d.E, on, d.E, sc.G, 0, sc.csum, sc.tokred_ws, sc.tokred_floats, ss);
+        const int trc = bf_gemm_tokred_deferred(d.dtype, d.E, d.E, d.N, dsrc, d.E, on, d.E, sc.G, 0, sc.csum, sc.tokred_ws, sc.tokred_floats, ss);
         if (trc < 0) return trc;
         if (trc == 1) {
             ZERO_ON(ss, sc.G, (size_t)((char*)sc.csum - (char*)sc.G) + (size_t)d.E * 4);     // G and csum are adjacent in the arena: one memset
@@ -629,11 +659,17 @@ int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on,
             e.colsum = sc.csum;                  // dbeta = colsum(dout), fused into the same pass over dout
             TRY(bf_gemm(d.dtype, d.E, d.E, (int)d.N, &A, &Bo, &e, splitk_for(d.E, d.E, d.N), ss));
         }
+        return 0;
+    }));
+    // G's slab sum rides in the stage's NEXT weight-gradient launch (bf_gemm_tokred_deferred): the fold's parameter gradients, which read G, follow
+    // the stage's last such launch on the side stream (or flush the sum themselves when nothing followed)
+    fk.run_late([=](hipStream_t ss) -> int {
+        if (bf_gemm_tokred_pending_out() == sc.G) TRY(bf_gemm_tokred_flush(ss));
         hipLaunchKernelGGL(outproj_finalize_kernel, dim3(d.E + (lo ? bf_cdiv(d.E, 64) : 0)), dim3(256), 0, ss, sc.G, sc.csum, W, bias, nb, gamma, lo, hi, mc,
                            dW, dbias, dnb, dgamma, dlo, dhi, d.E);
         BF_CHECK_LAUNCH();
         return 0;
-    }));
+    });
     if (fu) return dgrad_inbwd(d, dout, d.E, w_s, d.E, don, *fu, st);      // ... followed by norm2's backward
     {   // don = (dout * alpha) @ W = dout @ (diag(alpha) W): the scaled weight was written by the forward's parameter prep
         bf_operand A = op_plain(dout, d.E, BF_LAY_KC);
@@ -659,7 +695,7 @@ int linear_bwd(const D& d, const Scratch& sc, const void* dy, int Nout, const vo
         }
         bf_operand Bo = op_plain(xo, Kin, BF_LAY_XC);
         if (pro == BF_PRO_NONE) {
-            const int trc = bf_gemm_tokred(d.dtype, Nout, Kin, d.N, dy, Nout, xo, Kin, dW, 1, db, sc.tokred_ws, sc.tokred_floats, ss);
+            const int trc = bf_gemm_tokred_deferred(d.dtype, Nout, Kin, d.N, dy, Nout, xo, Kin, dW, 1, db, sc.tokred_ws, sc.tokred_floats, ss);
             if (trc <= 0) return trc;
         }
         if (pro != BF_PRO_NONE) op_affine(Bo, pro, xsc, xsh, d.S, Kin);

@@ -49,7 +49,7 @@ def normalise(name: str) -> str:
     m = re.search(r"gemm_pair_kernel<(\d)>", name) or re.search(r"gemm_pair_kernelILi(\d)E", name)
     if m:      # MODE 0: data gradient + InstanceNorm backward; 1: plain data gradient (+ residual) -- the library's profiler names it <add>; 2: MODE 0 + the chained second norm
         # 3: the forward twin (out-projection + the next stage's norm1); 4: fc2 + MLP-branch norm (+ the next stage's norm1)
-        return {"0": "gemm_pair<inbwd>", "2": "gemm_pair<inbwd,chain>", "3": "gemm_pair<fwd,chain>", "4": "gemm_pair<fwd,norm>"}.get(m.group(1), "gemm_pair<add>")
+        return {"0": "gemm_pair<inbwd>", "2": "gemm_pair<inbwd,chain>", "3": "gemm_pair<fwd,chain>", "4": "gemm_pair<fwd,norm>", "5": "gemm_pair<inbwd,scaled>"}.get(m.group(1), "gemm_pair<add>")
     m = re.search(r"tokred_pp_reduce_kernel", name)
     if m:
         return "tokred_reduce_kernel"

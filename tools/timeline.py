@@ -28,7 +28,7 @@ def short(n):
         return "stream_pp<%s>" % ("gelu2" if m.group(2) in ("true", "1") else {"0": "plain", "1": "add", "2": "dgelu"}[m.group(1)])
     m = re.search(r"gemm_pair_kernel<(\d)>", n)
     if m:
-        return {"0": "gemm_pair<inbwd>", "2": "gemm_pair<inbwd,chain>", "3": "gemm_pair<fwd,chain>", "4": "gemm_pair<fwd,norm>"}.get(m.group(1), "gemm_pair<add>")
+        return {"0": "gemm_pair<inbwd>", "2": "gemm_pair<inbwd,chain>", "3": "gemm_pair<fwd,chain>", "4": "gemm_pair<fwd,norm>", "5": "gemm_pair<inbwd,scaled>"}.get(m.group(1), "gemm_pair<add>")
     if "tokred_pp_reduce" in n:
         return "tokred_reduce"
     for key in ("gather_wgrad_reduce", "gather_wgrad", "gather_gemm", "scatter_gemm", "embed_tail_bwd", "embed_tail_frame", "embed_tail_sum", "debed_last_inbwd", "tokred_narrow_reduce",
