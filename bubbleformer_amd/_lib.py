@@ -77,6 +77,7 @@ SIGNATURES = {
     "bf_abi_version": (C.c_int, []),
     "bf_prof_enable": (None, [C.c_int]),
     "bf_debug_force_generic_attn": (None, [C.c_int]),
+    "bf_debug_tokred_fold": (None, [C.c_int]),
     "bf_side_defer": (None, [C.c_int]),
     "bf_prep_stages": (C.c_int, [C.POINTER(Dims), C.c_int, C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]),
     "bf_stage_prepared": (None, [C.c_int]),

@@ -71,6 +71,12 @@ inline int bf_knob(const char* name, int dflt) { const char* v = getenv(name); r
 constexpr int bf_knob(const char*, int dflt) { return dflt; }
 #endif
 
+// "once per device" flag for hipFuncSetAttribute (the dynamic-LDS limit is a per-device property of a kernel: a process that drives a second
+// device must set it there too)
+struct BfPerDeviceOnce {
+    bool done[64] = {};
+    bool& flag() { int dev = 0; (void)hipGetDevice(&dev); return done[(dev >= 0 && dev < 64) ? dev : 0]; }
+};
 int bf_fail(hipError_t e, const char* file, int line);
 int bf_fail_msg(const char* msg, const char* file, int line);
 int bf_decline(const char* msg);      // returns 1 (shape not covered) and records why

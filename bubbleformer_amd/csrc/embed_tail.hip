@@ -338,7 +338,7 @@ extern "C" int bf_embed_tail_bwd(int dtype, const void* dy1, const void* w1c, co
 #define BF_TAIL_GO(NKS, YM)                                                                                                                \
         do {                                                                                                                              \
             constexpr int lds = tail_lds_bytes<6, NKS, YM>();                                                                             \
-            static bool attr_done = false;                                                                                                \
+            static BfPerDeviceOnce attr_once; bool& attr_done = attr_once.flag();                                                                                                \
             if (!attr_done) {                                                                                                             \
                 hipError_t e_ = hipFuncSetAttribute((const void*)embed_tail_bwd_kernel<6, NKS, YM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
                 if (e_ != hipSuccess) return bf_fail(e_, __FILE__, __LINE__);                                                             \

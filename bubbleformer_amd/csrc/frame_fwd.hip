@@ -448,8 +448,8 @@ extern "C" int bf_frame_linear(int dtype, int frames, int S, int K, int N, const
     static thread_local char pname[64];
     snprintf(pname, sizeof(pname), "frame_linear<%s,bn%d%s>", res ? "res" : "ring", 32 * ntc, norm_w ? ",norm" : en_w ? ",in" : "");
     BfProfScope prof(st, pname, 2.0 * frames * FS * (double)N * K, ((double)frames * FS * (K + N * (resid ? 2.0 : 1.0)) + (double)N * K) * 2.0);
-#define FR_RES(NTC, NSB, NORM) do { static bool done = false; return launch_frame(frame_res_kernel<NTC, NSB, NORM>, done, (size_t)(6 * ABLK + NSB * 32 * NTC * 64) * 2, grid, a, st); } while (0)
-#define FR_RING(NTC, NS) do { static bool done = false; return launch_frame(frame_ring_kernel<NTC, NS>, done, (size_t)NS * (ABLK + 32 * NTC * 64) * 2, grid, a, st); } while (0)
+#define FR_RES(NTC, NSB, NORM) do { static BfPerDeviceOnce once; return launch_frame(frame_res_kernel<NTC, NSB, NORM>, once.flag(), (size_t)(6 * ABLK + NSB * 32 * NTC * 64) * 2, grid, a, st); } while (0)
+#define FR_RING(NTC, NS) do { static BfPerDeviceOnce once; return launch_frame(frame_ring_kernel<NTC, NS>, once.flag(), (size_t)NS * (ABLK + 32 * NTC * 64) * 2, grid, a, st); } while (0)
     if (res) {
         if (norm_w) { if (ntc == 3) FR_RES(3, 4, true); else if (ntc == 2) FR_RES(2, 6, true); else FR_RES(1, 6, true); }
         else { if (ntc == 3) FR_RES(3, 4, false); else if (ntc == 2) FR_RES(2, 6, false); else FR_RES(1, 6, false); }

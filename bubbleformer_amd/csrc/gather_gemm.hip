@@ -492,7 +492,7 @@ static int gather_gemm_launch(int dtype, const void* map, const void* patches, c
                      rows * ((reb ? 4.0 * 16 : 4.0 * C0) + N) * 2.0);
 #define BF_GG_GO(PRO, REB)                                                                                                                 \
     do {                                                                                                                                  \
-        static bool attr_done = false;                                                                                                    \
+        static BfPerDeviceOnce attr_once; bool& attr_done = attr_once.flag();                                                                                                    \
         if (!attr_done) {                                                                                                                 \
             hipError_t e_ = hipFuncSetAttribute((const void*)gather_gemm_kernel<6, 6, PRO, REB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
             if (e_ != hipSuccess) return bf_fail(e_, __FILE__, __LINE__);                                                                 \
@@ -542,7 +542,7 @@ extern "C" int bf_scatter_gemm(int dtype, const void* a, const void* w, int w_kn
     BfProfScope prof(st, sc ? "scatter_gemm<gelu>" : "scatter_gemm<plain>", 2.0 * rows * 4 * C0 * K, rows * (4.0 * C0 + K) * 2.0);
 #define BF_SG_GO(PRO)                                                                                                                      \
     do {                                                                                                                                  \
-        static bool attr_done = false;                                                                                                    \
+        static BfPerDeviceOnce attr_once; bool& attr_done = attr_once.flag();                                                                                                    \
         if (!attr_done) {                                                                                                                 \
             hipError_t e_ = hipFuncSetAttribute((const void*)scatter_gemm_kernel<3, 6, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
             if (e_ != hipSuccess) return bf_fail(e_, __FILE__, __LINE__);                                                                 \

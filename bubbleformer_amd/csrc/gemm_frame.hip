@@ -730,7 +730,7 @@ __global__ void __launch_bounds__(512) gemm_pair_kernel(PairArgs a) {
 
 template <int MODE>
 int launch_pair(const PairArgs& a, int M, hipStream_t st) {
-    static bool attr_done = false;
+    static BfPerDeviceOnce attr_once; bool& attr_done = attr_once.flag();
     if (!attr_done) {
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pair_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, PNSLOT * PSLOT_BYTES);
         if (e_ != hipSuccess) return bf_fail(e_, __FILE__, __LINE__);
@@ -814,9 +814,12 @@ static int inbwd_frames_impl2(int dtype, int M, int N, int K, const void* A, int
     }
     if (ch || sc2) return 1;
     if (S != FM) return 1;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_inbwd_frames_kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (attr != hipSuccess) return bf_fail(attr, __FILE__, __LINE__);
+    static BfPerDeviceOnce attr_once;
+    if (bool& done = attr_once.flag(); !done) {
+        const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_inbwd_frames_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (attr != hipSuccess) return bf_fail(attr, __FILE__, __LINE__);
+        done = true;
+    }
     hipStream_t st = (hipStream_t)stream;
     FrameArgs a;
     a.A = (const bf16*)A; a.lda = lda; a.B = (const bf16*)B; a.ldb = ldb; a.N = N; a.nk = K / FK; a.nt = N / FN;

@@ -628,7 +628,7 @@ int bf_gemm_stream_try(int M, int N, int K, const bf_operand* A, const bf_operan
     BfProfScope prof(st, pname, 2.0 * M * N * K, ((double)M * K + (double)N * K + (double)M * N * (E->gelu_out ? 2 : 1) + (E->aux_mode != BF_AUX_NONE ? (double)M * N : 0.0)) * 2.0);
 #define BF_STREAM_GO(AUXM, G2, CSF)                                                                                                       \
     do {                                                                                                                                \
-        static bool attr_done = false, attr_pp_done = false;                                                                            \
+        static BfPerDeviceOnce attr_once, attr_pp_once; bool& attr_done = attr_once.flag(); bool& attr_pp_done = attr_pp_once.flag();                                                                            \
         if (use_pp) {                                                                                                                   \
             if (!attr_pp_done) {                                                                                                        \
                 hipError_t e_ = hipFuncSetAttribute((const void*)stream_pp_kernel<AUXM, G2, CSF>, hipFuncAttributeMaxDynamicSharedMemorySize, PNSLOT * PSLOT); \

@@ -568,6 +568,9 @@ int bf_gemm_tokred_flush(hipStream_t st) {
     BF_CHECK_LAUNCH();
     return 0;
 }
+namespace { bool g_fold_off = false; }
+// test hook: run every slab sum as a launch of its own right behind its GEMM (the deferred entry point then behaves like bf_gemm_tokred)
+extern "C" void bf_debug_tokred_fold(int on) { g_fold_off = on == 0; }
 bool bf_gemm_tokred_pending() { return pending_slot().on; }
 const float* bf_gemm_tokred_pending_out() { const PendingRed& p = pending_slot(); return p.on ? p.r.out : nullptr; }      // whose sum is pending
 // as bf_gemm_tokred, but the slab sum may stay pending (see above); returns 0 / 1 / < 0 likewise.  A shape outside the ping-pong tiling, or a
@@ -620,7 +623,7 @@ static int tokred_impl(int dtype, int Nout, int Kin, int64_t M, const void* dy, 
         // deferred form: this launch's slabs go to one half of the workspace while a pending sum reads the other
         static const bool fold_on = bf_knob("BF_TOKRED_FOLD", 1) != 0;
         const int64_t half_floats = (ws_floats / 2) & ~(int64_t)3;
-        const bool fold = defer && fold_on && (int64_t)ns * (n + Nout) <= half_floats;
+        const bool fold = defer && fold_on && !g_fold_off && (int64_t)ns * (n + Nout) <= half_floats;
         PendingRed& pend = pending_slot();
         if (!fold && pend.on) { const int frc = bf_gemm_tokred_flush(st); if (frc) return frc; }      // (also: the immediate form may be about to overwrite its slabs)
         if (fold && pend.on && pend.NI != (big ? 6 : 3)) { const int frc = bf_gemm_tokred_flush(st); if (frc) return frc; }
@@ -639,7 +642,7 @@ static int tokred_impl(int dtype, int Nout, int Kin, int64_t M, const void* dy, 
             {                                                                                                                             \
                 BfProfScope prof(st, NIV == 6 ? "tokred_pp_kernel<384x192,h32,ring4>" : "tokred_pp_kernel<192x192,h32,ring4>",           \
                                  2.0 * Nout * Kin * (double)M, (double)M * (Nout + Kin) * 2.0 + (double)n * 4.0);                         \
-                static bool attr_done = false;                                                                                            \
+                static BfPerDeviceOnce attr_once; bool& attr_done = attr_once.flag();                                                                                            \
                 constexpr int lds_bytes = NBUF * PPGeom<NIV>::HALFB;                                                                      \
                 if (!attr_done) {                                                                                                         \
                     hipError_t e_ = hipFuncSetAttribute((const void*)tokred_pp_kernel<NIV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
@@ -676,7 +679,7 @@ static int tokred_impl(int dtype, int Nout, int Kin, int64_t M, const void* dy, 
     float* cslab = colsum ? ws + (size_t)ns * n : nullptr;
     {
         BfProfScope prof(st, "tokred_kernel<128x128,bk64,slots3>", 2.0 * Nout * Kin * (double)M, (double)M * (Nout + Kin) * 2.0 + (double)n * 4.0);
-        static bool attr_done = false;
+        static BfPerDeviceOnce attr_once; bool& attr_done = attr_once.flag();
         constexpr int lds_bytes = NSLOT * 2 * BK * TB * 2;
         if (!attr_done) {
             hipError_t e_ = hipFuncSetAttribute((const void*)tokred_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);

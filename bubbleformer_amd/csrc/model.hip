@@ -753,6 +753,7 @@ const void* g_tail_done_for = nullptr;
 // stage behind it (g_pending_reduce), whose own chained tail -- for the NEXT spatial stage, same scratch set -- must not overwrite them
 float* g_tail_ws = nullptr;
 bool g_tail_ws_flip = false;
+const void* g_tail_dx = nullptr;      // the gradient tensor the chained tail was computed from: the spatial backward must be handed exactly that one
 }  // namespace
 extern "C" int bf_stage_chain_tail(const bf_spatial_params* prev_p, const void* prev_saved, int has_drop_mlp) {
     g_next_tail.armed = prev_p && prev_saved;
@@ -905,7 +906,7 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
         }
         g_tail_done_for = nullptr;
         TRY(linear_bwd(d, sc, dqkv, 3 * d.E, sv.xn, d.E, BF_PRO_NONE, nullptr, nullptr, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk, &fu1, true));
-        if (tail_done) g_tail_done_for = h.saved;
+        if (tail_done) { g_tail_done_for = h.saved; g_tail_dx = dx; }
     } else
     TRY(linear_bwd(d, sc, dqkv, 3 * d.E, sv.xn, d.E, BF_PRO_NONE, nullptr, nullptr, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk, &fu1, true));
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws, (int)d.F, d.E, p->norm1_w, p->norm1_b, nullptr, 1, g->norm1_w, g->norm1_b, nullptr, nullptr, nullptr, nullptr};
@@ -1081,8 +1082,10 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     // out = x1 + gamma_mlp * IN(z)
     void* dz = sc.t1;
     ReduceJobs jobs;        // parameter-gradient reductions, all launched together at the end
-    const bool tail_done = g_tail_done_for == saved;      // the temporal stage behind left dz and the partial sums in place (bf_stage_chain_tail)
-    g_tail_done_for = nullptr;
+    // the temporal stage behind left dz and the partial sums in place (bf_stage_chain_tail) -- usable only if this call's dout IS the dx that stage
+    // wrote (another consumer of the stage's output, or a gradient hook, makes autograd hand over a different, summed tensor: recompute then)
+    const bool tail_done = g_tail_done_for == saved && g_tail_dx == dout;
+    g_tail_done_for = nullptr; g_tail_dx = nullptr;
     if (drop_mlp) {   // gtab[f][c] = drop_mlp[f] * gamma_mlp[c] was the scale: d gamma_mlp = sum_f drop_mlp[f] * (w s2 + b s1), folded in the reduction
         if (!tail_done)
             TRY(bf_in_bwd_partials(d.dtype, dout, sv.z, nullptr, dz, (int)d.F, (int)d.S, d.E, sv.mean3, sv.rstd3, p->mlp_norm_w, p->mlp_norm_b, sv.gtab, 1, 0, sc.in_ws3, st));

@@ -225,6 +225,9 @@ int bf_attn_bwd(int dtype, const void* qkv, const void* dout, void* dqkv, int64_
 void bf_side_defer(int on);
 int bf_side_join(bf_stream_t stream);
 void bf_debug_force_generic_attn(int on);
+/* test hook: 0 = every weight-gradient slab sum runs as a launch of its own right behind its GEMM; 1 (default) = inside the stage backwards it
+ * rides in the NEXT token-reduction launch (extra workgroups) -- the results are bit-identical either way */
+void bf_debug_tokred_fold(int on);
 
 int bf_im2col_nchw(int dtype, const float* x, void* out, int frames, int C, int H, int W, int Kp, bf_stream_t stream);
 int bf_col2im_nchw(int dtype, const void* g, float* dx, int frames, int C, int H, int W, int Kp, bf_stream_t stream);
