@@ -332,15 +332,35 @@ __global__ void frame_table_kernel(const float* __restrict__ m, int fdiv, const 
     out[i] = m[f / fdiv] * (v ? v[c] : 1.f);
 }
 
-// dst[c][r] = (bf16) src[r][c]: 8 consecutive r per thread (strided reads of a small weight, 16-byte stores)
-__device__ __forceinline__ void transpose_cast(const float* __restrict__ src, bf16* __restrict__ dst, int R, int C, long first, long stride) {
-    const long n8 = (long)C * (R / 8);
-    for (long i = first; i < n8; i += stride) {
-        const int c = (int)(i / (R / 8)), r0 = (int)(i % (R / 8)) * 8;
-        bf16x8 o;
+// dst[c][r] = (bf16) src[r][c] (R x C fp32 -> C x R bf16) in 64 x 64 tiles through LDS: coalesced 16-byte reads along c, 16-byte stores along r
+// (the first form read 8 rows per thread with a stride of C floats: every 4-byte read its own cache line -- 16x the bytes of the weight).
+// `tile0`, `tstride`: the calling workgroup's first tile and the tile stride (256 threads; R, C multiples of 64).
+__device__ __forceinline__ void transpose_cast(const float* __restrict__ src, bf16* __restrict__ dst, int R, int C, int tile0, int tstride) {
+    __shared__ float tl[64][65];
+    const int tr_ = (R + 63) / 64, tc_ = (C + 63) / 64;      // (R, C are multiples of 8: whole float4 reads, whole 8-row stores; edge tiles are partial)
+    const int tid = threadIdx.x;
+    for (int t = tile0; t < tr_ * tc_; t += tstride) {
+        const int r0 = (t / tc_) * 64, c0 = (t % tc_) * 64;
+        __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] = (bf16)src[(long)(r0 + q) * C + c];
-        *reinterpret_cast<bf16x8*>(dst + (long)c * R + r0) = o;
+        for (int k = 0; k < 4; ++k) {                  // 64 rows x 16 float4
+            const int i = tid + 256 * k, r = i >> 4, c4 = (i & 15) * 4;
+            if (r0 + r < R && c0 + c4 < C) {
+                const float4 v = *reinterpret_cast<const float4*>(src + (long)(r0 + r) * C + c0 + c4);
+                tl[r][c4] = v.x; tl[r][c4 + 1] = v.y; tl[r][c4 + 2] = v.z; tl[r][c4 + 3] = v.w;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {                  // 64 columns x 8 groups of 8 rows
+            const int i = tid + 256 * k, c = i >> 3, r8 = (i & 7) * 8;
+            if (c0 + c < C && r0 + r8 < R) {
+                bf16x8 o;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o[q] = (bf16)tl[r8 + q][c];
+                *reinterpret_cast<bf16x8*>(dst + (long)(c0 + c) * R + r0 + r8) = o;
+            }
+        }
     }
 }
 // up to four plain fp32 -> bf16 weight casts in ONE launch (a stage's projection weights)
@@ -358,7 +378,7 @@ __global__ void __launch_bounds__(256) cast4_kernel(Cast4 j) {
 // the same casts plus the out-projection fold (grid row cnt, one workgroup per output channel): a stage's parameter-only work in ONE launch
 __global__ void __launch_bounds__(256) stage_prep_kernel(Cast4 j, int cnt, PrepArgs a) {
     if ((int)blockIdx.y == cnt + 2) {          // transposed copy
-        if (a.tr_dst) transpose_cast(a.tr_src, (bf16*)a.tr_dst, a.tr_R, a.tr_C, (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256);
+        if (a.tr_dst) transpose_cast(a.tr_src, (bf16*)a.tr_dst, a.tr_R, a.tr_C, (int)blockIdx.x, (int)gridDim.x);
         return;
     }
     if ((int)blockIdx.y == cnt + 1) {
@@ -388,7 +408,7 @@ __global__ void __launch_bounds__(256) stage_prep_multi_kernel(PrepBatch b) {
     const Cast4& j = b.j[z];
     const PrepArgs& a = b.a[z];
     if ((int)blockIdx.y == cnt + 2) {
-        if (a.tr_dst) transpose_cast(a.tr_src, (bf16*)a.tr_dst, a.tr_R, a.tr_C, (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256);
+        if (a.tr_dst) transpose_cast(a.tr_src, (bf16*)a.tr_dst, a.tr_R, a.tr_C, (int)blockIdx.x, (int)gridDim.x);
         return;
     }
     if ((int)blockIdx.y == cnt + 1) {
