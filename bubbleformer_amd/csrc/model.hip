@@ -82,7 +82,7 @@ void epi_scatter(bf_epilogue& e, int gw, int gh, int C) { e.gw = gw; e.gh = gh; 
 
 int splitk_for(int M, int N, long K) {
     // the split-K partials are added with fp32 atomics, so splits cost write traffic in proportion to the output size.  An isolated
-    // sweep (tools/dw_sweep.py) prefers ~64/sqrt(tiles) slices, but inside the full step that loses 5% (A/B on the bench: 351 vs
+    // sweep prefers ~64/sqrt(tiles) slices, but inside the full step that loses 5% (A/B on the bench: 351 vs
     // 369 samples/s) to the rule below.
     const long tiles = (long)bf_cdiv(M, 128) * bf_cdiv(N, 128);
     static const long target = bf_knob("BF_SPLITK_TARGET", 256);
