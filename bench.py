@@ -257,7 +257,7 @@ def roofline_from(prof, nprof, dtype, config):
     tflops = flops / (avg_ms * 1e-3) / 1e12
     gbs = nbytes / (avg_ms * 1e-3) / 1e9
     traffic, src = None, None
-    tname = {"configs1": "r03_kernels.json", "configs4": "r02_rollout_kernels.json"}.get(config)     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
+    tname = {"configs1": "r04_kernels.json", "configs4": "r04_rollout_kernels.json"}.get(config)     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
     tpath = os.path.join(REPO, "profiles", tname) if tname else None
     if tpath and os.path.exists(tpath):
         for k in json.load(open(tpath))["kernels"]:
