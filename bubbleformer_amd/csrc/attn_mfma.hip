@@ -23,6 +23,11 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
 
+// All outstanding vector-memory operations complete, as an s_waitcnt the compiler's wait-count pass models (an inline-asm wait is opaque to
+// it).  In front of a loop that prefetches the next problem's rows: the pass merges the loop header's pending-load state from the preheader
+// and the back edge, and with the first problem's loads still pending there it counts every use of `cur` at the top of the body against
+// them -- vmcnt(7), vmcnt(6), ... right behind the eight NEW loads, i.e. a full memory round trip per problem and no look-ahead at all.
+__device__ __forceinline__ void drain_vm() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // vmcnt(0), expcnt / lgkmcnt untouched
 __device__ __forceinline__ void wsync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -78,12 +83,27 @@ __device__ __forceinline__ float dpp_add(float keep, float send) {
     return keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), CTRL, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float row16_scatter_sum(const float (&p)[16], int i16) {
-    const bool b3 = i16 & 8, b2 = i16 & 4, b1 = i16 & 2, b0 = i16 & 1;
-    float a[8], b[4], c[2];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = dpp_add<0x140>(b3 ? p[8 + j] : p[j], b3 ? p[j] : p[8 + j]);          // row_mirror: partner 15 - i
-#pragma unroll
-    for (int j = 0; j < 4; ++j) b[j] = dpp_add<0x141>(b2 ? a[4 + j] : a[j], b2 ? a[j] : a[4 + j]);          // row_half_mirror: partner i ^ 7
+    // The two wide steps (8 + 4 survivors) as bank-masked DPP adds: lanes whose index bit is 0 take own + partner's copy of the low half of the
+    // values, lanes whose bit is 1 the same of the high half -- both halves of a result register written by one v_add_f32_dpp each, no select,
+    // no separate v_mov_dpp (the compiler forms neither: bank masks have no builtin).  Bits 3 and 2 of the lane index are bank-aligned (a bank =
+    // four lanes); bits 1 and 0 are not, so the two narrow steps (2 + 1 survivors) stay selects.  s_nop: a DPP read of a VGPR a VALU op has
+    // just written needs two wait states (five after an EXEC write), and the compiler's hazard pass does not see inside the block.
+    float a0, a1, a2, a3, a4, a5, a6, a7, b[4];
+#define BF_M1(a, lo, hi) "v_add_f32_dpp " a ", " lo ", " lo " row_mirror row_mask:0xf bank_mask:0x3\n\t" \
+                         "v_add_f32_dpp " a ", " hi ", " hi " row_mirror row_mask:0xf bank_mask:0xc\n\t"
+#define BF_M2(b, lo, hi) "v_add_f32_dpp " b ", " lo ", " lo " row_half_mirror row_mask:0xf bank_mask:0x5\n\t" \
+                         "v_add_f32_dpp " b ", " hi ", " hi " row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+    asm("s_nop 4\n\t"
+        BF_M1("%4", "%12", "%20") BF_M1("%5", "%13", "%21") BF_M1("%6", "%14", "%22") BF_M1("%7", "%15", "%23")
+        BF_M1("%8", "%16", "%24") BF_M1("%9", "%17", "%25") BF_M1("%10", "%18", "%26") BF_M1("%11", "%19", "%27")
+        BF_M2("%0", "%4", "%8") BF_M2("%1", "%5", "%9") BF_M2("%2", "%6", "%10") BF_M2("%3", "%7", "%11")
+        : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6), "=&v"(a7)
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]),
+          "v"(p[8]), "v"(p[9]), "v"(p[10]), "v"(p[11]), "v"(p[12]), "v"(p[13]), "v"(p[14]), "v"(p[15]));
+#undef BF_M1
+#undef BF_M2
+    const bool b1 = i16 & 2, b0 = i16 & 1;
+    float c[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) c[j] = dpp_add<0x4E>(b1 ? b[2 + j] : b[j], b1 ? b[j] : b[2 + j]);           // quad_perm [2,3,0,1]: partner i ^ 2
     return dpp_add<0xB1>(b0 ? c[1] : c[0], b0 ? c[0] : c[1]);                                                // quad_perm [1,0,3,2]: partner i ^ 1
@@ -231,17 +251,12 @@ __device__ __forceinline__ bf16x8 tr_keys(const bf16* tile, int ld, int t, int l
     return cat(lo, hi);
 }
 // A operand = tile^T in natural k order (k = row 8g .. 8g+7).  A 16-row tile (NB == 1) has no rows 16..31: those
-// k-slots read (in-bounds) rows again and are then forced to zero -- every lane still executes the transposing read.
+// k-slots read (in-bounds, finite) rows again; the B operand it meets holds zeros in the same k-slots (columns 16..31 of the A^T / dS^T tiles).
 template <int NB>
 __device__ __forceinline__ bf16x8 tr_nat(const bf16* tile, int ld, int t, int lane) {
     const int g = lane >> 4;
     const int r0 = NB == 1 ? 8 * (g & 1) : 8 * g;
-    bf16x8 f = cat(tr4(tile, ld, r0, 16 * t, lane), tr4(tile, ld, r0 + 4, 16 * t, lane));
-    if (NB == 1 && g >= 2) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = (bf16)0.f;
-    }
-    return f;
+    return cat(tr4(tile, ld, r0, 16 * t, lane), tr4(tile, ld, r0 + 4, 16 * t, lane));
 }
 
 // stage L rows of `width` channels (global, 16-byte chunks) into a bf16 LDS tile [16*NB][ld]; rows >= L are zeroed
@@ -315,6 +330,7 @@ __global__ void __launch_bounds__(256) attn_fwd_mfma(const bf16* __restrict__ qk
     FwdRows<NB, KS> cur, nxt;
     Prob at = locate(g, heads, pr < nprob ? pr : 0), at_next = at;
     if (pr < nprob) load_fwd_rows<NB, KS>(cur, qkv, g, heads, at, lane);
+    if (PREFETCH) drain_vm();
     float mk[NB][NB][4], mneg[NB][NB][4];
     int eidx[NB][NB][4];
     lane_masks<NB>(L, lane, mk, mneg, eidx);
@@ -601,9 +617,11 @@ __device__ __forceinline__ void load_raw(RawRows<NB, KS>& r, const bf16* __restr
     }
 }
 
-template <int NB, int KS>
+// ACC >= 0: the accumulate mode as a compile-time constant (the training shapes: every `if (raw_in)` / `if (accumulate)` on a run-time flag
+// is otherwise compiled as compute-both-and-select, ~100 VALU instructions per problem in a VALU-bound loop); ACC < 0: the run-time argument.
+template <int NB, int KS, int ACC>
 __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_mfma(const bf16* __restrict__ qkv, const bf16* __restrict__ dout, bf16* __restrict__ dqkv, Geo g,
-                                                     int heads, Par p, Grd gr, float out_scale, int accumulate, float* __restrict__ ws) {
+                                                     int heads, Par p, Grd gr, float out_scale, int accumulate_rt, float* __restrict__ ws) {
     constexpr int D = 32 * KS, LD = D + 16, NT16 = D / 16, R = 16 * NB, LDP = 32 + 8, LDF = D + 4;
     constexpr bool PREFETCH = NB * KS <= 4;      // register budget: 16 * NB * KS VGPRs for the look-ahead rows
     extern __shared__ __attribute__((aligned(16))) bf16 smem_bwd[];
@@ -643,8 +661,8 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
     // respect to the LayerNorm outputs) and skip that backward and its parameter sums; bit 2 ("raw in", with bit 0) = the q / k values dqkv holds
     // are such raw gradients: they are added in front of the LayerNorm backward.  The LayerNorm backward is linear in its incoming gradient, so
     // the two axial passes over the same tokens (layers/attention.py:218-277) run it ONCE, on the sum: pass W with 2, pass H with 1 | 4.
-    const bool raw_out = accumulate & 2, raw_in = accumulate & 4;
-    accumulate &= 1;
+    const int mode = ACC >= 0 ? ACC : accumulate_rt;
+    const bool raw_out = mode & 2, raw_in = mode & 4, accumulate = mode & 1;
 
     // q/k LayerNorm parameter gradients: value v = ((2 * part + {dw: 0, db: 1}) * KS + ks) * 8 + j of channel group gq.  Each
     // problem's 16-row totals (DPP row reduction, VALU only) are deposited in lane (v & 15) of the row, slot v >> 4: 2 * KS
@@ -669,6 +687,7 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
     RawRows<NB, KS> cur, nxt;
     Prob at = locate(g, heads, pr < nprob ? pr : 0), at_next = at;
     if (pr < nprob) load_raw<NB, KS>(cur, qkv, dout, g, heads, at, lane);
+    if (PREFETCH) drain_vm();
     // lane-constant masks and T5 bucket offsets of this lane's (query, key) pairs: once, not per problem
     float mk[NB][NB][4], mneg[NB][NB][4];
     int eidx[NB][NB][4];
@@ -696,6 +715,11 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
                 }
 #pragma unroll
                 for (int t = 0; t < NT16; ++t) old.v[b][t] = *reinterpret_cast<const bf16x4*>(ob + 2 * D + 16 * t + 4 * gq);
+                if (raw_in && row >= L) {      // a clamped copy of row L - 1: must not reach the LayerNorm parameter sums
+                    const bf16x8 z8 = {};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) { old.q[b][ks] = z8; old.k[b][ks] = z8; }
+                }
             }
         }
         float xq[NB][KS][8], xk[NB][KS][8], rq[NB], rk[NB];
@@ -710,20 +734,16 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
             affine_frag<KS>(xq[b], s_par, s_par + D, scale, lane, qf[b]);
             rk[b] = ln_quad<KS>(xk[b], D);
             affine_frag<KS>(xk[b], s_par + 2 * D, s_par + 3 * D, 1.f, lane, kf[b]);
-            // Qn (with the d^-1/2 fold), Kn and dO tiles for the transposed operands; rows >= L read as zeros
+            // Qn (with the d^-1/2 fold), Kn and dO tiles for the transposed operands
             const int row = b * 16 + i16;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 vf[b][ks] = cur.v[b][ks];
                 df[b][ks] = cur.d[b][ks];
-                bf16x8 zq = qf[b][ks], zk = kf[b][ks], zd = df[b][ks];
-                if (row >= L) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { zq[j] = (bf16)0.f; zk[j] = (bf16)0.f; zd[j] = (bf16)0.f; }
-                }
-                *reinterpret_cast<bf16x8*>(qn_t + row * LD + 32 * ks + 8 * gq) = zq;
-                *reinterpret_cast<bf16x8*>(kn_t + row * LD + 32 * ks + 8 * gq) = zk;
-                *reinterpret_cast<bf16x8*>(do_t + row * LD + 32 * ks + 8 * gq) = zd;
+                // rows >= L hold copies of row L - 1 (finite): every product that reduces over them meets A = dS = 0 there (the masks mk)
+                *reinterpret_cast<bf16x8*>(qn_t + row * LD + 32 * ks + 8 * gq) = qf[b][ks];
+                *reinterpret_cast<bf16x8*>(kn_t + row * LD + 32 * ks + 8 * gq) = kf[b][ks];
+                *reinterpret_cast<bf16x8*>(do_t + row * LD + 32 * ks + 8 * gq) = df[b][ks];
             }
         }
         float P[NB][NB][4], A[NB][NB][4], dA[NB][NB][4];
@@ -867,8 +887,8 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float xh = part == 0 ? xq[b][ks][j] : xk[b][ks][j];
-                        float d0 = row < L ? raw[j] : 0.f;
-                        if (raw_in) d0 += row < L ? (float)(part == 0 ? old.q[b][ks][j] : old.k[b][ks][j]) : 0.f;      // the other pass's raw gradient
+                        float d0 = raw[j];      // rows >= L: exactly zero already (dS carries the masks)
+                        if (raw_in) d0 += (float)(part == 0 ? old.q[b][ks][j] : old.k[b][ks][j]);      // the other pass's raw gradient (zeroed for rows >= L above)
                         pw[ks][j] += d0 * xh;
                         pb[ks][j] += d0;
                         const float gg = d0 * w[32 * ks + 8 * gq + j];
@@ -984,13 +1004,13 @@ int go_fwd(const bf16* qkv, bf16* out, Geo g, int heads, Par p, float out_scale,
     BF_CHECK_LAUNCH();
     return 0;
 }
-template <int NB, int KS>
-int go_bwd(const bf16* qkv, const bf16* dout, bf16* dqkv, Geo g, int heads, Par p, Grd gr, float out_scale, int accumulate, float* ws,
-           long ws_floats, int* rows_out, hipStream_t st) {
+template <int NB, int KS, int ACC>
+int go_bwd_mode(const bf16* qkv, const bf16* dout, bf16* dqkv, Geo g, int heads, Par p, Grd gr, float out_scale, int accumulate, float* ws,
+                long ws_floats, int* rows_out, hipStream_t st) {
     constexpr int D = 32 * KS, R = 16 * NB;
     const int wpb = NB == 1 ? 4 : 2;
     const size_t shm = (size_t)wpb * (3 * R * (D + 16) + 2 * R * 40) * sizeof(bf16);
-    if (int rc = set_lds(attn_bwd_mfma<NB, KS>, shm)) return rc;
+    if (int rc = set_lds(attn_bwd_mfma<NB, KS, ACC>, shm)) return rc;
     const long nprob = g.nseq * heads;
     BF_REQUIRE(nprob < (1L << 31) && g.inner < (1L << 31), "attention: problem count must fit 31 bits");
     const int nvals = 4 * D + 32 * heads + heads;
@@ -1000,7 +1020,7 @@ int go_bwd(const bf16* qkv, const bf16* dout, bf16* dqkv, Geo g, int heads, Par 
         int dev = 0, cus = 256, per_cu = 1;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, attn_bwd_mfma<NB, KS>, wpb * 64, shm) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, attn_bwd_mfma<NB, KS, ACC>, wpb * 64, shm) != hipSuccess || per_cu < 1) per_cu = 1;
         static const int bpc = bf_knob("BF_ATTN_BWD_BPC", 0);
         if (bpc > 0) per_cu = bpc;
         resident = cus * per_cu;
@@ -1013,7 +1033,7 @@ int go_bwd(const bf16* qkv, const bf16* dout, bf16* dqkv, Geo g, int heads, Par 
         if (grid >= 8 * m) grid -= grid % m;
     }
     if (ws && ws_floats < grid * nvals) { grid = ws_floats / nvals; if (grid < 1) ws = nullptr; }
-    hipLaunchKernelGGL((attn_bwd_mfma<NB, KS>), dim3((int)grid), dim3(wpb * 64), shm, st, qkv, dout, dqkv, g, heads, p, gr, out_scale, accumulate, ws);
+    hipLaunchKernelGGL((attn_bwd_mfma<NB, KS, ACC>), dim3((int)grid), dim3(wpb * 64), shm, st, qkv, dout, dqkv, g, heads, p, gr, out_scale, accumulate, ws);
     BF_CHECK_LAUNCH();
     if (rows_out) { *rows_out = ws ? (int)grid : 0; return 0; }       // the caller reduces the workspace rows later (AttnReduceJob)
     if (ws) {
@@ -1022,6 +1042,16 @@ int go_bwd(const bf16* qkv, const bf16* dout, bf16* dqkv, Geo g, int heads, Par 
         BF_CHECK_LAUNCH();
     }
     return 0;
+}
+template <int NB, int KS>
+int go_bwd(const bf16* qkv, const bf16* dout, bf16* dqkv, Geo g, int heads, Par p, Grd gr, float out_scale, int accumulate, float* ws,
+           long ws_floats, int* rows_out, hipStream_t st) {
+#define BF_MODE(A) return go_bwd_mode<NB, KS, A>(qkv, dout, dqkv, g, heads, p, gr, out_scale, accumulate, ws, ws_floats, rows_out, st)
+    if (NB == 1 && KS == 2) {      // FiLMAViT-small's head width, sequences of <= 16 tokens: one instantiation per mode
+        switch (accumulate) { case 0: BF_MODE(0); case 1: BF_MODE(1); case 2: BF_MODE(2); case 5: BF_MODE(5); default: break; }
+    }
+    BF_MODE(-1);
+#undef BF_MODE
 }
 
 }  // namespace
