@@ -592,7 +592,7 @@ __global__ void __launch_bounds__(64 * WPB) attn_fwd_axial_mfma(const bf16* __re
 // channels 32*s + 8*g .. +7 of row i.  The backward loads the NEXT problem's rows while it works on the current one: a wave runs
 // ~20 dependent phases per problem, and with only two waves per SIMD every exposed global round trip is paid in full.
 template <int NB, int KS> struct RawRows { bf16x8 q[NB][KS], k[NB][KS], v[NB][KS], d[NB][KS]; };
-template <int NB, int KS> struct OldRows { bf16x8 q[NB][KS], k[NB][KS]; bf16x4 v[NB][2 * KS]; };
+template <int NB, int KS> struct OldRows { bf16x8 q[NB][KS], k[NB][KS], v[NB][KS]; };
 
 template <int NB, int KS>
 __device__ __forceinline__ void load_raw(RawRows<NB, KS>& r, const bf16* __restrict__ qkv, const bf16* __restrict__ dout, const Geo& g, int heads, const Prob& at,
@@ -622,7 +622,7 @@ __device__ __forceinline__ void load_raw(RawRows<NB, KS>& r, const bf16* __restr
 template <int NB, int KS, int ACC>
 __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_mfma(const bf16* __restrict__ qkv, const bf16* __restrict__ dout, bf16* __restrict__ dqkv, Geo g,
                                                      int heads, Par p, Grd gr, float out_scale, int accumulate_rt, float* __restrict__ ws) {
-    constexpr int D = 32 * KS, LD = D + 16, NT16 = D / 16, R = 16 * NB, LDP = 32 + 8, LDF = D + 4;
+    constexpr int D = 32 * KS, LD = D + 16, NT16 = D / 16, R = 16 * NB, LDP = 32 + 8;
     constexpr bool PREFETCH = NB * KS <= 4;      // register budget: 16 * NB * KS VGPRs for the look-ahead rows
     extern __shared__ __attribute__((aligned(16))) bf16 smem_bwd[];
     __shared__ float s_demb[32 * 16];
@@ -633,15 +633,15 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
     __shared__ float s_emb[32 * 16];
     __shared__ float s_hsc[16];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;      // provably wave-uniform: problem bookkeeping in SGPRs
-    // per-wave: Qn, Kn, dO tiles [R][LD] bf16; A^T and dS^T tiles [R][LDP] bf16 ([key j][query i]); fp32 re-layout buffer aliases the tiles
+    // per-wave: Qn, Kn, dO tiles [R][LD] bf16; A^T and dS^T tiles [R][LDP] bf16 ([key j][query i])
     constexpr int PER_WAVE = 3 * R * LD + 2 * R * LDP;
-    static_assert(3 * R * LD * 2 >= R * LDF * 4, "re-layout buffer must fit in the operand tiles");
+    static_assert(3 * R * LD * 2 >= 4 * D * 4, "the parameter-gradient flush must fit in the operand tiles");
     bf16* qn_t = smem_bwd + wave * PER_WAVE;
     bf16* kn_t = qn_t + R * LD;
     bf16* do_t = kn_t + R * LD;
     bf16* at_t = do_t + R * LD;
     bf16* ds_t = at_t + R * LDP;
-    float* relay = reinterpret_cast<float*>(qn_t);
+    float* relay = reinterpret_cast<float*>(qn_t);      // end of the kernel only: this wave's LayerNorm parameter sums on their way to the block total
     for (int i = threadIdx.x; i < 32 * 16; i += blockDim.x) {
         s_demb[i] = 0.f;
         const int t = i >> 4, h = i & 15;
@@ -712,9 +712,8 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
                 for (int ks = 0; ks < KS; ++ks) {
                     old.q[b][ks] = *reinterpret_cast<const bf16x8*>(ob + 32 * ks + 8 * gq);
                     old.k[b][ks] = *reinterpret_cast<const bf16x8*>(ob + D + 32 * ks + 8 * gq);
+                    old.v[b][ks] = *reinterpret_cast<const bf16x8*>(ob + 2 * D + 32 * ks + 8 * gq);
                 }
-#pragma unroll
-                for (int t = 0; t < NT16; ++t) old.v[b][t] = *reinterpret_cast<const bf16x4*>(ob + 2 * D + 16 * t + 4 * gq);
                 if (raw_in && row >= L) {      // a clamped copy of row L - 1: must not reach the LayerNorm parameter sums
                     const bf16x8 z8 = {};
 #pragma unroll
@@ -740,10 +739,16 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
             for (int ks = 0; ks < KS; ++ks) {
                 vf[b][ks] = cur.v[b][ks];
                 df[b][ks] = cur.d[b][ks];
-                // rows >= L hold copies of row L - 1 (finite): every product that reduces over them meets A = dS = 0 there (the masks mk)
-                *reinterpret_cast<bf16x8*>(qn_t + row * LD + 32 * ks + 8 * gq) = qf[b][ks];
-                *reinterpret_cast<bf16x8*>(kn_t + row * LD + 32 * ks + 8 * gq) = kf[b][ks];
-                *reinterpret_cast<bf16x8*>(do_t + row * LD + 32 * ks + 8 * gq) = df[b][ks];
+                // rows >= L hold copies of row L - 1 (finite): every product that reduces over them meets A = dS = 0 there (the masks mk).
+                // Column order of the tiles: this lane's channels 32 ks + 8 g + j go to column 16 (2 ks + (j >> 2)) + 4 g + (j & 3).  The
+                // products below put tile column 16 t + 4 g + r in register r of lane group g, so with this order a lane gets dQ / dK / dV
+                // for exactly the channels whose xhat it holds (t = 2 ks + (j >> 2), r = j & 3): the LayerNorm backward needs no re-layout
+                // through LDS, and the gradient rows leave as 16-byte stores.
+#define BF_HALVES(tile, v) { \
+                    *reinterpret_cast<bf16x4*>(tile + row * LD + 32 * ks + 4 * gq) = __builtin_shufflevector(v, v, 0, 1, 2, 3); \
+                    *reinterpret_cast<bf16x4*>(tile + row * LD + 32 * ks + 16 + 4 * gq) = __builtin_shufflevector(v, v, 4, 5, 6, 7); }
+                BF_HALVES(qn_t, qf[b][ks]) BF_HALVES(kn_t, kf[b][ks]) BF_HALVES(do_t, df[b][ks])
+#undef BF_HALVES
             }
         }
         float P[NB][NB][4], A[NB][NB][4], dA[NB][NB][4];
@@ -799,6 +804,7 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
         // ---- dV^T[e][j] = sum_i dO[i][e] A[i][j]   and   dKn^T[e][j] = sum_i Qn[i][e] dS[i][j]      (k = query i, natural order)
         // ---- dQn^T[e][i] = sum_j Kn[j][e] dS[i][j]                                                (k-slots in key order)
         float dq[NB][NT16][4], dk[NB][NT16][4];
+        f32x4 dv_even[NB];
 #pragma unroll
         for (int t = 0; t < NT16; ++t) {
             const bf16x8 doT = tr_nat<NB>(do_t, LD, t, lane);
@@ -814,16 +820,19 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
                 const f32x4 dkk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qnT, sB, z, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dk[jb][t][r] = dkk[r];     // Qn tile carries d^-1/2 already
-                const int j = 16 * jb + i16;
-                if (j < L) {    // dV: lane (key j, channels 16t + 4g + r) -> 8-byte store
-                    bf16* dst = dqkv + (tok0 + j * g.tok_stride) * 3L * E + head * 3 * D + 2 * D + 16 * t + 4 * gq;
-                    float v[4] = {dv[0] * out_scale, dv[1] * out_scale, dv[2] * out_scale, dv[3] * out_scale};
-                    if (accumulate) {
+                if (!(t & 1)) dv_even[jb] = dv;
+                else {      // dV: lane (key j, channels 32 ks + 8 g .. + 7), ks = t >> 1 -> 16-byte store
+                    const int j = 16 * jb + i16, ks = t >> 1;
+                    if (j < L) {
+                        bf16x8 o;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += (float)old.v[jb][t][r];
+                        for (int r = 0; r < 4; ++r) {
+                            float lo = dv_even[jb][r] * out_scale, hi = dv[r] * out_scale;
+                            if (accumulate) { lo += (float)old.v[jb][ks][r]; hi += (float)old.v[jb][ks][4 + r]; }
+                            o[r] = (bf16)lo; o[4 + r] = (bf16)hi;
+                        }
+                        *reinterpret_cast<bf16x8*>(dqkv + (tok0 + j * g.tok_stride) * 3L * E + head * 3 * D + 2 * D + 32 * ks + 8 * gq) = o;
                     }
-                    const bf16x4 w4 = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                    *reinterpret_cast<bf16x4*>(dst) = w4;
                 }
             }
 #pragma unroll
@@ -834,40 +843,31 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
                 for (int r = 0; r < 4; ++r) dq[ib][t][r] = dqq[r] * scale;
             }
         }
-        wsync();   // all transposed reads of the tiles are done: the tiles become the fp32 re-layout buffer
-        if (raw_out) {      // the first of two passes over these tokens: the gradients with respect to the LayerNorm outputs, as they stand (8-byte stores)
+        // dq[b][2 ks + (j >> 2)][j & 3] / dk[..] are this lane's gradients for channel 32 ks + 8 g + j of row 16 b + (l & 15) (see the tile writes)
+        if (raw_out) {      // the first of two passes over these tokens: the gradients with respect to the LayerNorm outputs, as they stand
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const int row = 16 * b + i16;
                 if (row < L) {
-                    bf16* dst = dqkv + (tok0 + row * g.tok_stride) * 3L * E + head * 3 * D + 4 * gq;
+                    bf16* dst = dqkv + (tok0 + row * g.tok_stride) * 3L * E + head * 3 * D + 8 * gq;
 #pragma unroll
-                    for (int t = 0; t < NT16; ++t) {
-                        float vq[4] = {dq[b][t][0], dq[b][t][1], dq[b][t][2], dq[b][t][3]}, vk[4] = {dk[b][t][0], dk[b][t][1], dk[b][t][2], dk[b][t][3]};
-                        if (accumulate) {
-                            const bf16x4 oq = *reinterpret_cast<const bf16x4*>(dst + 16 * t), ok = *reinterpret_cast<const bf16x4*>(dst + D + 16 * t);
+                    for (int ks = 0; ks < KS; ++ks) {
+                        bf16x8 oq, ok;
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) { vq[r] += (float)oq[r]; vk[r] += (float)ok[r]; }
+                        for (int j = 0; j < 8; ++j) {
+                            float vq = dq[b][2 * ks + (j >> 2)][j & 3], vk = dk[b][2 * ks + (j >> 2)][j & 3];
+                            if (accumulate) { vq += (float)old.q[b][ks][j]; vk += (float)old.k[b][ks][j]; }
+                            oq[j] = (bf16)vq; ok[j] = (bf16)vk;
                         }
-                        const bf16x4 a4 = {(bf16)vq[0], (bf16)vq[1], (bf16)vq[2], (bf16)vq[3]}, b4 = {(bf16)vk[0], (bf16)vk[1], (bf16)vk[2], (bf16)vk[3]};
-                        *reinterpret_cast<bf16x4*>(dst + 16 * t) = a4;
-                        *reinterpret_cast<bf16x4*>(dst + D + 16 * t) = b4;
+                        *reinterpret_cast<bf16x8*>(dst + 32 * ks) = oq;
+                        *reinterpret_cast<bf16x8*>(dst + D + 32 * ks) = ok;
                     }
                 }
             }
         } else
-        // ---- LayerNorm backward in the operand layout, q then k
+        // ---- LayerNorm backward, q then k: two independent register-only chains
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-#pragma unroll
-                for (int t = 0; t < NT16; ++t) {
-                    const float4 v4 = part == 0 ? make_float4(dq[b][t][0], dq[b][t][1], dq[b][t][2], dq[b][t][3])
-                                                : make_float4(dk[b][t][0], dk[b][t][1], dk[b][t][2], dk[b][t][3]);
-                    *reinterpret_cast<float4*>(relay + (16 * b + i16) * LDF + 16 * t + 4 * gq) = v4;
-                }
-            wsync();
             const float* w = part == 0 ? s_par : s_par + 2 * D;
             float pw[KS][8], pb[KS][8];
 #pragma unroll
@@ -881,13 +881,10 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
                 float m1 = 0.f, m2 = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const float4 lo = *reinterpret_cast<const float4*>(relay + row * LDF + 32 * ks + 8 * gq);
-                    const float4 hi = *reinterpret_cast<const float4*>(relay + row * LDF + 32 * ks + 8 * gq + 4);
-                    const float raw[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float xh = part == 0 ? xq[b][ks][j] : xk[b][ks][j];
-                        float d0 = raw[j];      // rows >= L: exactly zero already (dS carries the masks)
+                        float d0 = part == 0 ? dq[b][2 * ks + (j >> 2)][j & 3] : dk[b][2 * ks + (j >> 2)][j & 3];      // rows >= L: exactly zero (dS carries the masks)
                         if (raw_in) d0 += (float)(part == 0 ? old.q[b][ks][j] : old.k[b][ks][j]);      // the other pass's raw gradient (zeroed for rows >= L above)
                         pw[ks][j] += d0 * xh;
                         pb[ks][j] += d0;
@@ -929,8 +926,8 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
                     a_ln[part * KS + gi] += row16_scatter_sum(grp, i16);
                 }
             }
-            wsync();
         }
+        wsync();   // this problem's transposed reads of the tiles sit in front of the next problem's writes
         if (PREFETCH) cur = nxt;
         else if (more) load_raw<NB, KS>(cur, qkv, dout, g, heads, at_next, lane);
         at = at_next;
