@@ -1044,7 +1044,7 @@ template <int NB, int KS>
 int go_bwd(const bf16* qkv, const bf16* dout, bf16* dqkv, Geo g, int heads, Par p, Grd gr, float out_scale, int accumulate, float* ws,
            long ws_floats, int* rows_out, hipStream_t st) {
 #define BF_MODE(A) return go_bwd_mode<NB, KS, A>(qkv, dout, dqkv, g, heads, p, gr, out_scale, accumulate, ws, ws_floats, rows_out, st)
-    if (NB == 1 && KS == 2) {      // FiLMAViT-small's head width, sequences of <= 16 tokens: one instantiation per mode
+    if constexpr (NB == 1 && KS == 2) {      // FiLMAViT-small's head width, sequences of <= 16 tokens: one instantiation per mode
         switch (accumulate) { case 0: BF_MODE(0); case 1: BF_MODE(1); case 2: BF_MODE(2); case 5: BF_MODE(5); default: break; }
     }
     BF_MODE(-1);
