@@ -77,6 +77,12 @@ struct BfPerDeviceOnce {
     bool done[64] = {};
     bool& flag() { int dev = 0; (void)hipGetDevice(&dev); return done[(dev >= 0 && dev < 64) ? dev : 0]; }
 };
+// host-side state that links one library call to the next (chain hints, pending work, alternating buffers): one instance per device, so that
+// a process driving several devices (one stream of stage calls each) does not cross them
+template <class T> struct BfPerDevice {
+    T tab[64] = {};
+    T& get() { int dev = 0; (void)hipGetDevice(&dev); return tab[(dev >= 0 && dev < 64) ? dev : 0]; }
+};
 int bf_fail(hipError_t e, const char* file, int line);
 int bf_fail_msg(const char* msg, const char* file, int line);
 int bf_decline(const char* msg);      // returns 1 (shape not covered) and records why

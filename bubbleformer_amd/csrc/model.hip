@@ -556,7 +556,7 @@ struct Scratch {
 // ------------------------------------------------------------------------------------------------ stage-end parameter reductions
 // All InstanceNorm / attention parameter-gradient reductions of one stage backward in ONE launch (grid z = job): nothing on the
 // critical path reads them, and eight dependent ~5 us launches per block are worth ~3 % of the step.
-struct ReduceJobs { int n_in = 0, n_attn = 0; InReduceJob in[6]; AttnReduceJob at[4]; };      // room for a spatial + a temporal stage (see g_pending_reduce)
+struct ReduceJobs { int n_in = 0, n_attn = 0; InReduceJob in[6]; AttnReduceJob at[4]; };      // room for a spatial + a temporal stage (see g_pending_reduce.get())
 __global__ void __launch_bounds__(256) stage_param_reduce_kernel(ReduceJobs J) {
     __shared__ float red[5][4][64];
     const int z = blockIdx.z;
@@ -584,17 +584,17 @@ int launch_reduce_jobs(ReduceJobs& J, hipStream_t st) {
 // Deferred mode (bf_side_defer): the spatial stage's reductions wait for the temporal stage's backward that follows it and ride in ITS launch
 // (one launch per block pair instead of two: 12 launches less on the caller's queue per step).  The two stages use different scratch sets, so
 // the spatial stage's partial sums are intact until the next spatial stage, which flushes a leftover first -- as does every full join.
-ReduceJobs g_pending_reduce;
-bool g_pending_reduce_on = false;
+BfPerDevice<ReduceJobs> g_pending_reduce;
+BfPerDevice<bool> g_pending_reduce_on;
 int flush_pending_reduce(hipStream_t st) {
-    if (!g_pending_reduce_on) return 0;
-    g_pending_reduce_on = false;
-    return launch_reduce_jobs(g_pending_reduce, st);
+    if (!g_pending_reduce_on.get()) return 0;
+    g_pending_reduce_on.get() = false;
+    return launch_reduce_jobs(g_pending_reduce.get(), st);
 }
 int launch_with_pending(ReduceJobs& J, hipStream_t st) {
-    if (g_pending_reduce_on) {
-        g_pending_reduce_on = false;
-        const ReduceJobs& P = g_pending_reduce;
+    if (g_pending_reduce_on.get()) {
+        g_pending_reduce_on.get() = false;
+        const ReduceJobs& P = g_pending_reduce.get();
         for (int i = 0; i < P.n_in && J.n_in < 6; ++i) J.in[J.n_in++] = P.in[i];
         for (int i = 0; i < P.n_attn && J.n_attn < 4; ++i) J.at[J.n_attn++] = P.at[i];
     }
@@ -623,11 +623,11 @@ int outproj_gemm(const D& d, const void* on, const void* w_c, const float* alpha
     return bf_gemm(d.dtype, (int)d.N, d.E, d.E, &A, &Bo, &e, 1, st);
 }
 // scratch set of a trunk backward stage: deferred mode alternates, so that the side stream may still read the previous stage's set
-int g_scratch_parity = 0;
+BfPerDevice<int> g_scratch_parity;
 void* bwd_scratch(const D& d, void* scratch) {
     if (!g_side_defer || !side_stream()) return scratch;
-    g_scratch_parity ^= 1;
-    return (char*)scratch + (size_t)g_scratch_parity * Scratch(d, nullptr).bytes;
+    g_scratch_parity.get() ^= 1;
+    return (char*)scratch + (size_t)g_scratch_parity.get() * Scratch(d, nullptr).bytes;
 }
 // A data gradient dy @ W whose consumer is the backward of the InstanceNorm that fed the projection: when a frame is one
 // 144-row GEMM tile the two run as ONE kernel (gemm_frame.hip); otherwise GEMM into `tmp`, then the InstanceNorm backward.
@@ -759,25 +759,27 @@ extern "C" int bf_side_join(bf_stream_t s) { return side_join_pending((hipStream
 // opening InstanceNorm(out) behind in the same launch (norm.hip, InChain).  bf_stage_chain_head arms it with the next temporal stage's
 // parameters and saved record; the stage that consumed it remembers the record, and that stage's forward skips its own norm1.
 namespace {
-struct NextHead { bool armed = false; const float *w = nullptr, *b = nullptr; float *mean = nullptr, *rstd = nullptr, *sc = nullptr, *sh = nullptr; void* xn = nullptr; const void* saved = nullptr; } g_next_head;
-const void* g_head_done_for = nullptr;
+struct NextHead { bool armed = false; const float *w = nullptr, *b = nullptr; float *mean = nullptr, *rstd = nullptr, *sc = nullptr, *sh = nullptr; void* xn = nullptr; const void* saved = nullptr; };
+BfPerDevice<NextHead> g_next_head;
+BfPerDevice<const void*> g_head_done_for;
 }  // namespace
 // ... and the mirror image in the backward: the temporal stage's last kernel (QKV data gradient + norm1 backward) produces the output
 // gradient of the spatial stage in front of it, whose backward opens with its MLP-branch InstanceNorm.  bf_stage_chain_tail arms that
 // norm's backward (the spatial stage's parameters, saved record and whether its MLP branch carried stochastic depth) for the temporal
 // backward called next; the spatial backward on the same record then finds dz and the partial sums in place.
 namespace {
-struct NextTail { bool armed = false; const bf_spatial_params* p = nullptr; const void* saved = nullptr; bool drop = false; } g_next_tail;
-const void* g_tail_done_for = nullptr;
+struct NextTail { bool armed = false; const bf_spatial_params* p = nullptr; const void* saved = nullptr; bool drop = false; };
+BfPerDevice<NextTail> g_next_tail;
+BfPerDevice<const void*> g_tail_done_for;
 // where the chained tail left the norm's partial sums.  Two regions, alternating: the spatial stage's reduction of them waits for the temporal
-// stage behind it (g_pending_reduce), whose own chained tail -- for the NEXT spatial stage, same scratch set -- must not overwrite them
-float* g_tail_ws = nullptr;
-bool g_tail_ws_flip = false;
-const void* g_tail_dx = nullptr;      // the gradient tensor the chained tail was computed from: the spatial backward must be handed exactly that one
+// stage behind it (g_pending_reduce.get()), whose own chained tail -- for the NEXT spatial stage, same scratch set -- must not overwrite them
+BfPerDevice<float*> g_tail_ws;
+BfPerDevice<bool> g_tail_ws_flip;
+BfPerDevice<const void*> g_tail_dx;     // the gradient tensor the chained tail was computed from: the spatial backward must be handed exactly that one
 }  // namespace
 extern "C" int bf_stage_chain_tail(const bf_spatial_params* prev_p, const void* prev_saved, int has_drop_mlp) {
-    g_next_tail.armed = prev_p && prev_saved;
-    g_next_tail.p = prev_p; g_next_tail.saved = prev_saved; g_next_tail.drop = has_drop_mlp != 0;
+    g_next_tail.get().armed = prev_p && prev_saved;
+    g_next_tail.get().p = prev_p; g_next_tail.get().saved = prev_saved; g_next_tail.get().drop = has_drop_mlp != 0;
     return 0;
 }
 // Stochastic depth in the backward: a temporal stage multiplies its incoming gradient by its per-sample factors before anything else reads it.
@@ -786,32 +788,41 @@ extern "C" int bf_stage_chain_tail(const bf_spatial_params* prev_p, const void* 
 // temporal backward finds it in place (one elementwise launch and one read of the gradient less per block).  Two buffers, alternating: the
 // temporal stage's side-stream work may still read its copy while the next spatial stage writes the next one.
 namespace {
-struct NextScale { const float* f = nullptr; int fdiv = 1; } g_next_scale;
-struct DbrReady { const void* dx = nullptr; const float* f = nullptr; void* buf = nullptr; } g_dbr_ready;
-bool g_dbr_flip = false;
+struct NextScale { const float* f = nullptr; int fdiv = 1; };
+BfPerDevice<NextScale> g_next_scale;
+struct DbrReady { const void* dx = nullptr; const float* f = nullptr; void* buf = nullptr; };
+BfPerDevice<DbrReady> g_dbr_ready;
+BfPerDevice<bool> g_dbr_flip;
 }  // namespace
+// A forward pass starts at the embed and a backward pass at the debed: what an aborted pass left armed (a hint whose consumer never ran, a
+// "done for" record whose address a later allocation may reuse) must not survive into the next one.
+static void links_clear(bool forward_side) {
+    if (forward_side) { g_next_head.get().armed = false; g_head_done_for.get() = nullptr; }
+    g_next_tail.get().armed = false; g_tail_done_for.get() = nullptr; g_tail_dx.get() = nullptr;
+    g_next_scale.get() = NextScale{}; g_dbr_ready.get() = DbrReady{};
+}
 extern "C" int bf_stage_next_scale(const float* factors, int fdiv) {
-    g_next_scale.f = factors; g_next_scale.fdiv = fdiv > 0 ? fdiv : 1;
+    g_next_scale.get().f = factors; g_next_scale.get().fdiv = fdiv > 0 ? fdiv : 1;
     return 0;
 }
 extern "C" int bf_stage_chain_next(const bf_dims* dims, int next_kind, const void* next_params, void* next_saved) {
-    g_next_head.armed = false;
+    g_next_head.get().armed = false;
     if (!dims || !next_params || !next_saved) return 0;     // disarm
     BF_REQUIRE(next_kind == 0 || next_kind == 1, "bf_stage_chain_next: kind must be 0 (temporal) or 1 (spatial)");
     D d; TRY(get_dims(dims, &d));
     if (next_kind == 0) {
         const bf_temporal_params* np = (const bf_temporal_params*)next_params;
         TemporalSaved sv(d, next_saved);
-        g_next_head.w = np->norm1_w; g_next_head.b = np->norm1_b;
-        g_next_head.mean = sv.mean1; g_next_head.rstd = sv.rstd1; g_next_head.sc = sv.sc1; g_next_head.sh = sv.sh1; g_next_head.xn = sv.xn;
+        g_next_head.get().w = np->norm1_w; g_next_head.get().b = np->norm1_b;
+        g_next_head.get().mean = sv.mean1; g_next_head.get().rstd = sv.rstd1; g_next_head.get().sc = sv.sc1; g_next_head.get().sh = sv.sh1; g_next_head.get().xn = sv.xn;
     } else {
         const bf_spatial_params* np = (const bf_spatial_params*)next_params;
         SpatialSaved sv(d, next_saved);
-        g_next_head.w = np->norm1_w; g_next_head.b = np->norm1_b;
-        g_next_head.mean = sv.mean1; g_next_head.rstd = sv.rstd1; g_next_head.sc = sv.sc1; g_next_head.sh = sv.sh1; g_next_head.xn = sv.xn;
+        g_next_head.get().w = np->norm1_w; g_next_head.get().b = np->norm1_b;
+        g_next_head.get().mean = sv.mean1; g_next_head.get().rstd = sv.rstd1; g_next_head.get().sc = sv.sc1; g_next_head.get().sh = sv.sh1; g_next_head.get().xn = sv.xn;
     }
-    g_next_head.saved = next_saved;
-    g_next_head.armed = true;
+    g_next_head.get().saved = next_saved;
+    g_next_head.get().armed = true;
     return 0;
 }
 extern "C" int bf_stage_chain_head(const bf_dims* dims, const bf_temporal_params* next_p, void* next_saved) {
@@ -841,7 +852,7 @@ extern "C" int bf_temporal_fwd(const bf_dims* dims, const bf_temporal_params* p,
         else TRY(wviews(d, 2, src, dst, n, out, st, &prep));
         win_c = out[0]; wout_c = out[1];
     }
-    if (g_head_done_for == saved) g_head_done_for = nullptr;      // the stage in front left norm1's statistics and xn behind (bf_stage_chain_head)
+    if (g_head_done_for.get() == saved) g_head_done_for.get() = nullptr;      // the stage in front left norm1's statistics and xn behind (bf_stage_chain_head)
     else
         TRY(bf_in_stats_apply(d.dtype, x, (int)d.F, (int)d.S, d.E, p->norm1_w, p->norm1_b, nullptr, 1, nullptr, sv.mean1, sv.rstd1, sv.sc1, sv.sh1, sc.in_ws,
                               nullptr, sv.xn, st));
@@ -851,15 +862,15 @@ extern "C" int bf_temporal_fwd(const bf_dims* dims, const bf_temporal_params* p,
                     p->knorm_w, p->knorm_b, p->rel_pos_emb, d.attn_scale ? p->attn_scale_factor : nullptr, 1.f, 0, st));
     TRY(bf_in_stats_apply(d.dtype, sv.o, (int)d.F, (int)d.S, d.E, p->norm2_w, p->norm2_b, nullptr, 1, nullptr, sv.mean2, sv.rstd2, sv.sc2, sv.sh2, sc.in_ws,
                           nullptr, sv.on, st));
-    if (g_next_head.armed) {      // the stage behind opens with InstanceNorm(out): it rides in the out-projection's launch (bf_stage_chain_next)
-        const NextHead h = g_next_head;
-        g_next_head.armed = false;
-        g_head_done_for = nullptr;
+    if (g_next_head.get().armed) {      // the stage behind opens with InstanceNorm(out): it rides in the out-projection's launch (bf_stage_chain_next)
+        const NextHead h = g_next_head.get();
+        g_next_head.get().armed = false;
+        g_head_done_for.get() = nullptr;
         const bf_frame_norm n2{h.w, h.b, nullptr, 1, h.mean, h.rstd, h.sc, h.sh, nullptr, h.xn};
         const int rc = bf_gemm_fwd_frames(d.dtype, (int)d.N, d.E, d.E, sv.on, d.E, sv.wout_t, d.E, nullptr, sv.alpha, sv.beta, drop, d.T, x, out, (int)d.S,
                                           nullptr, &n2, s);
         if (rc < 0) return rc;
-        if (rc == 0) { g_head_done_for = h.saved; return 0; }
+        if (rc == 0) { g_head_done_for.get() = h.saved; return 0; }
     }
     TRY(outproj_gemm(d, sv.on, wout_c, sv.alpha, sv.beta, x, out, drop, (long)d.T * d.S, st));   // mask per batch element
     return 0;
@@ -873,7 +884,7 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
     TemporalSaved sv(d, saved);
     Scratch sc(d, bwd_scratch(d, scratch));
     const void* win_c = d.dtype == BF_DTYPE_F32 ? (const void*)p->input_head_w : sv.win_c;
-    Fork fk(st, true, g_scratch_parity);      // weight-gradient GEMMs go to the side stream; nothing they read (dbr, t3, s1) is rewritten before the join
+    Fork fk(st, true, g_scratch_parity.get());      // weight-gradient GEMMs go to the side stream; nothing they read (dbr, t3, s1) is rewritten before the join
     if (fk.deferred) TRY(side_join_pending(st, fk.set));      // the stage before the previous one used this scratch set
     void* don = sc.t1;      // [N][E]
     void* dO = sc.t1b;      // [N][E]
@@ -882,13 +893,13 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
     // stream instead was measured twice and lost: EXPERIMENTS.md)
     const void* dbr = dout;
     if (drop) {
-        if (g_dbr_ready.dx == dout && g_dbr_ready.f == drop && g_dbr_ready.buf) dbr = g_dbr_ready.buf;      // the stage in front left the scaled copy behind
+        if (g_dbr_ready.get().dx == dout && g_dbr_ready.get().f == drop && g_dbr_ready.get().buf) dbr = g_dbr_ready.get().buf;      // the stage in front left the scaled copy behind
         else {
             TRY(bf_frame_scale(d.dtype, dout, drop, d.T, sc.t4, d.N, (int)d.S, d.E, st));
             dbr = sc.t4;
         }
     }
-    g_dbr_ready = DbrReady{};
+    g_dbr_ready.get() = DbrReady{};
     const InFuse fu2{sv.o, nullptr, dO, sv.mean2, sv.rstd2, p->norm2_w, p->norm2_b, sc.in_ws2};      // don @ ... then norm2's backward -> dO
     TRY(outproj_bwd(d, sc, dbr, sv.on, sv.wout_s, p->output_head_w, p->output_head_b, p->norm2_b, p->gamma, nullptr, nullptr,
                     sv.alpha, sv.mc, g->output_head_w, g->output_head_b, nullptr, g->gamma, nullptr, nullptr, don, st, fk, &fu2));
@@ -910,23 +921,23 @@ extern "C" int bf_temporal_bwd(const bf_dims* dims, const bf_temporal_params* p,
     // spatial stage itself would at its start).
     TailNorm tn;
     bool tail_done = false;
-    if (g_next_tail.armed) {
-        const NextTail h = g_next_tail;
-        g_next_tail.armed = false;
+    if (g_next_tail.get().armed) {
+        const NextTail h = g_next_tail.get();
+        g_next_tail.get().armed = false;
         static const bool chain_on = bf_knob("BF_BWD_CHAIN", 1) != 0;
         if (chain_on && fk.deferred && d.dtype == BF_DTYPE_BF16 && d.S == 144 && d.F % 2 == 0) {
-            const int oset = g_scratch_parity ^ 1;
+            const int oset = g_scratch_parity.get() ^ 1;
             TRY(side_join_pending(st, oset));
             Scratch so(d, (char*)scratch + (size_t)oset * Scratch(d, nullptr).bytes);
             SpatialSaved ps(d, const_cast<void*>(h.saved));
-            tn = TailNorm{ps.z, so.t1, ps.mean3, ps.rstd3, h.p->mlp_norm_w, h.drop ? ps.gtab : h.p->gamma_mlp, h.drop ? 1 : (int)d.F, g_tail_ws_flip ? so.in_ws5 : so.in_ws4, &tail_done};
-            g_tail_ws = tn.ws;
-            g_tail_ws_flip = !g_tail_ws_flip;
+            tn = TailNorm{ps.z, so.t1, ps.mean3, ps.rstd3, h.p->mlp_norm_w, h.drop ? ps.gtab : h.p->gamma_mlp, h.drop ? 1 : (int)d.F, g_tail_ws_flip.get() ? so.in_ws5 : so.in_ws4, &tail_done};
+            g_tail_ws.get() = tn.ws;
+            g_tail_ws_flip.get() = !g_tail_ws_flip.get();
             fu1.tail = &tn;
         }
-        g_tail_done_for = nullptr;
+        g_tail_done_for.get() = nullptr;
         TRY(linear_bwd(d, sc, dqkv, 3 * d.E, sv.xn, d.E, BF_PRO_NONE, nullptr, nullptr, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk, &fu1, true));
-        if (tail_done) { g_tail_done_for = h.saved; g_tail_dx = dx; }
+        if (tail_done) { g_tail_done_for.get() = h.saved; g_tail_dx.get() = dx; }
     } else
     TRY(linear_bwd(d, sc, dqkv, 3 * d.E, sv.xn, d.E, BF_PRO_NONE, nullptr, nullptr, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk, &fu1, true));
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws, (int)d.F, d.E, p->norm1_w, p->norm1_b, nullptr, 1, g->norm1_w, g->norm1_b, nullptr, nullptr, nullptr, nullptr};
@@ -989,8 +1000,8 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
                               const float* drop_att, const float* drop_mlp, bf_stream_t s) {
     D d; TRY(get_dims(dims, &d));
     BF_REQUIRE(p && x && out && saved && scratch, "bf_spatial_fwd: null pointer");
-    const bool head_done = g_head_done_for == saved;      // the temporal stage in front left norm1's statistics and xn behind (bf_stage_chain_next)
-    g_head_done_for = nullptr;         // (a chained head is consumed by the stage called right after the stage that made it)
+    const bool head_done = g_head_done_for.get() == saved;      // the temporal stage in front left norm1's statistics and xn behind (bf_stage_chain_next)
+    g_head_done_for.get() = nullptr;         // (a chained head is consumed by the stage called right after the stage that made it)
     hipStream_t st = (hipStream_t)s;
     TRY(side_join_pending(st));
     SpatialSaved sv(d, saved);
@@ -1051,14 +1062,14 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
     }
     if (d.dtype == BF_DTYPE_BF16) {      // z = hid @ W2^T + b2, the MLP-branch norm + residual and (armed) the next stage's opening norm in ONE launch
         const bf_frame_norm n1{p->mlp_norm_w, p->mlp_norm_b, g3, g3div, sv.mean3, sv.rstd3, sv.sc3, sv.sh3, sv.x1, out};
-        const NextHead h = g_next_head;
+        const NextHead h = g_next_head.get();
         const bf_frame_norm n2{h.w, h.b, nullptr, 1, h.mean, h.rstd, h.sc, h.sh, nullptr, h.xn};
         const int rc = bf_gemm_fwd_frames(d.dtype, (int)d.N, d.E, 4 * d.E, sv.hid, 4L * d.E, sv.w2t_c, d.E, p->fc2_b, nullptr, nullptr, nullptr, 1, nullptr, sv.z,
                                           (int)d.S, &n1, h.armed ? &n2 : nullptr, s);
         if (rc < 0) return rc;
         if (rc == 0) {
-            g_next_head.armed = false;
-            g_head_done_for = h.armed ? h.saved : nullptr;
+            g_next_head.get().armed = false;
+            g_head_done_for.get() = h.armed ? h.saved : nullptr;
             return 0;
         }
     }
@@ -1069,13 +1080,13 @@ extern "C" int bf_spatial_fwd(const bf_dims* dims, const bf_spatial_params* p, c
         e.bias = p->fc2_b;
         TRY(bf_gemm(d.dtype, (int)d.N, d.E, 4 * d.E, &A, &Bo, &e, 1, st));
     }
-    if (g_next_head.armed) {
-        const NextHead h = g_next_head;
-        g_next_head.armed = false;
+    if (g_next_head.get().armed) {
+        const NextHead h = g_next_head.get();
+        g_next_head.get().armed = false;
         bool chained = false;
         TRY(bf_in_stats_apply_chain(d.dtype, sv.z, (int)d.F, (int)d.S, d.E, p->mlp_norm_w, p->mlp_norm_b, g3, g3div, nullptr, sv.mean3, sv.rstd3, sv.sc3, sv.sh3,
                                     sc.in_ws, sv.x1, out, h.w, h.b, h.mean, h.rstd, h.sc, h.sh, h.xn, &chained, st));
-        g_head_done_for = chained ? h.saved : nullptr;
+        g_head_done_for.get() = chained ? h.saved : nullptr;
         return 0;
     }
     TRY(bf_in_stats_apply(d.dtype, sv.z, (int)d.F, (int)d.S, d.E, p->mlp_norm_w, p->mlp_norm_b, g3, g3div, nullptr, sv.mean3, sv.rstd3,
@@ -1097,25 +1108,25 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     // weight-gradient GEMMs go to the side stream and are joined at the end; every buffer they read (dz = t1, dpre = t4,
     // dx1 = t1b, dbr = e5, dqkv = t3, s1) is written once per call, so the critical path below never recycles one under them.
     TRY(flush_pending_reduce(st));      // (a spatial stage that no temporal stage followed: its partial sums live in the set this stage is about to use)
-    Fork fk(st, true, g_scratch_parity);
+    Fork fk(st, true, g_scratch_parity.get());
     if (fk.deferred) TRY(side_join_pending(st, fk.set));      // the stage before the previous one used this scratch set
     // out = x1 + gamma_mlp * IN(z)
     void* dz = sc.t1;
     ReduceJobs jobs;        // parameter-gradient reductions, all launched together at the end
     // the temporal stage behind left dz and the partial sums in place (bf_stage_chain_tail) -- usable only if this call's dout IS the dx that stage
     // wrote (another consumer of the stage's output, or a gradient hook, makes autograd hand over a different, summed tensor: recompute then)
-    const bool tail_done = g_tail_done_for == saved && g_tail_dx == dout;
-    g_tail_done_for = nullptr; g_tail_dx = nullptr;
+    const bool tail_done = g_tail_done_for.get() == saved && g_tail_dx.get() == dout;
+    g_tail_done_for.get() = nullptr; g_tail_dx.get() = nullptr;
     if (drop_mlp) {   // gtab[f][c] = drop_mlp[f] * gamma_mlp[c] was the scale: d gamma_mlp = sum_f drop_mlp[f] * (w s2 + b s1), folded in the reduction
         if (!tail_done)
             TRY(bf_in_bwd_partials(d.dtype, dout, sv.z, nullptr, dz, (int)d.F, (int)d.S, d.E, sv.mean3, sv.rstd3, p->mlp_norm_w, p->mlp_norm_b, sv.gtab, 1, 0, sc.in_ws3, st));
-        jobs.in[jobs.n_in++] = InReduceJob{tail_done ? g_tail_ws : sc.in_ws3, (int)d.F, d.E, p->mlp_norm_w, p->mlp_norm_b, sv.gtab, 1, g->mlp_norm_w, g->mlp_norm_b, nullptr, nullptr,
+        jobs.in[jobs.n_in++] = InReduceJob{tail_done ? g_tail_ws.get() : sc.in_ws3, (int)d.F, d.E, p->mlp_norm_w, p->mlp_norm_b, sv.gtab, 1, g->mlp_norm_w, g->mlp_norm_b, nullptr, nullptr,
                                            drop_mlp, g->gamma_mlp};
     } else {
         if (!tail_done)
             TRY(bf_in_bwd_partials(d.dtype, dout, sv.z, nullptr, dz, (int)d.F, (int)d.S, d.E, sv.mean3, sv.rstd3, p->mlp_norm_w, p->mlp_norm_b, p->gamma_mlp,
                                    (int)d.F, 0, sc.in_ws3, st));
-        jobs.in[jobs.n_in++] = InReduceJob{tail_done ? g_tail_ws : sc.in_ws3, (int)d.F, d.E, p->mlp_norm_w, p->mlp_norm_b, p->gamma_mlp, (int)d.F, g->mlp_norm_w, g->mlp_norm_b,
+        jobs.in[jobs.n_in++] = InReduceJob{tail_done ? g_tail_ws.get() : sc.in_ws3, (int)d.F, d.E, p->mlp_norm_w, p->mlp_norm_b, p->gamma_mlp, (int)d.F, g->mlp_norm_w, g->mlp_norm_b,
                                            g->gamma_mlp, nullptr, nullptr, nullptr};
     }
     // fc2: z = gelu(pre) @ W2^T + b2 ; dpre = (dz @ W2) * gelu'(pre)
@@ -1173,19 +1184,19 @@ extern "C" int bf_spatial_bwd(const bf_dims* dims, const bf_spatial_params* p, c
     void* dxn = sc.e6;      // don is dead (it was only read on this stream)
     InFuse fu1{x, dx1, dx, sv.mean1, sv.rstd1, p->norm1_w, p->norm1_b, sc.in_ws};              // dqkv @ W_in, then norm1's backward + residual
     bool scaled_done = false;
-    const NextScale ns = g_next_scale;
-    g_next_scale = NextScale{};
-    g_dbr_ready = DbrReady{};
+    const NextScale ns = g_next_scale.get();
+    g_next_scale.get() = NextScale{};
+    g_dbr_ready.get() = DbrReady{};
     static const bool scaled_on = bf_knob("BF_BWD_SCALED_COPY", 1) != 0;
     if (ns.f && scaled_on && fk.deferred && d.dtype == BF_DTYPE_BF16) {
-        fu1.scaled_out = (char*)scratch + 2 * Scratch(d, nullptr).bytes + (g_dbr_flip ? dbr_bytes(d) : 0);
+        fu1.scaled_out = (char*)scratch + 2 * Scratch(d, nullptr).bytes + (g_dbr_flip.get() ? dbr_bytes(d) : 0);
         fu1.scaled_f = ns.f; fu1.scaled_fdiv = ns.fdiv; fu1.scaled_done = &scaled_done;
     }
     TRY(linear_bwd(d, sc, dqkv, 3 * d.E, sv.xn, d.E, BF_PRO_NONE, nullptr, nullptr, win_c, g->input_head_w, g->input_head_b, dxn, nullptr, st, fk, &fu1, true));
-    if (scaled_done) { g_dbr_ready = DbrReady{dx, ns.f, fu1.scaled_out}; g_dbr_flip = !g_dbr_flip; }
+    if (scaled_done) { g_dbr_ready.get() = DbrReady{dx, ns.f, fu1.scaled_out}; g_dbr_flip.get() = !g_dbr_flip.get(); }
     jobs.in[jobs.n_in++] = InReduceJob{sc.in_ws, (int)d.F, d.E, p->norm1_w, p->norm1_b, nullptr, 1, g->norm1_w, g->norm1_b, nullptr, nullptr, nullptr, nullptr};
     static const bool merge_on = bf_knob("BF_REDUCE_MERGE", 1) != 0;
-    if (fk.deferred && merge_on) { g_pending_reduce = jobs; g_pending_reduce_on = true; }      // rides in the next temporal stage's launch (or the next join)
+    if (fk.deferred && merge_on) { g_pending_reduce.get() = jobs; g_pending_reduce_on.get() = true; }      // rides in the next temporal stage's launch (or the next join)
     else TRY(launch_reduce_jobs(jobs, st));
     return fk.join();
 }
@@ -1473,14 +1484,14 @@ extern "C" int64_t bf_debed_saved_bytes(const bf_dims* s) { D d; if (get_dims(s,
 
 // saved records whose stage-0 map was NOT stored by the forward (host-side memory of a per-call decision; the record itself is device memory)
 namespace {
-std::vector<const void*> g_embed_lean;
+BfPerDevice<std::vector<const void*>> g_embed_lean;
 void embed_lean_set(const void* saved, bool lean) {
-    for (size_t i = 0; i < g_embed_lean.size(); ++i)
-        if (g_embed_lean[i] == saved) { if (!lean) { g_embed_lean[i] = g_embed_lean.back(); g_embed_lean.pop_back(); } return; }
-    if (lean) g_embed_lean.push_back(saved);
+    for (size_t i = 0; i < g_embed_lean.get().size(); ++i)
+        if (g_embed_lean.get()[i] == saved) { if (!lean) { g_embed_lean.get()[i] = g_embed_lean.get().back(); g_embed_lean.get().pop_back(); } return; }
+    if (lean) g_embed_lean.get().push_back(saved);
 }
 bool embed_lean_get(const void* saved) {
-    for (const void* p : g_embed_lean) if (p == saved) return true;
+    for (const void* p : g_embed_lean.get()) if (p == saved) return true;
     return false;
 }
 }  // namespace
@@ -1490,6 +1501,7 @@ extern "C" int bf_embed_fwd(const bf_dims* dims, const bf_embed_params* p, const
     BF_REQUIRE(p && x && out && saved && scratch && d.nst >= 1 && d.cin >= 1, "bf_embed_fwd: bad arguments");
     BF_REQUIRE((d.nfluid > 0) == (fluid != nullptr), "bf_embed_fwd: fluid parameters must be given exactly when nfluid > 0");
     hipStream_t st = (hipStream_t)s;
+    links_clear(true);
     TRY(side_join_pending(st));
     EmbedSaved sv(d, saved);
     Scratch sc(d, scratch);
@@ -1516,7 +1528,7 @@ extern "C" int bf_embed_fwd(const bf_dims* dims, const bf_embed_params* p, const
             static const bool part_on = bf_knob("BF_EMBED_STATS", 1) != 0;
             const bool part_ok = part_on && n > 1 && bf_in_ws_floats(d.dtype, (int)d.F, S0, sv.C[0]) >= (int64_t)2 * d.F * sv.C[0] * (1 + (S0 + 255) / 256);      // the sliced workspace holds 256-row slices
             // lean: the stage-0 map is W0 . patch -- when every consumer of this call's saved record can rebuild its rows (the streaming
-            // stage-1 kernels, the one-pass backward tail) it is not stored at all; g_embed_lean remembers the decision for the backward
+            // stage-1 kernels, the one-pass backward tail) it is not stored at all; g_embed_lean.get() remembers the decision for the backward
             static const bool lean_on = bf_knob("BF_EMBED_LEAN", 1) != 0;
             // ... and only when the BACKWARD kernels that rebuild the rows will take this frame count with the workspaces this call's scratch holds
             // (the one-pass tail's partials live in the token-reduction workspace, the rebuilt-rows weight gradient's slabs in t1b: a batch of
@@ -1773,6 +1785,7 @@ extern "C" int bf_debed_bwd(const bf_dims* dims, const bf_debed_params* p, const
     BF_REQUIRE(p && g && x && dx && saved && scratch && d.nst >= 1, "bf_debed_bwd: bad arguments");
     BF_REQUIRE(dpred || (pred && target), "bf_debed_bwd: need dpred or (pred, target) of the fused loss");
     hipStream_t st = (hipStream_t)s;
+    links_clear(false);
     TRY(side_join_pending(st));
     DebedSaved sv(d, saved);
     Scratch sc(d, scratch);

@@ -109,7 +109,8 @@ int bf_gemm_inbwd_frames(int dtype, int M, int N, int K, const void* A, int64_t 
 /* ... and the backward of a SECOND InstanceNorm applied to `out` in the same launch: the norm whose output gradient `out` is (in the model: the
  * MLP-branch norm of the spatial stage in front of a temporal stage, autograd of layers/attention.py:305-317 behind :77-78).  cz: that norm's
  * input rows, cmean / crstd its statistics [frames][N], cw its weight, cg an optional post scale [frames / cgdiv][N] (layer scale, or the
- * stochastic-depth table).  cdz = crstd cw cg (out - (s1 + xh s2) / S), xh = (cz - cmean) crstd; partials {s1, s2} to cws (ws layout).
+ * stochastic-depth table).  cdz = crstd cw cg (out - (s1 + xh s2) / S), xh = (cz - cmean) crstd; partials {s1, s2} to cws (ws layout; cws may
+ * be null: the sums are then not kept).  cz / cdz are [M][N] with row stride N (the x / out stride).
  * Returns 1 (nothing launched) where the two-frames-per-tile kernel does not apply (S != 144, odd frame counts, fp32). */
 int bf_gemm_inbwd_frames_chain(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, const void* x,
                                const void* add, void* out, int S, const float* mean, const float* rstd, const float* w, float* ws,
