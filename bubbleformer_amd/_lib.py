@@ -149,6 +149,8 @@ SIGNATURES = {
     "bf_eikonal_l1_frames": (C.c_int, [fp, i64, C.c_int, C.c_int, f32, fp, vp]),
     "bf_heatflux_rows": (C.c_int, [fp, fp, i64, i64, C.c_int, f32, f32, f32, f32, fp, vp]),
     "bf_clip_gather": (C.c_int, [fp, i64, vp, vp, C.c_int, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "bf_clip_gather_batch": (C.c_int, [fp, i64, vp, i64, vp, vp, fp, fp, C.c_int, C.c_int, fp, vp, fp, fp, C.c_int, C.c_int, fp, fp, vp, C.c_int, fp,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "bf_temporal_saved_bytes": (i64, [P(Dims)]),
     "bf_spatial_saved_bytes": (i64, [P(Dims)]),
     "bf_embed_saved_bytes": (i64, [P(Dims)]),

@@ -1035,6 +1035,68 @@ extern "C" int bf_clip_gather(const float* src, int64_t field_stride, const int3
     return 0;
 }
 
+// A training batch in ONE launch: the input clips (frames first .. first + Tin - 1), the target clips (the Tout frames behind them) and the
+// per-sample fluid-parameter rows, all indexed by SAMPLE number on the device (first_tab / file_tab: absolute first frame and file of every
+// sample of the dataset) -- what took two launches and three index kernels of the host framework (first_tab[idx], file_tab[idx], fluid[...]).
+struct ClipSeg { const int* field; const float* diff; const float* dv; float* out; int T, C, t0; };
+__global__ void __launch_bounds__(NT) clip_gather_batch_kernel(const float* __restrict__ src, long field_stride, const long* __restrict__ idx, long nsamples,
+                                                              const long* __restrict__ first_tab, ClipSeg a, ClipSeg b,
+                                                              const float* __restrict__ fluid_tab, const long* __restrict__ file_tab, int P,
+                                                              float* __restrict__ fluid_out, int B, int H, int W, int Ho, int Wo) {
+    const int wq = (Wo + 3) / 4;
+    const long per_a = (long)a.T * a.C * Ho * wq, per_b = (long)b.T * b.C * Ho * wq, per = per_a + per_b;
+    const long total = (long)B * per;
+    const float sy = (float)H / (float)Ho, sx = (float)W / (float)Wo;
+    const bool ident = Ho == H && Wo == W;
+    if (fluid_out && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < B * P; i += NT) fluid_out[i] = fluid_tab[file_tab[min(max(idx[i / P], 0L), nsamples - 1)] * P + i % P];
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int bb = (int)(i / per);
+        long r = i - (long)bb * per;
+        const bool second = r >= per_a;
+        if (second) r -= per_a;
+        const ClipSeg& sg = second ? b : a;
+        const int xq = (int)(r % wq); r /= wq;
+        const int yo = (int)(r % Ho); r /= Ho;
+        const int c = (int)(r % sg.C);
+        const int t = (int)(r / sg.C);
+        const int ys = ident ? yo : min((int)floorf((float)yo * sy), H - 1);
+        const long smp = min(max(idx[bb], 0L), nsamples - 1);      // an index out of range reads a valid sample, never past a table
+        const float* row = src + (long)sg.field[c] * field_stride + ((first_tab[smp] + sg.t0 + t) * H + ys) * (long)W;
+        float* dst = sg.out + ((((long)bb * sg.T + t) * sg.C + c) * Ho + yo) * (long)Wo + 4 * xq;
+        const float d = sg.diff[c], q = sg.dv[c];
+        if (ident && (W & 3) == 0) {
+            const float4 v = *reinterpret_cast<const float4*>(row + 4 * xq);
+            *reinterpret_cast<float4*>(dst) = make_float4((v.x - d) / q, (v.y - d) / q, (v.z - d) / q, (v.w - d) / q);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int xo = 4 * xq + j;
+                if (xo < Wo) {
+                    const int xs = ident ? xo : min((int)floorf((float)xo * sx), W - 1);
+                    dst[j] = (row[xs] - d) / q;
+                }
+            }
+        }
+    }
+}
+extern "C" int bf_clip_gather_batch(const float* src, int64_t field_stride, const int64_t* idx, int64_t nsamples, const int64_t* first_tab, const int32_t* in_field,
+                                    const float* in_diff, const float* in_div, int Cin, int Tin, float* in_out, const int32_t* out_field,
+                                    const float* out_diff, const float* out_div, int Cout, int Tout, float* out_out, const float* fluid_tab,
+                                    const int64_t* file_tab, int P, float* fluid_out, int B, int H, int W, int Ho, int Wo, bf_stream_t stream) {
+    BF_REQUIRE(src && idx && first_tab && in_field && in_diff && in_div && in_out && out_field && out_diff && out_div && out_out,
+               "bf_clip_gather_batch: null pointer");
+    BF_REQUIRE(nsamples > 0 && B > 0 && Tin > 0 && Tout > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && Ho <= H && Wo <= W, "bf_clip_gather_batch: bad sizes");
+    BF_REQUIRE(!fluid_out || (fluid_tab && file_tab && P > 0), "bf_clip_gather_batch: the fluid rows need their table, the file table and P > 0");
+    BF_REQUIRE(((uintptr_t)src % 16 == 0) && ((uintptr_t)in_out % 16 == 0) && ((uintptr_t)out_out % 16 == 0), "bf_clip_gather_batch: buffers must be 16-byte aligned");
+    const ClipSeg a{(const int*)in_field, in_diff, in_div, in_out, Tin, Cin, 0}, b{(const int*)out_field, out_diff, out_div, out_out, Tout, Cout, Tin};
+    const long total = (long)B * ((long)Tin * Cin + (long)Tout * Cout) * Ho * ((Wo + 3) / 4);
+    hipLaunchKernelGGL(clip_gather_batch_kernel, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, src, (long)field_stride, (const long*)idx, (long)nsamples,
+                       (const long*)first_tab, a, b, fluid_tab, (const long*)file_tab, P, fluid_out, B, H, W, Ho, Wo);
+    BF_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------- Lion (Chen et al. 2023, "Symbolic Discovery of Optimization
 // Algorithms"; the update lion_pytorch.Lion applies at bubbleformer/modules.py:139-140):
 //   p *= 1 - lr*wd;  p -= lr * sign(b1*m + (1-b1)*g);  m = b2*m + (1-b2)*g

@@ -235,9 +235,13 @@ class DeviceClipStore:
             if host.numel() and (int(host.min()) < 0 or int(host.max()) >= len(ds)):
                 raise IndexError("sample index out of range")
             idx = host.pin_memory().to(self.device, non_blocking=True) if self.device.type == "cuda" else host.to(self.device)
-        first = first_all[idx]
         tw, f = ds.time_window, ds.downsample_factor
         ho, wo = (self.H // f, self.W // f) if f > 1 else (self.H, self.W)
+        if self.device.type == "cuda":       # one launch: both clips and the fluid rows, indexed by sample number on the device
+            inp, out, fl = ops.clip_gather_batch(self.frames, idx.contiguous(), first_all, tw, self.in_tab, self.out_tab, ho, wo,
+                                                 self.fluid, file_all if self.fluid is not None else None)
+            return (inp, out, fl) if self.fluid is not None else (inp, out)
+        first = first_all[idx]
         inp = ops.clip_gather(self.frames, first, 0, tw, self.in_tab, ho, wo)
         out = ops.clip_gather(self.frames, first, tw, tw, self.out_tab, ho, wo)
         if self.fluid is not None:

@@ -891,6 +891,25 @@ def clip_gather(frames: torch.Tensor, first: torch.Tensor, t0: int, T: int, tabl
     return out
 
 
+def clip_gather_batch(frames: torch.Tensor, idx: torch.Tensor, first_tab: torch.Tensor, T: int, in_table, out_table, Ho: int, Wo: int,
+                      fluid_tab: Optional[torch.Tensor] = None, file_tab: Optional[torch.Tensor] = None):
+    """One launch for a batch: idx [B] int64 sample numbers (device), first_tab / file_tab per-sample tables (device) -> input clips
+    (B, T, Cin, Ho, Wo), target clips (B, T, Cout, Ho, Wo) and, when fluid_tab is given, the (B, P) fluid-parameter rows."""
+    _require_gpu(frames)
+    (iid, idf, idv), (oid, odf, odv) = in_table, out_table
+    nf, total, H, W = frames.shape
+    B = idx.numel()
+    inp = torch.empty((B, T, iid.numel(), Ho, Wo), dtype=torch.float32, device=frames.device)
+    out = torch.empty((B, T, oid.numel(), Ho, Wo), dtype=torch.float32, device=frames.device)
+    P = int(fluid_tab.shape[1]) if fluid_tab is not None else 0
+    fl = torch.empty((B, P), dtype=torch.float32, device=frames.device) if fluid_tab is not None else None
+    L.check(L.lib().bf_clip_gather_batch(_p(frames), total * H * W, _p(idx), first_tab.numel(), _p(first_tab), _p(iid), _p(idf), _p(idv), iid.numel(), T, _p(inp),
+                                         _p(oid), _p(odf), _p(odv), oid.numel(), T, _p(out), _p(fluid_tab) if fl is not None else None,
+                                         _p(file_tab) if fl is not None else None, P, _p(fl) if fl is not None else None, B, H, W, Ho, Wo,
+                                         _stream()), "bf_clip_gather_batch")
+    return inp, out, fl
+
+
 def lion_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, lr: float, betas=(0.9, 0.99), weight_decay: float = 0.0,
           grad_scale: float = 1.0) -> None:
     """Fused Lion over flat fp32 buffers (lion_pytorch.Lion semantics, bubbleformer/modules.py:139-140)."""

@@ -324,6 +324,15 @@ int bf_adamw(float* p, const float* g, float* m, float* v, int64_t n, int step, 
  * (yo, xo) when Ho x Wo < H x W (F.interpolate(mode="nearest") index rule), identity otherwise.  out is (B, T, C, Ho, Wo) fp32. */
 int bf_clip_gather(const float* src, int64_t field_stride, const int32_t* field, const int64_t* first, int t0, const float* diff,
                    const float* div, float* out, int B, int T, int C, int H, int W, int Ho, int Wo, bf_stream_t stream);
+/* The same for a whole training batch in one launch, indexed by SAMPLE number on the device: idx [B] (int64; clamped to 0 .. nsamples - 1 in the
+ * kernel, so a bad index reads another sample, never past a table), first_tab / file_tab [nsamples] = absolute first input frame and file of every sample.  in_out (B, Tin, Cin, Ho, Wo) = frames
+ * first .. first + Tin - 1 of the input fields, out_out (B, Tout, Cout, Ho, Wo) = the Tout frames behind them of the output fields (each with
+ * its own field ids and constants), fluid_out (B, P) = fluid_tab[file_tab[idx[b]]] (optional: fluid_out may be null).
+ * Replaces BubbleForecast.__getitem__ + the DataLoader's collate for a batch (bubbleformer/data/dataset.py:120-182). */
+int bf_clip_gather_batch(const float* src, int64_t field_stride, const int64_t* idx, int64_t nsamples, const int64_t* first_tab, const int32_t* in_field,
+                         const float* in_diff, const float* in_div, int Cin, int Tin, float* in_out, const int32_t* out_field,
+                         const float* out_diff, const float* out_div, int Cout, int Tout, float* out_out, const float* fluid_tab,
+                         const int64_t* file_tab, int P, float* fluid_out, int B, int H, int W, int Ho, int Wo, bf_stream_t stream);
 /* Normalisation statistics of device-resident trajectories (BubbleForecast.normalize, bubbleformer/data/dataset.py:74-117: mean / std / min /
  * max of every full field of every file): segment i = seg_len[i] floats at src + seg_begin[i] (both arrays on the DEVICE);
  * out[i] = {sum, sum of squares, min, max} in fp64, summed in a fixed order (bit-reproducible).  ws: bf_field_stats_ws_doubles(nseg) doubles. */

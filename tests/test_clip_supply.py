@@ -152,6 +152,18 @@ def test_device_gather_is_bit_identical_to_host_collate(tmp_path, norm, ds):
     assert torch.equal(inp2, inp) and torch.equal(out2, out) and torch.equal(fp2, fp)
     with pytest.raises(IndexError):
         store.gather([n])
+    # the batch entry point is ONE launch; the two single-clip launches with framework indexing in front give the same bits
+    from bubbleformer_amd import ops
+    first_all, file_all = store._index_tables()
+    dev_idx = torch.tensor(idx, device="cuda")
+    ho, wo = inp.shape[-2:]
+    a = ops.clip_gather(store.frames, first_all[dev_idx], 0, d.time_window, store.in_tab, ho, wo)
+    b = ops.clip_gather(store.frames, first_all[dev_idx], d.time_window, d.time_window, store.out_tab, ho, wo)
+    assert torch.equal(a, inp) and torch.equal(b, out) and torch.equal(store.fluid[file_all[dev_idx]], fp)
+    # an index out of range on the device path is clamped inside the kernel (it cannot be checked without a host synchronisation)
+    bad = store.gather(torch.tensor([n + 5, -3], device="cuda"))
+    ok = store.gather(torch.tensor([n - 1, 0], device="cuda"))
+    assert all(torch.equal(x, y) for x, y in zip(bad, ok))
 
 
 @pytest.mark.gpu
