@@ -71,6 +71,11 @@ def _product(B, T, H, W, seed, dtype):
     return pred.detach().cpu(), float(loss.detach()), x.grad.detach().cpu(), {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
 
 
+# bf16 throughput mode at FULL depth: every gradient family must also POINT the way the oracle's does (measured worst: 0.968 at 8x96x96 --
+# blocks.3.temporal.attn_scale_factor, 6 values -- and 0.923 at 16x192x192 -- film_embed.film_net.1.weight, whose gradient passes through all 12 blocks)
+BF16_FAMILY_COSINE = 0.9
+
+
 def _compare(prod, orac, dtype):
     pred, loss, dx, grads = prod
     pred_o, loss_o, dx_o, grads_o = orac
@@ -81,6 +86,7 @@ def _compare(prod, orac, dtype):
     assert abs(loss - loss_o) / abs(loss_o) < ft
     assert rel_l2(dx, dx_o) < (1e-4 if f32 else 2e-1)
     num = den = 0.0
+    worst_cos = (1.0, "")
     gscale = max(float(g.norm()) for g in grads_o.values())
     for k, g in grads.items():
         ref = grads_o[k]
@@ -90,6 +96,12 @@ def _compare(prod, orac, dtype):
             assert float(g.norm()) <= (1e-5 if f32 else 1e-2) * gscale, k
         else:
             assert rel_l2(g, ref) < (gt if f32 else 0.9), k
+            if not f32 and float(ref.norm()) > 1e-6 * gscale:      # direction of every gradient family at full depth, not only its size
+                cos = float(torch.nn.functional.cosine_similarity(g.double().flatten(), ref.double().flatten(), dim=0))
+                worst_cos = min(worst_cos, (cos, k))
+    if not f32:
+        print("worst gradient-family cosine against the oracle", worst_cos)
+        assert worst_cos[0] > BF16_FAMILY_COSINE, worst_cos
     assert (num / den) ** 0.5 < gt
 
 
