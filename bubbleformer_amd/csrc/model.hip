@@ -266,31 +266,39 @@ __global__ void outproj_finalize_kernel(const float* __restrict__ G, const float
                                         float* __restrict__ dlo, float* __restrict__ dhi, int E) {
     __shared__ float red[4];
     __shared__ float s_dmc, s_alpha;
-    if ((int)blockIdx.x >= E) {      // extra workgroups (feature scaling only): dnb[k] += sum_n dmc[n] * W[n][k], 64 columns each -- dmc[n] =
+    if ((int)blockIdx.x >= E) {      // extra workgroups (feature scaling only): dnb[k] += sum_n dmc[n] * W[n][k], 16 columns each -- dmc[n] =
         // csum[n] * gamma[n] * (lo[n] - hi[n]) needs nothing the row workgroups compute, and one writer per column replaces E x E float
         // atomics on E addresses (the launch took 14 us with them)
-        __shared__ float part[4][64];
+        // 16 columns x 16 row groups per workgroup (row group q: rows q, q + 16, ...): with 64 columns x 4 row groups a thread walked 96 rows in
+        // twelve dependent batches of eight loads, ~24 us on six workgroups while the rest of the launch took 5 -- the whole launch waited
+        // for them (26 us, 24 times a step on the side queue).  Now three batches.
+        __shared__ float part[16][16];
         __shared__ float coef[1024];           // dmc[n] (E <= 1024: host-checked)
         for (int n = threadIdx.x; n < E; n += blockDim.x) coef[n] = csum[n] * gamma[n] * (lo[n] - hi[n]);
         __syncthreads();
-        const int k = ((int)blockIdx.x - E) * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+        const int c = threadIdx.x & 15, k = ((int)blockIdx.x - E) * 16 + c, q = threadIdx.x >> 4;
         float a = 0.f;
         if (k < E) {
             int n = q;
-            for (; n + 28 < E; n += 32) {      // eight rows of W in flight per thread (a load-then-add loop pays a round trip per row)
+            for (; n + 112 < E; n += 128) {      // eight rows of W in flight per thread (a load-then-add loop pays a round trip per row)
                 float wv[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) wv[u] = W[(long)(n + 4 * u) * E + k];
+                for (int u = 0; u < 8; ++u) wv[u] = W[(long)(n + 16 * u) * E + k];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) a = fmaf(coef[n + 4 * u], wv[u], a);
+                for (int u = 0; u < 8; ++u) a = fmaf(coef[n + 16 * u], wv[u], a);
             }
-            for (; n < E; n += 4) a = fmaf(coef[n], W[(long)n * E + k], a);
+            for (; n < E; n += 16) a = fmaf(coef[n], W[(long)n * E + k], a);
         }
-        part[q][threadIdx.x & 63] = a;
+        part[q][c] = a;
         __syncthreads();
         // one atomic per column: the caller's stream adds norm2's own bias gradient to the same addresses at the same time (the stage's
         // InReduceJob) -- two addends on a zeroed slot give the same bits in either order, a plain += could lose one of them
-        if (q == 0 && k < E) atomicAdd(dnb + k, (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
+        if (q == 0 && k < E) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t += part[i][c];      // fixed order
+            atomicAdd(dnb + k, t);
+        }
         return;
     }
     const int n = blockIdx.x;
@@ -685,7 +693,7 @@ int outproj_bwd(const D& d, const Scratch& sc, const void* dout, const void* on,
     // the stage's last such launch on the side stream (or flush the sum themselves when nothing followed)
     fk.run_late([=](hipStream_t ss) -> int {
         if (bf_gemm_tokred_pending_out() == sc.G) TRY(bf_gemm_tokred_flush(ss));
-        hipLaunchKernelGGL(outproj_finalize_kernel, dim3(d.E + (lo ? bf_cdiv(d.E, 64) : 0)), dim3(256), 0, ss, sc.G, sc.csum, W, bias, nb, gamma, lo, hi, mc,
+        hipLaunchKernelGGL(outproj_finalize_kernel, dim3(d.E + (lo ? bf_cdiv(d.E, 16) : 0)), dim3(256), 0, ss, sc.G, sc.csum, W, bias, nb, gamma, lo, hi, mc,
                            dW, dbias, dnb, dgamma, dlo, dhi, d.E);
         BF_CHECK_LAUNCH();
         return 0;
