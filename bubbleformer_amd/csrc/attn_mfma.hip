@@ -1035,7 +1035,7 @@ int go_bwd_mode(const bf16* qkv, const bf16* dout, bf16* dqkv, Geo g, int heads,
     if (rows_out) { *rows_out = ws ? (int)grid : 0; return 0; }       // the caller reduces the workspace rows later (AttnReduceJob)
     if (ws) {
         const AttnReduceJob j{ws, (int)grid, D, heads, gr.dqw, gr.dqb, gr.dkw, gr.dkb, gr.demb, gr.dhscale};
-        hipLaunchKernelGGL(attn_ws_reduce, dim3(bf_cdiv(nvals, 64), 16), dim3(256), 0, st, j);
+        hipLaunchKernelGGL(attn_ws_reduce, dim3(bf_cdiv(nvals, 64), 1), dim3(256), 0, st, j);      // one row slice: one writer per value
         BF_CHECK_LAUNCH();
     }
     return 0;

@@ -331,33 +331,42 @@ __global__ void __launch_bounds__(256) tokred_narrow_kernel(const bf16* __restri
         const s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, r);
     };
-    if (t_beg < t_end) issue(t_beg, 0);
-    int slot = 0;
+    // The tile loop waits by COUNT for its own LDS-DMA pieces, so nothing else may sit in the vector-memory queue while it runs: the
+    // frame's scale / shift (ordinary loads to registers) are fetched BETWEEN loops -- a wave's tile range is cut at frame boundaries, and
+    // each segment starts with an empty queue (drain, load, drain) and restarts the two-slot pipeline.  (With the loads inside the loop
+    // -- issued when a tile crossed into a new frame, ordered only by hipcc's own vmcnt bookkeeping, which does not see the DMAs -- the
+    // second channel block of the last debed stage's weight gradient came out 1-2 % off and different from run to run.)
     float scv[CT], shv[CT];
-    long frame = -1;
-    for (long t = t_beg; t < t_end; ++t) {
+    for (long s_beg = t_beg; s_beg < t_end;) {
+        long s_end = t_end;
         if constexpr (PRO) {
-            const long f = t / tiles_per_frame;          // wave-uniform
-            if (f != frame) {
-                frame = f;
+            const long f = s_beg / tiles_per_frame;          // wave-uniform
+            s_end = min(t_end, (f + 1) * (long)tiles_per_frame);
+            wait_vm<0>();
 #pragma unroll
-                for (int i = 0; i < CT; ++i) { scv[i] = psc[f * C + 16 * i + (lane & 15)]; shv[i] = psh ? psh[f * C + 16 * i + (lane & 15)] : 0.f; }
-            }
+            for (int i = 0; i < CT; ++i) { scv[i] = psc[f * C + 16 * i + (lane & 15)]; shv[i] = psh ? psh[f * C + 16 * i + (lane & 15)] : 0.f; }
+#pragma unroll
+            for (int i = 0; i < CT; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(scv[i]), "+v"(shv[i]) :: "memory");      // operands: the loads cannot sink below
         }
-        if (t + 1 < t_end) { issue(t + 1, slot ^ 1); wait_vm<PCS>(); } else wait_vm<0>();
-        const unsigned tb = lds0 + (unsigned)slot * (unsigned)TB_;
-        const bf16x8 fx = trf(tb + offX, 4 * 32);
+        issue(s_beg, 0);
+        int slot = 0;
+        for (long t = s_beg; t < s_end; ++t) {
+            if (t + 1 < s_end) { issue(t + 1, slot ^ 1); wait_vm<PCS>(); } else wait_vm<0>();
+            const unsigned tb = lds0 + (unsigned)slot * (unsigned)TB_;
+            const bf16x8 fx = trf(tb + offX, 4 * 32);
 #pragma unroll
-        for (int i = 0; i < CT; ++i) {
-            bf16x8 fd = trf(tb + offD + (unsigned)(i * 32), 4 * C * 2);
-            if constexpr (PRO) {
+            for (int i = 0; i < CT; ++i) {
+                bf16x8 fd = trf(tb + offD + (unsigned)(i * 32), 4 * C * 2);
+                if constexpr (PRO) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) fd[j] = (bf16)gelu_fast(fmaf((float)fd[j], scv[i], shv[i]));
+                    for (int j = 0; j < 8; ++j) fd[j] = (bf16)gelu_fast(fmaf((float)fd[j], scv[i], shv[i]));
+                }
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx, fd, acc[i], 0, 0, 0);      // acc[i][r]: dW[16 i + (lane & 15)][4 (lane >> 4) + r]
             }
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx, fd, acc[i], 0, 0, 0);      // acc[i][r]: dW[16 i + (lane & 15)][4 (lane >> 4) + r]
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads of this slot are done before the next iteration's DMA may refill it
+            slot ^= 1;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads of this slot are done before the next iteration's DMA may refill it
-        slot ^= 1;
+        s_beg = s_end;
     }
     // ---- the workgroup's four partial results -> one slab row [C][16], summed in wave order
     __syncthreads();

@@ -574,7 +574,7 @@ __global__ void __launch_bounds__(256) stage_param_reduce_kernel(ReduceJobs J) {
     } else {
         const AttnReduceJob& j = J.at[z - J.n_in];
         const int nvals = 4 * j.D + 32 * j.heads + j.heads;
-        if ((int)blockIdx.x < (nvals + 63) / 64 && blockIdx.y < 16) attn_reduce_block(j, blockIdx.x, blockIdx.y, 16, red);
+        if ((int)blockIdx.x < (nvals + 63) / 64 && blockIdx.y == 0) attn_reduce_block(j, blockIdx.x, 0, 1, red);
     }
 }
 int launch_reduce_jobs(ReduceJobs& J, hipStream_t st) {
@@ -584,7 +584,7 @@ int launch_reduce_jobs(ReduceJobs& J, hipStream_t st) {
     if (J.n_in + J.n_attn == 0) return 0;
     int gx = 1, gy = 1;
     for (int i = 0; i < J.n_in; ++i) { gx = std::max(gx, bf_cdiv(J.in[i].C, 64)); gy = std::max(gy, bf_cdiv(J.in[i].frames, J.in[i].rdiv())); }
-    for (int i = 0; i < J.n_attn; ++i) { gx = std::max(gx, bf_cdiv(4 * J.at[i].D + 33 * J.at[i].heads, 64)); gy = std::max(gy, 16); }
+    for (int i = 0; i < J.n_attn; ++i) { gx = std::max(gx, bf_cdiv(4 * J.at[i].D + 33 * J.at[i].heads, 64)); }
     hipLaunchKernelGGL(stage_param_reduce_kernel, dim3(gx, gy, J.n_in + J.n_attn), dim3(256), 0, st, J);
     BF_CHECK_LAUNCH();
     return 0;

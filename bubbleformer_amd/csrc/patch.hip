@@ -570,33 +570,44 @@ __global__ void film_net_fwd_kernel(const float* __restrict__ cond, const float*
         }
     }
 }
-// dgb: [B][2E] (dgamma | dbeta).  Single block.  dW[o][i] += sum_b dgb[b][o] c[b][i]; dbias[o] += sum_b dgb;
+// dgb: [B][2E] (dgamma | dbeta).  dW[o][i] += sum_b dgb[b][o] c[b][i]; dbias[o] += sum_b dgb;
 // dc[b][i] = sum_o dgb[b][o] W[o][i]; dlnw[i] += sum_b dc*chat; dlnb[i] += sum_b dc   (d cond is not needed)
 __global__ void film_net_bwd_kernel(const float* __restrict__ dgb_, const float* __restrict__ chat, const float* __restrict__ lnw,
                                     const float* __restrict__ lnb, const float* __restrict__ W, float* __restrict__ dW,
                                     float* __restrict__ dbias, float* __restrict__ dlnw, float* __restrict__ dlnb, int B, int P, int E2) {
-    // one thread per output row o of the Linear: dW[o][:], dbias[o], and its share of dc[b][i] (atomics into dlnw/dlnb)
     const int E = E2 / 2;
-    const int o0 = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = o0 < E2;                 // no early return: the wave reductions below need every lane
-    const int o = valid ? o0 : 0;
     // fp64 accumulation: the LayerNorm(P) gradients are sums of 2E signed terms that largely cancel, and the kernel is tiny
+    if (blockIdx.x == gridDim.x - 1) {
+        // the last workgroup (64 threads): dlnw[i] / dlnb[i], each a sum over ALL outputs o and samples b -- lane l takes o = l, l + 64, ...
+        // in order and the 64 partial sums meet in a fixed butterfly: one writer per value, no float atomics (they used to arrive from
+        // every wave in arrival order: the two gradients differed from run to run)
+        for (int i = 0; i < P; ++i) {
+            double sw = 0.0, sbias = 0.0;
+            for (int o = threadIdx.x; o < E2; o += 64) {
+                const double w = W[(long)o * P + i];
+                for (int b = 0; b < B; ++b) {
+                    const double dg = (double)dgb_[(long)(o / E) * B * E + (long)b * E + (o % E)];
+                    sw += dg * w * chat[b * P + i];
+                    sbias += dg * w;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { sw += __shfl_xor(sw, off, 64); sbias += __shfl_xor(sbias, off, 64); }
+            if (threadIdx.x == 0) { dlnw[i] += (float)sw; dlnb[i] += (float)sbias; }
+        }
+        return;
+    }
+    // one thread per output row o of the Linear: dW[o][:] and dbias[o]
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= E2) return;
     double sb = 0.0;
     for (int b = 0; b < B; ++b) sb += (double)dgb_[(long)(o / E) * B * E + (long)b * E + (o % E)];
-    if (valid) dbias[o] += (float)sb;
+    dbias[o] += (float)sb;
     for (int i = 0; i < P; ++i) {
-        double acc = 0.0, sw = 0.0, sbias = 0.0;
-        const double w = W[(long)o * P + i];
-        for (int b = 0; b < B; ++b) {
-            const double dg = valid ? (double)dgb_[(long)(o / E) * B * E + (long)b * E + (o % E)] : 0.0;
-            acc += dg * ((double)chat[b * P + i] * lnw[i] + lnb[i]);
-            sw += dg * w * chat[b * P + i];
-            sbias += dg * w;
-        }
-        if (valid) dW[(long)o * P + i] += (float)acc;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { sw += __shfl_xor(sw, off, 64); sbias += __shfl_xor(sbias, off, 64); }
-        if ((threadIdx.x & 63) == 0) { atomicAdd(dlnw + i, (float)sw); atomicAdd(dlnb + i, (float)sbias); }
+        double acc = 0.0;
+        for (int b = 0; b < B; ++b)
+            acc += (double)dgb_[(long)(o / E) * B * E + (long)b * E + (o % E)] * ((double)chat[b * P + i] * lnw[i] + lnb[i]);
+        dW[(long)o * P + i] += (float)acc;
     }
 }
 
@@ -834,7 +845,7 @@ extern "C" int bf_film_net_fwd(const float* cond, const float* lnw, const float*
 extern "C" int bf_film_net_bwd(const float* dgb, const float* chat, const float* lnw, const float* lnb, const float* W, float* dW,
                                float* dbias, float* dlnw, float* dlnb, int B, int P, int E2, bf_stream_t stream) {
     BF_REQUIRE(dgb && chat && lnw && lnb && W && dW && dbias && dlnw && dlnb, "bf_film_net_bwd: bad arguments");
-    hipLaunchKernelGGL(film_net_bwd_kernel, dim3(bf_cdiv(E2, 64)), dim3(64), 0, (hipStream_t)stream, dgb, chat, lnw, lnb, W, dW, dbias, dlnw, dlnb, B, P, E2);
+    hipLaunchKernelGGL(film_net_bwd_kernel, dim3(bf_cdiv(E2, 64) + 1), dim3(64), 0, (hipStream_t)stream, dgb, chat, lnw, lnb, W, dW, dbias, dlnw, dlnb, B, P, E2);
     BF_CHECK_LAUNCH();
     return 0;
 }
