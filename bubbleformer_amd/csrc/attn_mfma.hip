@@ -973,8 +973,8 @@ __global__ void __launch_bounds__(256, ((NB == 1 && KS <= 2) ? 2 : 1)) attn_bwd_
 }
 
 // dst += sum over workspace rows (param_reduce.h)
-__global__ void __launch_bounds__(256) attn_ws_reduce(AttnReduceJob j) {
-    __shared__ float red[1][4][64];
+__global__ void __launch_bounds__(64 * BF_RED_FL) attn_ws_reduce(AttnReduceJob j) {
+    __shared__ float red[1][BF_RED_FL][64];
     attn_reduce_block(j, blockIdx.x, blockIdx.y, gridDim.y, red);
 }
 
@@ -1035,7 +1035,7 @@ int go_bwd_mode(const bf16* qkv, const bf16* dout, bf16* dqkv, Geo g, int heads,
     if (rows_out) { *rows_out = ws ? (int)grid : 0; return 0; }       // the caller reduces the workspace rows later (AttnReduceJob)
     if (ws) {
         const AttnReduceJob j{ws, (int)grid, D, heads, gr.dqw, gr.dqb, gr.dkw, gr.dkb, gr.demb, gr.dhscale};
-        hipLaunchKernelGGL(attn_ws_reduce, dim3(bf_cdiv(nvals, 64), 1), dim3(256), 0, st, j);      // one row slice: one writer per value
+        hipLaunchKernelGGL(attn_ws_reduce, dim3(bf_cdiv(nvals, 64), 1), dim3(64 * BF_RED_FL), 0, st, j);      // one row slice: one writer per value
         BF_CHECK_LAUNCH();
     }
     return 0;

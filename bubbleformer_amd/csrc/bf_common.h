@@ -56,6 +56,8 @@ int bf_wprep_multi(int dtype, int n, const int* mode, const float* const* src, v
 int bf_frame_scale(int dtype, const void* z, const float* m, int fdiv, void* out, long nrows, int S, int C, hipStream_t st);
 
 // narrow weight-gradient stream dW[C][16] = act(wide)^T narrow, or its transpose (gemm_tokred.hip; internal): 0 = handled, 1 = shape not covered
+int bf_gemm_slabs(int dtype, int M, int N, int K, const bf_operand* A, const bf_operand* B, float* out, long ldc, int accumulate, int splitk,
+                  float* ws, long ws_floats, hipStream_t st);      // gemm.hip: split-K into per-slice images + ordered sum (no float atomics)
 int bf_tokred_narrow(int dtype, int C, int64_t P, const void* wide, const void* narrow, float* out, int ldo, int accumulate, int transposed,
                      const float* sc, const float* sh, int64_t rows_per_frame, float* ws, int64_t ws_floats, hipStream_t st);
 // frame-pair data-gradient GEMM with a second, row-scaled output (gemm_frame.hip; internal): 0 = handled, 1 = shape not covered

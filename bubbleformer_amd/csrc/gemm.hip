@@ -345,6 +345,12 @@ __global__ void __launch_bounds__(NT) gemm_kernel(int M, int N, int K, OpDev A, 
     }
     // ------------------------------------------------------------------ epilogue (row-major through LDS)
     if ((dbg & 1) && acc[0][0][0] != 12345.678f) return;     // timing experiment: skip the epilogue
+    if (AXC && E.zstride) {      // split-K into slabs (bf_gemm_slabs): this K-slice's own [M][ldc] image -- one addend per element, summed in slice order later
+        EpiDev Ez = E;
+        Ez.c = reinterpret_cast<float*>(E.c) + (long)zt * E.zstride;
+        epilogue_rows<T, TM, TN, 2, WN, AXC>(acc, Ez, M, N, m0, n0, reinterpret_cast<float*>(lds), tid);
+        return;
+    }
     epilogue_rows<T, TM, TN, 2, WN, AXC>(acc, E, M, N, m0, n0, reinterpret_cast<float*>(lds), tid);
 }
 
@@ -357,7 +363,7 @@ OpDev to_dev(const bf_operand* o) {
 }
 
 template <typename T>
-int launch(int M, int N, int K, const bf_operand* A, const bf_operand* B, const bf_epilogue* E, int splitk, hipStream_t st) {
+int launch(int M, int N, int K, const bf_operand* A, const bf_operand* B, const bf_epilogue* E, int splitk, hipStream_t st, long zstride = 0, int* splits_out = nullptr) {
     constexpr int BK = GemmCfg<T>::BK;
     OpDev a = to_dev(A), b = to_dev(B);
     EpiDev e;
@@ -369,6 +375,8 @@ int launch(int M, int N, int K, const bf_operand* A, const bf_operand* B, const 
     if (splitk > ktiles) splitk = ktiles;
     const int kper = bf_cdiv(ktiles, splitk) * BK;
     splitk = bf_cdiv(K, kper);
+    e.zstride = zstride;
+    if (splits_out) *splits_out = splitk;
     const int nt = bf_cdiv(N, BN);
     static const int small_env = bf_knob("BF_GEMM_SMALL", -1);
     // measured: with 8-wave workgroups the 128 x 128 tile beats 64 x 128 even on grids of < 2 workgroups per CU
@@ -458,4 +466,45 @@ extern "C" int bf_gemm(int dtype, int M, int N, int K, const bf_operand* A, cons
     if (dtype == BF_DTYPE_BF16) return launch<bf16>(M, N, K, A, B, E, splitk, st);
     if (dtype == BF_DTYPE_F32) return launch<float>(M, N, K, A, B, E, splitk, st);
     return bf_fail_msg("bf_gemm: unknown dtype", __FILE__, __LINE__);
+}
+
+// ---- split-K without float atomics on shared addresses (library-internal; bf_common.h).  The token-reduction form of bf_gemm with
+// out = [M][ldc] fp32, C (+)= sum over K-slices: every slice adds its tile into ITS OWN zeroed image in `ws` (one addend per element: the
+// atomic is a plain add there) and a second small kernel sums the images in slice order -- the same bits every run.  Returns 1 (nothing
+// launched) when the workspace is too small; the caller then runs bf_gemm with its atomics.
+namespace {
+__global__ void __launch_bounds__(256) slab_sum_kernel(const float* __restrict__ ws, long n4, int splits, long zstride, float* __restrict__ out, int accumulate) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 a = accumulate ? reinterpret_cast<const float4*>(out)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s0 = 0; s0 < splits; s0 += 8) {          // eight slices in flight
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = s0 + u < splits ? reinterpret_cast<const float4*>(ws + (long)(s0 + u) * zstride)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+    }
+    reinterpret_cast<float4*>(out)[i] = a;
+}
+}  // namespace
+int bf_gemm_slabs(int dtype, int M, int N, int K, const bf_operand* A, const bf_operand* B, float* out, long ldc, int accumulate, int splitk,
+                  float* ws, long ws_floats, hipStream_t st) {
+    BF_REQUIRE(A && B && out && ws && A->layout == BF_LAY_XC && ldc % 4 == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)ws & 15) == 0, "bf_gemm_slabs: bad arguments");
+    constexpr int BK = 64;
+    int s = splitk < 1 ? 1 : splitk;
+    const int ktiles = bf_cdiv(K, BK);
+    if (s > ktiles) s = ktiles;
+    s = bf_cdiv(K, bf_cdiv(ktiles, s) * BK);          // the slice count launch() settles on
+    const long zstride = (long)M * ldc;
+    if ((long)s * zstride > ws_floats) return 1;
+    if (hipMemsetAsync(ws, 0, (size_t)s * zstride * 4, st) != hipSuccess) return bf_fail_msg("bf_gemm_slabs: memset failed", __FILE__, __LINE__);
+    bf_epilogue e = {};
+    e.out_mode = BF_OUT_ATOMIC_F32; e.c = ws; e.ldc = ldc;
+    int splits = 0;
+    const int rc = dtype == BF_DTYPE_BF16 ? launch<bf16>(M, N, K, A, B, &e, s, st, zstride, &splits) : launch<float>(M, N, K, A, B, &e, s, st, zstride, &splits);
+    if (rc) return rc;
+    const long n4 = zstride / 4;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)bf_cdiv(n4, 256)), dim3(256), 0, st, ws, n4, splits, zstride, out, accumulate);
+    BF_CHECK_LAUNCH();
+    return 0;
 }

@@ -17,6 +17,7 @@ struct OpDev {
 struct EpiDev {
     const float* bias; const float* colscale; const float* colshift; int aux_mode; const void* aux; long ld_aux;
     int out_mode; void* c; long ldc; int seglen; long segstride; int gw, gh, gc; void* gelu_out; float* colsum; const float* rowscale; int rpg;
+    long zstride;      // split-K into slabs: K-slice z adds into c + z * zstride floats (0: every slice into c itself)
 };
 
 __device__ __forceinline__ long row_base(int row, long ld, int gw, int gh, int gc) {

@@ -565,8 +565,8 @@ struct Scratch {
 // All InstanceNorm / attention parameter-gradient reductions of one stage backward in ONE launch (grid z = job): nothing on the
 // critical path reads them, and eight dependent ~5 us launches per block are worth ~3 % of the step.
 struct ReduceJobs { int n_in = 0, n_attn = 0; InReduceJob in[6]; AttnReduceJob at[4]; };      // room for a spatial + a temporal stage (see g_pending_reduce.get())
-__global__ void __launch_bounds__(256) stage_param_reduce_kernel(ReduceJobs J) {
-    __shared__ float red[5][4][64];
+__global__ void __launch_bounds__(64 * BF_RED_FL) stage_param_reduce_kernel(ReduceJobs J) {
+    __shared__ float red[5][BF_RED_FL][64];
     const int z = blockIdx.z;
     if (z < J.n_in) {
         const InReduceJob& j = J.in[z];
@@ -585,7 +585,7 @@ int launch_reduce_jobs(ReduceJobs& J, hipStream_t st) {
     int gx = 1, gy = 1;
     for (int i = 0; i < J.n_in; ++i) { gx = std::max(gx, bf_cdiv(J.in[i].C, 64)); gy = std::max(gy, bf_cdiv(J.in[i].frames, J.in[i].rdiv())); }
     for (int i = 0; i < J.n_attn; ++i) { gx = std::max(gx, bf_cdiv(4 * J.at[i].D + 33 * J.at[i].heads, 64)); }
-    hipLaunchKernelGGL(stage_param_reduce_kernel, dim3(gx, gy, J.n_in + J.n_attn), dim3(256), 0, st, J);
+    hipLaunchKernelGGL(stage_param_reduce_kernel, dim3(gx, gy, J.n_in + J.n_attn), dim3(64 * BF_RED_FL), 0, st, J);
     BF_CHECK_LAUNCH();
     return 0;
 }
@@ -1646,13 +1646,19 @@ extern "C" int bf_embed_bwd(const bf_dims* dims, const bf_embed_params* p, const
         if (wrc < 0) return wrc;
         if (wrc == 1 && reb) return bf_fail_msg("bf_embed_bwd: the rebuilt-rows weight gradient declined a shape the lean path was chosen for", __FILE__, __LINE__);
         if (wrc == 1) {
-            ZERO_ON(ss, sc.wg, (size_t)sv.C[i] * K4 * 4);
             bf_operand A = op_plain(dy, sv.C[i], BF_LAY_XC);
             bf_operand Bo = op_plain(sv.y[i - 1], cp, BF_LAY_XC);
             op_gather(Bo, sv.gw[i], sv.gh[i], cp);
             op_affine(Bo, BF_PRO_AFFINE_GELU, sv.sc[i - 1], sv.sh[i - 1], rpf, cp);
-            bf_epilogue e = epi_atomic(sc.wg, K4);
-            TRY(bf_gemm(d.dtype, sv.C[i], K4, (int)sv.P[i], &A, &Bo, &e, splitk_for(sv.C[i], K4, sv.P[i]), ss));
+            // split-K into per-slice images summed in order (no float atomics on shared addresses: the same bits every run); atomics only
+            // where the workspace cannot hold the images
+            const int src = bf_gemm_slabs(d.dtype, sv.C[i], K4, (int)sv.P[i], &A, &Bo, sc.wg, K4, 0, splitk_for(sv.C[i], K4, sv.P[i]), (float*)sc.t1b, sc.t1b_floats, ss);
+            if (src < 0) return src;
+            if (src == 1) {
+                ZERO_ON(ss, sc.wg, (size_t)sv.C[i] * K4 * 4);
+                bf_epilogue e = epi_atomic(sc.wg, K4);
+                TRY(bf_gemm(d.dtype, sv.C[i], K4, (int)sv.P[i], &A, &Bo, &e, splitk_for(sv.C[i], K4, sv.P[i]), ss));
+            }
         }
         TRY(bf_wgrad_unprep(1, sc.wg, g->conv_w[i], sv.C[i], K4, K4, 0, ss));
         if (i == 1 && !dx_in) {
@@ -1854,13 +1860,17 @@ extern "C" int bf_debed_bwd(const bf_dims* dims, const bf_debed_params* p, const
                                                     cin, (float*)sc.t1b, sc.t1b_floats, ss) : 1;
             if (wrc < 0) return wrc;
             if (wrc == 1) {
-                ZERO_ON(ss, sc.wg, (size_t)N4 * cin * 4);
                 bf_operand A = op_plain(dy, co, BF_LAY_XC);
                 op_gather(A, sv.gw[i], sv.gh[i], co);
                 bf_operand Bo = op_plain(ain, cin, BF_LAY_XC);
                 if (i > 0) op_affine(Bo, BF_PRO_AFFINE_GELU, sv.sc[i - 1], sv.sh[i - 1], rpf, cin);
-                bf_epilogue e = epi_atomic(sc.wg, cin);
-                TRY(bf_gemm(d.dtype, N4, cin, (int)sv.Pin[i], &A, &Bo, &e, splitk_for(N4, cin, sv.Pin[i]), ss));
+                const int src = bf_gemm_slabs(d.dtype, N4, cin, (int)sv.Pin[i], &A, &Bo, sc.wg, cin, 0, splitk_for(N4, cin, sv.Pin[i]), (float*)sc.t1b, sc.t1b_floats, ss);      // (see bf_embed_bwd)
+                if (src < 0) return src;
+                if (src == 1) {
+                    ZERO_ON(ss, sc.wg, (size_t)N4 * cin * 4);
+                    bf_epilogue e = epi_atomic(sc.wg, cin);
+                    TRY(bf_gemm(d.dtype, N4, cin, (int)sv.Pin[i], &A, &Bo, &e, splitk_for(N4, cin, sv.Pin[i]), ss));
+                }
             }
             TRY(bf_wgrad_unprep(2, sc.wg, g->conv_w[i], N4, cin, cin, 0, ss));
             {

@@ -567,8 +567,8 @@ __global__ void __launch_bounds__(NT) in_slice_sum_kernel(const float* __restric
 }
 
 // parameter gradients from the per-frame partials ws[f][c] = {s1, s2}: see param_reduce.h
-__global__ void __launch_bounds__(NT) in_param_reduce_kernel(InReduceJob j) {
-    __shared__ float red[5][4][64];
+__global__ void __launch_bounds__(64 * BF_RED_FL) in_param_reduce_kernel(InReduceJob j) {
+    __shared__ float red[5][BF_RED_FL][64];
     in_reduce_block(j, blockIdx.x, blockIdx.y, red);
 }
 
@@ -792,7 +792,7 @@ static int in_bwd_impl(int dtype, const void* dy, const void* x, const void* add
     }
     if (ws && reduce) {
         const InReduceJob j{ws, frames, C, w, b, g, gdiv, dw, db, dg, dgb, nullptr, nullptr};
-        hipLaunchKernelGGL(in_param_reduce_kernel, dim3(bf_cdiv(C, 64), bf_cdiv(frames, j.rdiv())), dim3(NT), 0, st, j);
+        hipLaunchKernelGGL(in_param_reduce_kernel, dim3(bf_cdiv(C, 64), bf_cdiv(frames, j.rdiv())), dim3(64 * BF_RED_FL), 0, st, j);
         BF_CHECK_LAUNCH();
     }
     return 0;

@@ -442,8 +442,8 @@ __global__ void __launch_bounds__(NT) dl_slice_sum_kernel(const float* __restric
     reinterpret_cast<float2*>(tot)[(long)f * C + c] = make_float2((red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]),
                                                                  (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]));
 }
-__global__ void __launch_bounds__(NT) dl_param_reduce_kernel(InReduceJob j) {
-    __shared__ float red[5][4][64];
+__global__ void __launch_bounds__(64 * BF_RED_FL) dl_param_reduce_kernel(InReduceJob j) {
+    __shared__ float red[5][BF_RED_FL][64];
     in_reduce_block(j, blockIdx.x, blockIdx.y, red);
 }
 // loss = sum_c mean_f sqrt(num/den);  coef[f][c] = 1 / (F * sqrt(num) * sqrt(den))   (single block)
@@ -577,11 +577,13 @@ __global__ void film_net_bwd_kernel(const float* __restrict__ dgb_, const float*
                                     float* __restrict__ dbias, float* __restrict__ dlnw, float* __restrict__ dlnb, int B, int P, int E2) {
     const int E = E2 / 2;
     // fp64 accumulation: the LayerNorm(P) gradients are sums of 2E signed terms that largely cancel, and the kernel is tiny
-    if (blockIdx.x == gridDim.x - 1) {
-        // the last workgroup (64 threads): dlnw[i] / dlnb[i], each a sum over ALL outputs o and samples b -- lane l takes o = l, l + 64, ...
-        // in order and the 64 partial sums meet in a fixed butterfly: one writer per value, no float atomics (they used to arrive from
-        // every wave in arrival order: the two gradients differed from run to run)
-        for (int i = 0; i < P; ++i) {
+    const int nmain = ((E2 + 63) / 64);
+    if ((int)blockIdx.x >= nmain) {
+        // P more workgroups (64 threads), one per LayerNorm input i: dlnw[i] / dlnb[i], each a sum over ALL outputs o and samples b -- lane l
+        // takes o = l, l + 64, ... in order and the 64 partial sums meet in a fixed butterfly: one writer per value, no float atomics (they
+        // used to arrive from every wave in arrival order: the two gradients differed from run to run)
+        {
+            const int i = (int)blockIdx.x - nmain;
             double sw = 0.0, sbias = 0.0;
             for (int o = threadIdx.x; o < E2; o += 64) {
                 const double w = W[(long)o * P + i];
@@ -766,7 +768,7 @@ extern "C" int bf_debed_last_bwd_norm(int dtype, const float* dpred, const float
     }
     if (d_in_w || d_in_b) {
         const InReduceJob j{tot, frames, Ci, in_w, in_b, nullptr, 1, d_in_w, d_in_b, nullptr, nullptr, nullptr, nullptr};
-        hipLaunchKernelGGL(dl_param_reduce_kernel, dim3(bf_cdiv(Ci, 64), bf_cdiv(frames, j.rdiv())), dim3(NT), 0, st, j);
+        hipLaunchKernelGGL(dl_param_reduce_kernel, dim3(bf_cdiv(Ci, 64), bf_cdiv(frames, j.rdiv())), dim3(64 * BF_RED_FL), 0, st, j);
         BF_CHECK_LAUNCH();
     }
     return 0;
@@ -845,7 +847,7 @@ extern "C" int bf_film_net_fwd(const float* cond, const float* lnw, const float*
 extern "C" int bf_film_net_bwd(const float* dgb, const float* chat, const float* lnw, const float* lnb, const float* W, float* dW,
                                float* dbias, float* dlnw, float* dlnb, int B, int P, int E2, bf_stream_t stream) {
     BF_REQUIRE(dgb && chat && lnw && lnb && W && dW && dbias && dlnw && dlnb, "bf_film_net_bwd: bad arguments");
-    hipLaunchKernelGGL(film_net_bwd_kernel, dim3(bf_cdiv(E2, 64) + 1), dim3(64), 0, (hipStream_t)stream, dgb, chat, lnw, lnb, W, dW, dbias, dlnw, dlnb, B, P, E2);
+    hipLaunchKernelGGL(film_net_bwd_kernel, dim3(bf_cdiv(E2, 64) + P), dim3(64), 0, (hipStream_t)stream, dgb, chat, lnw, lnb, W, dW, dbias, dlnw, dlnb, B, P, E2);
     BF_CHECK_LAUNCH();
     return 0;
 }

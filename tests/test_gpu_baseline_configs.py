@@ -758,3 +758,34 @@ def test_native_trunk_call_and_folded_slab_sums_change_no_bit(monkeypatch):
             a = g1[off:off + p.numel()]
             assert torch.equal(a, g2[off:off + p.numel()]) and torch.equal(a, g3[off:off + p.numel()]), k
         off += n
+
+
+def test_training_step_is_bit_reproducible_run_to_run():
+    """Two identical bf16 training steps at the bench geometry (16 x 192 x 192, stochastic depth on, the deferred two-queue backward the
+    trainer uses): the loss AND every one of the parameter gradients come out with the same bits.  Nothing in the step adds floats in
+    arrival order any more: weight gradients are slab sums in slice order (gemm_tokred.hip, bf_gemm_slabs), the small parameter
+    reductions have one writer per value (param_reduce.h), the loss is an integer sum.  (Round 4 found this the hard way: the check
+    exposed a kernel whose result was not merely re-ordered but WRONG by 1e-4 .. 1e-2 in one channel block -- tokred_narrow's prologue
+    loads inside a loop that waits for LDS-DMA by count.)"""
+    from bubbleformer_amd import ops
+    from bubbleformer_amd.models import get_model
+
+    def grads():
+        torch.manual_seed(5)
+        m = get_model("filmavit", time_window=16, drop_path=0.2, compute_dtype=torch.bfloat16, **dict(SMALL, processor_blocks=4)).cuda().train()
+        x, y, c = (t.cuda() for t in _inputs(2, 16, 192, 192, 21))
+        torch.manual_seed(9)                     # the stochastic-depth draws
+        ops.set_side_defer(True)
+        try:
+            loss, _ = m.forward_loss(x, c, y)
+            loss.backward()
+        finally:
+            ops.set_side_defer(False)
+        torch.cuda.synchronize()
+        return float(loss), {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+    l1, g1 = grads()
+    l2, g2 = grads()
+    assert l1 == l2
+    differing = [k for k in g1 if not torch.equal(g1[k], g2[k])]
+    assert not differing, differing
