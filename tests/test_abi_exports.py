@@ -70,3 +70,26 @@ def test_state_dict_matches_reference_inventory():
     assert list(sd.keys()) == list(shapes.keys()) and len(sd) == 506
     assert sum(v.numel() for v in sd.values()) == 28906602
     assert all(tuple(sd[k].shape) == tuple(shapes[k]) for k in shapes)
+
+
+def test_register_audit_flags_compiler_loads_inside_a_counted_dma_loop(tmp_path):
+    """The second build-time rule (tools/register_audit.py: foreign_loads): a load hipcc issued itself inside the innermost loop that
+    orders LDS-DMA by a hand-counted `s_waitcnt vmcnt(N)` fails the build; the same load in an enclosing loop's own blocks does not
+    (the shape of tokred_narrow_kernel<.., true> before and after the round-4 fix)."""
+    from tools import register_audit
+    dma = ";;#ASMSTART\n\tglobal_load_lds_dwordx4 v[18:19], off\n;;#ASMEND\n"
+    wait = ";;#ASMSTART\n\ts_waitcnt vmcnt(7)\n;;#ASMEND\n"
+    bad = ("_Z3badv:                                ; @_Z3badv\n.LBB0_1:                                ; =>This Inner Loop Header: Depth=1\n"
+           "\tglobal_load_dword v2, v[22:23], off\n" + dma + wait + "\ts_cbranch_vccnz .LBB0_1\n.Lfunc_end0:\n")
+    good = ("_Z4goodv:                               ; @_Z4goodv\n.LBB1_1:                                ; =>This Loop Header: Depth=1\n"
+            "\tglobal_load_dword v2, v[22:23], off\n;;#ASMSTART\n\ts_waitcnt vmcnt(0)\n;;#ASMEND\n"
+            ".LBB1_2:                                ;   Parent Loop BB1_1 Depth=1\n                                        ; =>  This Inner Loop Header: Depth=2\n"
+            + dma + wait + "\ts_cbranch_vccnz .LBB1_2\n; %bb.3:                                ;   in Loop: Header=BB1_1 Depth=1\n\ts_cbranch_vccnz .LBB1_1\n.Lfunc_end1:\n")
+    f = tmp_path / "k.s"
+    f.write_text(bad + good)
+    nested_bad = ("_Z6nestedv:                             ; @_Z6nestedv\n.LBB2_1:                                ; =>This Loop Header: Depth=1\n"
+                  ".LBB2_2:                                ;   Parent Loop BB2_1 Depth=1\n                                        ; =>  This Inner Loop Header: Depth=2\n"
+                  "\tglobal_load_dword v2, v[22:23], off\n" + dma + wait + "\ts_cbranch_vccnz .LBB2_2\n\ts_cbranch_vccnz .LBB2_1\n.Lfunc_end2:\n")
+    f.write_text(bad + good + nested_bad)
+    hits = register_audit.foreign_loads(str(f))
+    assert [k for k, _ in hits] == ["_Z3badv", "_Z6nestedv"], hits

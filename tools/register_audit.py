@@ -6,8 +6,9 @@ a register spill inside such a kernel adds scratch loads / stores to the same co
 covers (EXPERIMENTS.md records a fault from exactly that).  This script reads the per-kernel resource remarks the Makefile leaves
 in csrc/build/<file>.remarks (hipcc -Rpass-analysis=kernel-resource-usage) and FAILS when a kernel compiled from a source file
 that uses counted waits (`wait_vm<`, or `s_waitcnt vmcnt` in inline asm) reports spilled VGPRs or scratch.  Spills in other
-kernels (compiler-ordered waits only) are reported as warnings.  --table prints every kernel (VGPRs, spills, scratch, LDS,
-occupancy).
+kernels (compiler-ordered waits only) are reported as warnings.  It also reads the device assembly the Makefile leaves in
+csrc/build/<file>.s and FAILS when hipcc-issued loads sit inside a loop that waits for LDS-DMA by count (`foreign_loads`).  --table
+prints every kernel (VGPRs, spills, scratch, LDS, occupancy).
 
 usage: python tools/register_audit.py [--table] [--json out.json]"""
 import json
@@ -55,7 +56,7 @@ def parse(path):
         m = re.search(r"remark:\s+(.*?)\s*\[-Rpass-analysis", line)
         if not m:
             continue
-        t = m.group(1)
+        t = re.sub(r"^\S+:\d+:\d+:\s+", "", m.group(1))      # (with -save-temps the location follows the word "remark:")
         if t.startswith("Function Name:"):
             cur = {"mangled": t.split(":", 1)[1].strip()}
             kernels.append(cur)
@@ -97,6 +98,70 @@ def audit():
     return rows, bad, warn, missing
 
 
+def foreign_loads(path):
+    """Kernels of one device assembly file in which hipcc-issued loads (outside ;;#ASMSTART .. ;;#ASMEND) sit inside a LOOP that also
+    holds an LDS-DMA load and a hand-counted `s_waitcnt vmcnt(N)`, N > 0, from inline asm.  Such a loop orders its DMA by counting
+    vector-memory operations; a load the compiler put there is an operation the count does not know -- hipcc waits for it by ITS
+    count, which does not know the DMAs (round 4: tokred_narrow_kernel<.., true> produced a channel block 1-2 % off, differently every
+    run, from exactly this).  Returns [(kernel, first offending line)]."""
+    out = []
+    text = open(path, errors="replace").read()
+    for m in re.finditer(r"^(_Z\S+):[ \t]*(?:;.*)?$", text, re.M):
+        end = text.find(".Lfunc_end", m.end())
+        if end < 0:
+            continue
+        lines = text[m.end():end].split("\n")
+        in_asm, flags = False, []          # per line: (is_asm, text)
+        for l in lines:
+            t = l.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+            flags.append((in_asm, t))
+            if t.startswith(";;#ASMEND"):
+                in_asm = False
+        # hipcc annotates every basic block with the innermost natural loop it belongs to ("=>This Inner Loop Header", "in Loop: Header=BBx_y"):
+        # group the lines by that loop, so that an outer loop's own blocks (per-segment operand fetches on a queue it drains itself --
+        # tokred_narrow_kernel<.., true> after the fix) are not mistaken for the counted loop inside it
+        by_loop, cur = {}, None
+        for i, (asm, t) in enumerate(flags):
+            bm = re.match(r"^(?:\.L(BB\d+_\d+):|; %bb\.\d+:)(.*)$", t)
+            if bm and not asm:
+                rest = bm.group(2)
+                for _, t2 in flags[i + 1:i + 4]:          # a nested header's annotation continues on comment lines ("Parent Loop ..." / "=> This Inner Loop Header")
+                    if not t2.startswith(";") or t2.startswith(";;#") or t2.startswith("; %bb."):
+                        break
+                    rest += " " + t2
+                hm = re.search(r"in Loop: Header=(BB\d+_\d+)", rest)
+                cur = bm.group(1) if (bm.group(1) and "Loop Header" in rest) else (hm.group(1) if hm else None)
+                continue
+            if cur is not None:
+                by_loop.setdefault(cur, []).append((asm, t))
+        hit = None
+        for body in by_loop.values():
+            dma = any(asm and re.match(r"^(global_load_lds|buffer_load\S* .*\blds\b)", t) for asm, t in body)
+            counted = any(asm and re.match(r"^s_waitcnt vmcnt\(([1-9]\d*)\)", t) for asm, t in body)
+            if not (dma and counted):
+                continue
+            for asm, t in body:
+                if not asm and re.match(r"^(global_load_|buffer_load_|flat_load_|scratch_load_)", t) and "lds" not in t:
+                    hit = t
+                    break
+            if hit:
+                break
+        if hit:
+            out.append((m.group(1), hit))
+    return out
+
+
+def audit_foreign_loads():
+    bad = []
+    for f in sorted(os.listdir(BUILD)):
+        if f.endswith(".s"):
+            for k, line in foreign_loads(os.path.join(BUILD, f)):
+                bad.append({"file": f[:-2], "kernel": short(demangle([k])[0]), "line": line})
+    return bad
+
+
 def table(rows):
     out = ["| file | kernel | VGPR | AGPR | spilled VGPR | scratch B/lane | LDS B | waves/SIMD | counted vmcnt |", "|---|---|---|---|---|---|---|---|---|"]
     for k in sorted(rows, key=lambda r: (r["file"], r["kernel"])):
@@ -120,6 +185,10 @@ def main(argv):
     for k in bad:
         print("register_audit: FAIL %s.hip `%s`: %d spilled VGPRs, %d B/lane scratch beside hand-counted vmcnt waits" % (
             k["file"], k["kernel"], k.get("vgpr_spill", 0), k.get("scratch", 0)))
+    foreign = audit_foreign_loads()
+    for k in foreign:
+        print("register_audit: FAIL %s.hip `%s`: a compiler-issued load (`%s`) inside a loop that waits for LDS-DMA by count" % (k["file"], k["kernel"], k["line"]))
+    bad = bad + foreign
     n_counted = sum(1 for k in rows if k["counted_waits"])
     print("register_audit: %d kernels, %d in files with counted vmcnt waits, %d failures" % (len(rows), n_counted, len(bad)))
     return 1 if bad else 0
