@@ -93,3 +93,16 @@ def test_register_audit_flags_compiler_loads_inside_a_counted_dma_loop(tmp_path)
     f.write_text(bad + good + nested_bad)
     hits = register_audit.foreign_loads(str(f))
     assert [k for k, _ in hits] == ["_Z3badv", "_Z6nestedv"], hits
+
+
+def test_register_audit_flags_packed_fp32_ops_with_the_low_lane_on_a_high_half(tmp_path):
+    """The third build-time rule (tools/register_audit.py: packed_high_select): `v_pk_fma_f32 .. op_sel:[0,1,1]` (low lane from the high
+    registers of src1 / src2) fails the build -- the form measured wrong in tokred_narrow_kernel<6, true> (EXPERIMENTS.md, round 4);
+    the default selectors, the high-lane selectors and a src0 swap do not."""
+    from tools import register_audit
+    f = tmp_path / "k.s"
+    f.write_text("_Z3badv:                                ; @_Z3badv\n\tv_pk_fma_f32 v[26:27], v[26:27], v[2:3], v[8:9] op_sel:[0,1,1]\n.Lfunc_end0:\n"
+                 "_Z4bad2v:                               ; @_Z4bad2v\n\tv_pk_mul_f32 v[26:27], v[26:27], v[2:3] op_sel:[0,1]\n.Lfunc_end1:\n"
+                 "_Z4goodv:                               ; @_Z4goodv\n\tv_pk_fma_f32 v[34:35], v[22:23], v[2:3], v[8:9] op_sel_hi:[1,0,0]\n"
+                 "\tv_pk_fma_f32 v[136:137], v[150:151], v[220:221], v[136:137] op_sel:[1,0,0] op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 v[2:3], v[4:5], v[6:7], v[8:9]\n.Lfunc_end2:\n")
+    assert [k for k, _ in register_audit.packed_high_select(str(f))] == ["_Z3badv", "_Z4bad2v"]

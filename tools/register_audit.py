@@ -7,7 +7,8 @@ covers (EXPERIMENTS.md records a fault from exactly that).  This script reads th
 in csrc/build/<file>.remarks (hipcc -Rpass-analysis=kernel-resource-usage) and FAILS when a kernel compiled from a source file
 that uses counted waits (`wait_vm<`, or `s_waitcnt vmcnt` in inline asm) reports spilled VGPRs or scratch.  Spills in other
 kernels (compiler-ordered waits only) are reported as warnings.  It also reads the device assembly the Makefile leaves in
-csrc/build/<file>.s and FAILS when hipcc-issued loads sit inside a loop that waits for LDS-DMA by count (`foreign_loads`).  --table
+csrc/build/<file>.s and FAILS when hipcc-issued loads sit inside a loop that waits for LDS-DMA by count (`foreign_loads`), or when a
+packed-fp32 instruction takes its LOW lane's src1 / src2 from the HIGH half of a register pair (`packed_high_select`).  --table
 prints every kernel (VGPRs, spills, scratch, LDS, occupancy).
 
 usage: python tools/register_audit.py [--table] [--json out.json]"""
@@ -153,6 +154,38 @@ def foreign_loads(path):
     return out
 
 
+def packed_high_select(path):
+    """Kernels of one device assembly file that hold a packed-fp32 VALU instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) whose
+    LOW lane takes src1 or src2 from the HIGH register of the pair (`op_sel:[_,1,_]` / `op_sel:[_,_,1]`).  Round 4, at the ISA level
+    (EXPERIMENTS.md): tokred_narrow_kernel<6, true> held four `v_pk_fma_f32 .. v[2:3], v[8:9] op_sel:[0,1,1]` -- the one channel
+    block computed with them came out 1-2 % off, differently every run, whenever two workgroups shared a CU; the same binary with only
+    those four instructions replaced (two v_fma_f32, or the high halves copied to a free pair and the default selectors) is exact and
+    reproducible.  hipcc picks the form when two neighbouring scalars of a register array are broadcast; no kernel of the build needs it.
+    Returns [(kernel, instruction)]."""
+    out = []
+    text = open(path, errors="replace").read()
+    for m in re.finditer(r"^(_Z\S+):[ \t]*(?:;.*)?$", text, re.M):
+        end = text.find(".Lfunc_end", m.end())
+        if end < 0:
+            continue
+        for l in text[m.end():end].split("\n"):
+            t = l.strip()
+            sm = re.match(r"^v_pk_(?:fma|mul|add)_f32 .*\bop_sel:\[([01]),([01])(?:,([01]))?\]", t)
+            if sm and (sm.group(2) == "1" or sm.group(3) == "1"):
+                out.append((m.group(1), t.split("//")[0].strip()))
+                break
+    return out
+
+
+def audit_packed_high_select():
+    bad = []
+    for f in sorted(os.listdir(BUILD)):
+        if f.endswith(".s"):
+            for k, line in packed_high_select(os.path.join(BUILD, f)):
+                bad.append({"file": f[:-2], "kernel": short(demangle([k])[0]), "line": line})
+    return bad
+
+
 def audit_foreign_loads():
     bad = []
     for f in sorted(os.listdir(BUILD)):
@@ -188,7 +221,10 @@ def main(argv):
     foreign = audit_foreign_loads()
     for k in foreign:
         print("register_audit: FAIL %s.hip `%s`: a compiler-issued load (`%s`) inside a loop that waits for LDS-DMA by count" % (k["file"], k["kernel"], k["line"]))
-    bad = bad + foreign
+    packed = audit_packed_high_select()
+    for k in packed:
+        print("register_audit: FAIL %s.hip `%s`: packed fp32 op whose low lane reads the high half of src1 / src2 (`%s`)" % (k["file"], k["kernel"], k["line"]))
+    bad = bad + foreign + packed
     n_counted = sum(1 for k in rows if k["counted_waits"])
     print("register_audit: %d kernels, %d in files with counted vmcnt waits, %d failures" % (len(rows), n_counted, len(bad)))
     return 1 if bad else 0
