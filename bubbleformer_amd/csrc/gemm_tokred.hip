@@ -333,9 +333,10 @@ __global__ void __launch_bounds__(256) tokred_narrow_kernel(const bf16* __restri
     };
     // The tile loop waits by COUNT for its own LDS-DMA pieces, so nothing else may sit in the vector-memory queue while it runs: the
     // frame's scale / shift (ordinary loads to registers) are fetched BETWEEN loops -- a wave's tile range is cut at frame boundaries, and
-    // each segment starts with an empty queue (drain, load, drain) and restarts the two-slot pipeline.  (With the loads inside the loop
-    // -- issued when a tile crossed into a new frame, ordered only by hipcc's own vmcnt bookkeeping, which does not see the DMAs -- the
-    // second channel block of the last debed stage's weight gradient came out 1-2 % off and different from run to run.)
+    // each segment starts with an empty queue (drain, load, drain) and restarts the two-slot pipeline.  (The earlier form, loads inside the
+    // loop, produced a second channel block 1-2 % off and different from run to run: traced at the ISA level to the packed fp32 form hipcc
+    // chose for that block's scale / shift -- v_pk_fma_f32 .. op_sel:[0,1,1], wrong with two workgroups on a CU; EXPERIMENTS.md round 4 --
+    // which tools/register_audit.py now refuses, as it refuses compiler loads inside a counted loop.)
     float scv[CT], shv[CT];
     for (long s_beg = t_beg; s_beg < t_end;) {
         long s_end = t_end;

@@ -103,8 +103,9 @@ def foreign_loads(path):
     """Kernels of one device assembly file in which hipcc-issued loads (outside ;;#ASMSTART .. ;;#ASMEND) sit inside a LOOP that also
     holds an LDS-DMA load and a hand-counted `s_waitcnt vmcnt(N)`, N > 0, from inline asm.  Such a loop orders its DMA by counting
     vector-memory operations; a load the compiler put there is an operation the count does not know -- hipcc waits for it by ITS
-    count, which does not know the DMAs (round 4: tokred_narrow_kernel<.., true> produced a channel block 1-2 % off, differently every
-    run, from exactly this).  Returns [(kernel, first offending line)]."""
+    count, which does not know the DMAs: a load placed BEHIND a DMA loosens the hand count by one.  (The round-4 kernel that prompted the
+    rule, tokred_narrow_kernel<.., true>, turned out to be wrong for another reason -- packed_high_select below; its loads sat in front of
+    the DMAs and only made the counts stricter.)  Returns [(kernel, first offending line)]."""
     out = []
     text = open(path, errors="replace").read()
     for m in re.finditer(r"^(_Z\S+):[ \t]*(?:;.*)?$", text, re.M):
